@@ -1,0 +1,297 @@
+"""Oracle (TEST INFRASTRUCTURE): pure-PyTorch CPU restatement of the ACT Stage-II /
+Stage-I models with injectable randomness.  state_dict keys equal the reference's.
+
+Reference files restated (file:line in /root/reference):
+  Group                               models/dvae.py:154-183
+  VisableOnlyMaskTransformer          models/act.py:148-309
+  ACTPromptedDiscreteVAEwithVIT       models/dvae.py:360-615
+  ACT_PointDistillation               models/act.py:1099-1258
+  ChamferDistanceL1/L2                extensions/chamfer_dist/__init__.py:13-84
+"""
+import math
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import point_ops as P
+from .layers import (Draws, Encoder, DGCNN, Decoder, TransformerEncoder, TransformerDecoder, BlockList,
+                     cosine_distill_loss, trunc_normal_, knn_graph_ref)
+
+
+class edict(dict):
+    """minimal EasyDict stand-in (the reference uses easydict, utils/config.py:2)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, edict):
+            v = edict(v)
+        super().__setitem__(k, v)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    __setattr__ = __setitem__
+
+
+class Group(nn.Module):
+    def __init__(self, num_group, group_size):
+        super().__init__()
+        self.num_group, self.group_size = num_group, group_size
+
+    def forward(self, xyz):
+        nb, center, _, _ = P.group_ref(xyz.detach().cpu().numpy(), self.num_group, self.group_size)
+        return torch.from_numpy(nb), torch.from_numpy(center)
+
+
+class _ChamferFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        d1, d2, i1, i2 = P.chamfer_fwd_ref(xyz1.detach().numpy(), xyz2.detach().numpy())
+        if xyz1.dtype == torch.float64:      # gradcheck path: distances in float64
+            a, b = xyz1.detach().numpy(), xyz2.detach().numpy()
+            B = a.shape[0]
+            d1 = ((a - b[np.arange(B)[:, None], i1]) ** 2).sum(-1)
+            d2 = ((b - a[np.arange(B)[:, None], i2]) ** 2).sum(-1)
+        ctx.save_for_backward(xyz1, xyz2, torch.from_numpy(i1), torch.from_numpy(i2))
+        return torch.from_numpy(d1).to(xyz1.dtype), torch.from_numpy(d2).to(xyz1.dtype)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        xyz1, xyz2, i1, i2 = ctx.saved_tensors
+        gx1, gx2 = P.chamfer_bwd_ref(xyz1.numpy(), xyz2.numpy(), i1.numpy(), i2.numpy(), g1.numpy(), g2.numpy())
+        return torch.from_numpy(gx1).to(xyz1.dtype), torch.from_numpy(gx2).to(xyz2.dtype)
+
+
+def chamfer_l1(xyz1, xyz2):
+    d1, d2 = _ChamferFn.apply(xyz1, xyz2)
+    return (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2
+
+
+def chamfer_l2(xyz1, xyz2):
+    d1, d2 = _ChamferFn.apply(xyz1, xyz2)
+    return torch.mean(d1) + torch.mean(d2)
+
+
+def rand_mask(B, G, num_mask, generator=None):
+    """exactly num_mask ones per row (models/act.py:244-267 semantics, torch RNG)."""
+    r = torch.rand(B, G, generator=generator)
+    order = r.argsort(dim=1)
+    mask = torch.zeros(B, G, dtype=torch.bool)
+    mask.scatter_(1, order[:, :num_mask], True)
+    return mask
+
+
+class VisableOnlyMaskTransformer(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        tc = config.transformer_config
+        self.mask_ratio, self.embed_dim, self.cls_dim = tc.mask_ratio, tc.embed_dim, tc.cls_dim
+        self.depth, self.num_heads = tc.depth, tc.num_heads
+        self.encoder_dims = config.dvae_config.encoder_dims
+        self.encoder = Encoder(self.encoder_dims)
+        self.reduce_dim = nn.Linear(self.encoder_dims, self.embed_dim) if self.encoder_dims != self.embed_dim \
+            else nn.Identity()
+        self.cls_token = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(self.embed_dim, self.depth, self.num_heads, dpr, tag="enc")
+        self.norm = nn.LayerNorm(self.embed_dim)
+        self.lm_head = nn.Linear(self.embed_dim, config.dvae_config.num_tokens)
+        self.cls_head = nn.Sequential(nn.Linear(self.embed_dim, self.cls_dim), nn.GELU(),
+                                      nn.Linear(self.cls_dim, self.cls_dim))
+        trunc_normal_(self.cls_token); trunc_normal_(self.cls_pos)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, (nn.Linear, nn.Conv1d)):
+            trunc_normal_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0); nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, neighborhood, center, draws, only_cls_tokens=False, noaug=False):
+        B, G, _ = center.shape
+        if noaug or self.mask_ratio == 0:
+            mask = torch.zeros(B, G, dtype=torch.bool)
+        else:
+            mask = draws.get("mask", lambda: rand_mask(B, G, int(self.mask_ratio * G)))
+        tok = self.reduce_dim(self.encoder(neighborhood))
+        C = tok.shape[-1]
+        x_vis = tok[~mask].reshape(B, -1, C)
+        pos = self.pos_embed(center[~mask].reshape(B, -1, 3))
+        x_vis = torch.cat((self.cls_token.expand(B, -1, -1), x_vis), dim=1)
+        pos = torch.cat((self.cls_pos.expand(B, -1, -1), pos), dim=1)
+        x_vis = self.norm(self.blocks(x_vis, pos, draws))
+        if only_cls_tokens:
+            return self.cls_head(x_vis[:, 0])
+        return x_vis[:, 1:], mask
+
+
+class ACTPromptedDiscreteVAEwithVIT(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        c = config
+        self.group_size, self.num_group = c.group_size, c.num_group
+        self.encoder_dims, self.tokens_dims = c.encoder_dims, c.tokens_dims
+        self.visual_embed_dim, self.num_prompt_token = c.visual_embed_dim, c.num_prompt_token
+        self.decoder_dims, self.num_tokens = c.decoder_dims, c.num_tokens
+        self.visual_embed_depth = int(c.get("visual_embed_depth", 12))
+        vit_heads = int(c.get("visual_embed_heads", 12))
+        self.group_divider = Group(self.num_group, self.group_size)
+        self.encoder = Encoder(self.encoder_dims)
+        self.dgcnn_1 = DGCNN(self.encoder_dims, self.num_tokens)
+        self.codebook = nn.Parameter(torch.randn(self.num_tokens, self.tokens_dims))
+        self.dgcnn_2 = DGCNN(self.tokens_dims, self.decoder_dims)
+        self.decoder = Decoder(self.decoder_dims, self.group_size)
+        D = self.visual_embed_dim
+        # visual_embed = Sequential(blocks, norm) of a timm ViT (models/dvae.py:405-410): LN eps 1e-6, qkv bias
+        vit = BlockList(D, self.visual_embed_depth, vit_heads, 0.0, qkv_bias=True, eps=1e-6, tag="vit")
+        self.visual_embed = nn.Sequential(vit.blocks, nn.LayerNorm(D, eps=1e-6))
+        self.proj_pre = nn.Linear(self.tokens_dims, D)
+        self.visual_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, D))
+        self.proj_post = nn.Linear(D, self.tokens_dims)
+        self.prompt_p = 0.1
+        Pn = self.num_prompt_token
+        self.visual_prompt_token = nn.Parameter(torch.zeros(1, Pn, D))
+        self.visual_prompt_pos = nn.Parameter(torch.randn(1, Pn, D))
+        self.deep_prompt_tokens = nn.Parameter(torch.zeros(self.visual_embed_depth - 1, Pn, D))
+        self.deep_prompt_pos = nn.Parameter(torch.randn(self.visual_embed_depth - 1, Pn, D))
+        for t in (self.visual_prompt_token, self.visual_prompt_pos, self.deep_prompt_tokens, self.deep_prompt_pos):
+            trunc_normal_(t)
+        for p in self.visual_embed.parameters():
+            p.requires_grad = False
+
+    # -- pieces -----------------------------------------------------------------------------
+    def _prompt_dropout(self, t, draws, key):
+        if not self.training or self.prompt_p == 0:
+            return t
+        keep = draws.get(key, lambda: (torch.rand_like(t) >= self.prompt_p).to(t.dtype))
+        return t * keep / (1.0 - self.prompt_p)
+
+    def visual_embedding(self, x, center, draws):
+        """visual_embedding_deep_prompt (models/dvae.py:536-576) + incorporate_prompt (:485-498)."""
+        B, Pn = x.shape[0], self.num_prompt_token
+        pos = self.visual_pos_embed(center)
+        f = self.proj_pre(x)
+        prm = self._prompt_dropout(self.visual_prompt_token.expand(B, -1, -1), draws, "prompt.0")
+        h = torch.cat((prm, f), dim=1)
+        pos = torch.cat((self.visual_prompt_pos.expand(B, -1, -1), pos), dim=1)
+        blocks = self.visual_embed[0]
+        for i in range(self.visual_embed_depth):
+            if i > 0:
+                prm = self._prompt_dropout(self.deep_prompt_tokens[i - 1].expand(B, -1, -1), draws, f"prompt.{i}")
+                h = torch.cat((prm, h[:, Pn:]), dim=1)
+                pos = torch.cat((self.deep_prompt_pos[i - 1].expand(B, -1, -1), pos[:, Pn:]), dim=1)
+            h = blocks[i](h + pos, draws)
+        h = self.visual_embed[1](h)[:, Pn:]
+        return self.proj_post(h)
+
+    def _gumbel(self, logits, tau, hard, draws):
+        g = draws.get("gumbel", lambda: -torch.empty_like(logits).exponential_().log())
+        y = (logits + g) / tau
+        if hard:
+            index = y.argmax(dim=-1)
+            return self.codebook[index]                 # == einsum(one_hot, codebook) (models/dvae.py:587-588)
+        return torch.einsum("bgn,nc->bgc", y.softmax(dim=-1), self.codebook)
+
+    def forward_tokenizer_features(self, neighborhood, center, draws, return_global=True):
+        idx = knn_graph_ref(center, 4)
+        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
+        sampled = self._gumbel(logits, 1.0, True, draws)
+        feature = self.visual_embedding(sampled, center, draws)
+        if return_global:
+            feature = self.dgcnn_2(feature, center, idx)
+        return feature
+
+    def forward(self, inp, draws, temperature=1.0, hard=False):
+        neighborhood, center = self.group_divider(inp)
+        idx = knn_graph_ref(center, 4)
+        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
+        sampled = self._gumbel(logits, temperature, hard, draws)
+        sampled = self.visual_embedding(sampled, center, draws)
+        feature = self.dgcnn_2(sampled, center, idx)
+        coarse, fine = self.decoder(feature)
+        with torch.no_grad():
+            whole_fine = (fine + center.unsqueeze(2)).reshape(inp.size(0), -1, 3)
+            whole_coarse = (coarse + center.unsqueeze(2)).reshape(inp.size(0), -1, 3)
+        return whole_coarse, whole_fine, coarse, fine, neighborhood, logits
+
+    def get_loss(self, ret, gt=None):
+        _, _, coarse, fine, group_gt, logits = ret
+        bs, g = coarse.shape[:2]
+        coarse = coarse.reshape(bs * g, -1, 3).contiguous()
+        fine = fine.reshape(bs * g, -1, 3).contiguous()
+        group_gt = group_gt.reshape(bs * g, -1, 3).contiguous()
+        loss_recon = chamfer_l1(coarse, group_gt) + chamfer_l1(fine, group_gt)
+        mean_softmax = F.softmax(logits, dim=-1).mean(dim=1)
+        log_qy = torch.log(mean_softmax)
+        log_uniform = torch.log(torch.tensor([1.0 / self.num_tokens]))
+        loss_klv = F.kl_div(log_qy, log_uniform.expand(log_qy.size(0), log_qy.size(1)), None, None, "batchmean",
+                            log_target=True)
+        return loss_recon, loss_klv
+
+
+class ACT_PointDistillation(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        tc = config.transformer_config
+        self.mask_ratio, self.embed_dim = tc.mask_ratio, tc.embed_dim
+        self.ACT_encoder = VisableOnlyMaskTransformer(config)
+        self.dvae_tokenizer = ACTPromptedDiscreteVAEwithVIT(config.dvae_config)
+        for p in self.dvae_tokenizer.parameters():
+            p.requires_grad = False
+        self.group_divider = Group(config.dvae_config.num_group, config.dvae_config.group_size)
+        self.proj_head = nn.Linear(self.embed_dim, config.dvae_config.tokens_dims)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
+        self.decoder_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, tc.decoder_depth)]
+        self.ACT_decoder = TransformerDecoder(self.embed_dim, tc.decoder_depth, tc.decoder_num_heads, dpr)
+        for m in self.ACT_decoder.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        trunc_normal_(self.mask_token)
+
+    def forward(self, pts, draws=None, noaug=False):
+        draws = draws if draws is not None else Draws()
+        neighborhood, center = self.group_divider(pts)
+        if noaug:
+            with torch.no_grad():
+                return self.ACT_encoder(neighborhood, center, draws, only_cls_tokens=True, noaug=True)
+        x_vis, mask = self.ACT_encoder(neighborhood, center, draws)
+        B, _, C = x_vis.shape
+        with torch.no_grad():
+            teacher = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, draws)
+        pos_vis = self.decoder_pos_embed(center[~mask]).reshape(B, -1, C)
+        pos_msk = self.decoder_pos_embed(center[mask]).reshape(B, -1, C)
+        num_mask = pos_msk.shape[1]
+        x_full = torch.cat([x_vis, self.mask_token.expand(B, num_mask, -1)], dim=1)
+        pos_full = torch.cat([pos_vis, pos_msk], dim=1)
+        student = self.proj_head(self.ACT_decoder(x_full, pos_full, num_mask, draws))
+        teacher = teacher[mask].reshape(B, -1, student.shape[-1])
+        return cosine_distill_loss(student, teacher)
+
+
+def param_groups(model, weight_decay):
+    """tools/builder.py:38-51 add_weight_decay."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if len(p.shape) == 1 or name.endswith(".bias") or "token" in name:
+            no_decay.append(p)
+        else:
+            decay.append(p)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]

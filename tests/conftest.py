@@ -1,0 +1,29 @@
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def oracle_c():
+    """ctypes handle on the plain-C oracle (built on demand; test infrastructure only)."""
+    import ctypes
+    import subprocess
+    d = os.path.join(ROOT, "oracle")
+    so = os.path.join(d, "liboracle_point_ops.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(d, "point_ops_c.c")):
+        subprocess.check_call(["make", "-C", d, "-s"])
+    return ctypes.CDLL(so)

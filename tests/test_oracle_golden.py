@@ -1,0 +1,191 @@
+"""CPU: the oracle (numpy / torch-CPU / C restatement) against the golden vectors produced by the
+reference's own Python modules (tests/golden/make_golden.py) and against the reference's only
+known-answer test (Chamfer gradcheck, extensions/chamfer_dist/test.py:23-29)."""
+import ctypes
+import numpy as np
+import torch
+import pytest
+
+from tests.conftest import golden
+from tests.golden.fill import fill_module, fill_tensor, clouds, TINY_STAGE2, TINY_B, TINY_N
+from oracle import point_ops as OP
+from oracle import layers as L
+from oracle import models as M
+
+TOL = 1e-4
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    err = np.abs(a - b).max()
+    assert err <= tol * max(1.0, np.abs(b).max()), f"max err {err}"
+
+
+def test_fps_matches_reference_intree_fps():
+    g = golden("g1_group")
+    pts = clouds(0, 4, 1024)
+    assert np.array_equal(OP.fps_ref(pts, 64), g["fps_idx"])           # bit-exact int32
+    assert np.array_equal(OP.fps_ref(clouds(1, 2, 4096), 256), g["fps_idx_big"])
+
+
+def test_group_matches_golden_and_knn_point_sets():
+    g = golden("g1_group")
+    nb, center, fidx, kidx = OP.group_ref(clouds(0, 4, 1024), 64, 32)
+    assert np.array_equal(kidx, g["knn_idx"]) and kidx.dtype == np.int64
+    assert np.array_equal(center, g["center"])
+    assert np.array_equal(nb, g["neighborhood"])
+    # agreement with the reference's in-tree expansion-form knn_point (models/dvae.py:120-152), as sets
+    same = (np.sort(kidx, axis=-1) == g["knn_point_sorted"]).all(axis=-1).mean()
+    assert same >= 0.98, same
+    # properties from SURVEY section 4
+    assert (fidx[:, 0] == 0).all()
+    assert all(len(set(r.tolist())) == 64 for r in fidx)
+    assert np.array_equal(kidx[:, :, 0], fidx.astype(np.int64))           # a center is its own nearest point
+    assert (nb[:, :, 0, :] == 0).all()
+
+
+def test_c_oracle_equals_numpy_oracle(oracle_c):
+    pts = clouds(3, 3, 512)
+    B, N, G, Mk = 3, 512, 32, 16
+    center = np.zeros((B, G, 3), np.float32); nbr = np.zeros((B, G, Mk, 3), np.float32)
+    fidx = np.zeros((B, G), np.int32); kidx = np.zeros((B, G, Mk), np.int64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert oracle_c.oracle_group_f32(P(pts), B, N, G, Mk, P(center), P(nbr), P(fidx), P(kidx)) == 0
+    nb, c, f, k = OP.group_ref(pts, G, Mk)
+    assert np.array_equal(f, fidx) and np.array_equal(k, kidx) and np.array_equal(nb, nbr) and np.array_equal(c, center)
+    # near-origin skip flag (upstream pointnet2_ops quirk) also agrees between the two restatements
+    pts2 = pts.copy(); pts2[:, 5] = 0.001
+    f2 = np.zeros((B, G), np.int32)
+    oracle_c.oracle_fps_f32(P(pts2), B, N, G, P(f2), 1)
+    assert np.array_equal(f2, OP.fps_ref(pts2, G, skip_near_origin=True))
+    # chamfer
+    x = clouds(5, 4, 64); y = clouds(6, 4, 128)
+    d1 = np.zeros((4, 64), np.float32); d2 = np.zeros((4, 128), np.float32)
+    i1 = np.zeros((4, 64), np.int32); i2 = np.zeros((4, 128), np.int32)
+    oracle_c.oracle_chamfer_fwd_f32(P(x), P(y), 4, 64, 128, P(d1), P(d2), P(i1), P(i2))
+    r = OP.chamfer_fwd_ref(x, y)
+    for a, b in zip((d1, d2, i1, i2), r):
+        assert np.array_equal(a, b)
+
+
+def test_fps_knn_ties_lowest_index():
+    pts = np.zeros((1, 8, 3), np.float32)
+    pts[0, 1:] = [[1, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, 1, 0], [2, 0, 0], [2, 0, 0]]
+    assert OP.fps_ref(pts, 3).tolist() == [[0, 6, 1]]   # three-way tie at d=1 -> lowest index
+    _, idx = OP.knn_ref(pts, pts[:, :1], 4)
+    assert idx.tolist() == [[[0, 1, 2, 3]]]
+
+
+def test_mini_pointnet_and_encoder_stack():
+    g = golden("g2_encoder")
+    nb = torch.from_numpy(golden("g1_group")["neighborhood"])
+    enc = fill_module(L.Encoder(128), "g2.enc.")
+    dpr = [0.0, 0.0]
+    tenc = fill_module(L.TransformerEncoder(128, 2, 2, dpr), "g2.tenc.")
+    pos = fill_tensor("g2.pos", (4, 64, 128), "b")
+    enc.train(); tok = enc(nb)
+    _close(tok.detach(), g["tok_train"])
+    _close(enc.first_conv[1].running_mean, g["bn1_running_mean"]); _close(enc.first_conv[1].running_var, g["bn1_running_var"])
+    enc.eval(); _close(enc(nb).detach(), g["tok_eval"])
+    _close(tenc(tok, pos, L.Draws()).detach(), g["out"])
+    # permutation invariance over the M axis (max-pool + BN are order free)
+    perm = torch.randperm(32)
+    enc.train(); _close(enc(nb[:, :, perm]).detach(), g["tok_train"], 2e-4)
+
+
+def test_block_forward_backward():
+    g = golden("g3_block")
+    blk = fill_module(L.Block(384, 6), "g3.blk.")
+    x = fill_tensor("g3.x", (2, 14, 384), "code").requires_grad_(True)
+    y = blk(x, L.Draws())
+    _close(y.detach(), g["y"]); _close(y.detach(), g["y_standalone"])
+    (y * fill_tensor("g3.w", (2, 14, 384), "code")).sum().backward()
+    _close(x.grad, g["dx"])
+    pd = dict(blk.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 1e-4 * max(1, v)
+    blk_t = fill_module(L.Block(128, 2, qkv_bias=True, eps=1e-6), "g3.blkt.")
+    _close(blk_t(fill_tensor("g3.xt", (2, 128, 128), "code"), L.Draws()).detach(), golden("g3_block_teacher")["y"])
+
+
+def _tiny_stage2():
+    torch.manual_seed(0)
+    model = M.ACT_PointDistillation(M.edict(TINY_STAGE2))
+    fill_module(model, "g4.")
+    model.dvae_tokenizer.prompt_p = 0.0
+    return model.train()
+
+
+def _gumbel_noise(shape):
+    torch.manual_seed(777)
+    return -torch.empty(shape).exponential_().log()
+
+
+def test_stage2_loss_grads_and_two_adamw_steps():
+    g = golden("g4_stage2")
+    model = _tiny_stage2()
+    pts = torch.from_numpy(clouds(4, TINY_B, TINY_N))
+    assert np.array_equal(pts.numpy(), g["pts"])
+    draws = L.Draws({"mask": torch.from_numpy(g["mask"]), "gumbel": _gumbel_noise((TINY_B, 16, 64))})
+    with torch.no_grad():
+        nb, c = model.group_divider(pts)
+        _close(model.dvae_tokenizer.forward_tokenizer_features(nb, c, draws), g["teacher_feat"])
+    loss = model(pts, draws)
+    assert abs(loss.item() - g["loss"][0]) <= TOL
+    loss.backward()
+    pd = dict(model.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 1e-4 * max(1.0, v), n
+    _close(pd["ACT_encoder.blocks.blocks.0.attn.qkv.weight"].grad, g["grad_qkv0"])
+    groups = M.param_groups(model, 0.05)
+    assert [len(groups[0]["params"]), len(groups[1]["params"])] == g["n_param_groups"].tolist()
+    opt = torch.optim.AdamW(groups, lr=1e-3, weight_decay=0.05)
+    opt.step(); model.zero_grad()
+    loss2 = model(pts, draws); loss2.backward(); opt.step()
+    assert abs(loss2.item() - g["loss"][1]) <= TOL
+    for n, v in zip(g["grad_names"][:3], g["norms_after_2_steps"]):
+        assert abs(pd[str(n)].detach().norm().item() - v) <= 1e-4 * max(1.0, v)
+    # lm_head / cls_head never receive gradients
+    assert pd["ACT_encoder.lm_head.weight"].grad is None or pd["ACT_encoder.lm_head.weight"].grad.abs().sum() == 0
+
+
+def test_stage1_forward_and_losses():
+    g = golden("g7_stage1")
+    torch.manual_seed(0)
+    vae = fill_module(M.ACTPromptedDiscreteVAEwithVIT(M.edict(TINY_STAGE2["dvae_config"])), "g7.")
+    vae.prompt_p = 0.0
+    vae.train()
+    pts = torch.from_numpy(clouds(4, TINY_B, TINY_N))
+    ret = vae(pts, L.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}), temperature=0.7, hard=False)
+    _close(ret[2].detach(), g["coarse"]); _close(ret[3].detach(), g["fine"]); _close(ret[5].detach(), g["logits"], 2e-4)
+    _close(ret[1], g["whole_fine"])
+    lr, lk = vae.get_loss(ret)
+    assert abs(lr.item() - g["loss"][0]) <= TOL and abs(lk.item() - g["loss"][1]) <= TOL
+    (lr + 0.1 * lk).backward()
+    pd = dict(vae.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 2e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)
+
+
+def test_chamfer_reductions_and_gradcheck():
+    g = golden("g5_chamfer")
+    x = fill_tensor("g5.x", (4, 64, 3), "code"); y = fill_tensor("g5.y", (4, 128, 3), "code")
+    assert abs(M.chamfer_l1(x, y).item() - g["l1"]) <= TOL and abs(M.chamfer_l2(x, y).item() - g["l2"]) <= TOL
+    assert abs(OP.chamfer_l1_ref(x.numpy(), y.numpy()) - g["l1"]) <= TOL
+    # the reference's only test: gradcheck on [4,64,3] x [4,128,3] doubles (extensions/chamfer_dist/test.py:23-29)
+    torch.manual_seed(1)
+    xd = torch.rand(4, 64, 3).double().requires_grad_(True); yd = torch.rand(4, 128, 3).double().requires_grad_(True)
+    assert torch.autograd.gradcheck(M._ChamferFn.apply, [xd, yd])
+    # symmetry / zero on identical clouds
+    a = OP.chamfer_fwd_ref(x.numpy(), y.numpy()); b = OP.chamfer_fwd_ref(y.numpy(), x.numpy())
+    assert np.array_equal(a[0], b[1]) and np.array_equal(a[2], b[3])
+    assert OP.chamfer_l2_ref(x.numpy(), x.numpy()) == 0
+
+
+def test_cosine_loss_and_augment():
+    s = fill_tensor("g6.s", (4, 51, 384), "code"); t = fill_tensor("g6.t", (4, 51, 384), "code")
+    assert abs(L.cosine_distill_loss(s, t).item() - golden("g6_cosine")["loss"]) <= 1e-6
+    g = golden("g9_augment")
+    out = OP.scale_translate_ref(clouds(9, 2, 128), g["scale"], g["shift"])
+    _close(out, g["out"], 1e-6)
