@@ -1,0 +1,317 @@
+// point_ops.hip -- FPS, fused kNN-group, point gather, augmentation for gfx950 (CDNA4).
+//
+// Design (MI355X-first, not a translation of the CUDA wheels the reference calls):
+//  * FPS is a chain of G-1 dependent arg-max steps, so the kernel minimises per-iteration
+//    latency: every point of a cloud lives in VGPRs (contiguous chunk per lane), the running
+//    min-distance never touches memory, the wave arg-max is a 6-step DPP reduction whose result
+//    is broadcast through an SGPR (no LDS, no barrier when one wave holds the cloud), and the
+//    winner's coordinates come from an LDS copy of the cloud read at a wave-uniform address.
+//  * kNN-group: one wave per query; each lane owns a contiguous chunk of reference points as
+//    fp32 distances in registers; K rounds of wave-wide extract-min (DPP min + ballot, lowest
+//    lane == lowest index because chunks are contiguous) yield the ascending (dist, idx) list
+//    directly; the same wave then gathers, centres and stores the neighbourhood.
+//  * Distances use __fsub_rn/__fmul_rn/__fadd_rn: (dx*dx + dy*dy) + dz*dz, bit-identical to the
+//    CPU oracle, so indices are bit-exact.
+#include "common.h"
+
+// =============================================== FPS ==============================================
+template <int WAVES, int PPL>
+__global__ __launch_bounds__(WAVES * 64) void fps_kernel(const float* __restrict__ xyz, int N, int G,
+                                                         int32_t* __restrict__ idx_out,
+                                                         float* __restrict__ centers_out, int skip_near_origin,
+                                                         int lds_cloud) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: [2][WAVES] best value, [2][WAVES] best index, then (optional) the cloud xyz
+    float* s_val = smem;
+    int* s_idx = reinterpret_cast<int*>(smem + 2 * WAVES);
+    float* s_xyz = smem + 4 * WAVES;
+
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const float* __restrict__ p = xyz + (size_t)b * N * 3;
+    const int base = tid * PPL;
+
+    float px[PPL], py[PPL], pz[PPL], td[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const int k = base + j;
+        if (k < N) {
+            px[j] = p[k * 3 + 0]; py[j] = p[k * 3 + 1]; pz[j] = p[k * 3 + 2];
+            td[j] = 1e10f;
+            if (skip_near_origin) {
+                const float mag = __fadd_rn(__fadd_rn(__fmul_rn(px[j], px[j]), __fmul_rn(py[j], py[j])), __fmul_rn(pz[j], pz[j]));
+                if (mag <= 1e-3f) td[j] = -1.0f;      // dead: min(d,-1) stays -1, never wins
+            }
+            if (lds_cloud) { s_xyz[k * 3 + 0] = px[j]; s_xyz[k * 3 + 1] = py[j]; s_xyz[k * 3 + 2] = pz[j]; }
+        } else {
+            px[j] = 0.f; py[j] = 0.f; pz[j] = 0.f; td[j] = -1.0f;
+        }
+    }
+    if (WAVES > 1 || lds_cloud) __syncthreads();
+
+    int old = 0;
+    float cx = p[0], cy = p[1], cz = p[2];
+    if (tid == 0) {
+        idx_out[(size_t)b * G] = 0;
+        if (centers_out) { float* c = centers_out + (size_t)b * G * 3; c[0] = cx; c[1] = cy; c[2] = cz; }
+    }
+
+    for (int it = 1; it < G; ++it) {
+        float best = -2.0f; int bj = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const float d = sqdist3(px[j], py[j], pz[j], cx, cy, cz);
+            const float t = fminf(td[j], d);
+            td[j] = t;
+            if (t > best) { best = t; bj = j; }       // strict '>' : lowest j wins inside the lane
+        }
+        const float wmax = wave_max_f32(best, -3.0f);
+        const int wl = first_lane(__ballot(best == wmax));     // lowest lane == lowest index (contiguous chunks)
+        int widx = __builtin_amdgcn_readlane(base + bj, wl);
+        if (WAVES > 1) {
+            const int par = it & 1;
+            if (lane == 0) { s_val[par * WAVES + wave] = wmax; s_idx[par * WAVES + wave] = widx; }
+            __syncthreads();
+            float gv = s_val[par * WAVES]; int gi = s_idx[par * WAVES];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                const float v = s_val[par * WAVES + w];
+                if (v > gv) { gv = v; gi = s_idx[par * WAVES + w]; }
+            }
+            widx = gi;
+        }
+        old = widx;
+        if (lds_cloud) { cx = s_xyz[old * 3 + 0]; cy = s_xyz[old * 3 + 1]; cz = s_xyz[old * 3 + 2]; }
+        else           { cx = p[old * 3 + 0];     cy = p[old * 3 + 1];     cz = p[old * 3 + 2]; }
+        if (tid == 0) {
+            idx_out[(size_t)b * G + it] = old;
+            if (centers_out) { float* c = centers_out + ((size_t)b * G + it) * 3; c[0] = cx; c[1] = cy; c[2] = cz; }
+        }
+    }
+}
+
+// fallback for clouds too large for registers: running distances in global scratch-free LDS-less loop
+__global__ __launch_bounds__(1024) void fps_big_kernel(const float* __restrict__ xyz, int N, int G,
+                                                       int32_t* __restrict__ idx_out, float* __restrict__ centers_out,
+                                                       float* __restrict__ temp, int skip_near_origin) {
+    __shared__ float s_val[2][16];
+    __shared__ int s_idx[2][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* __restrict__ p = xyz + (size_t)b * N * 3;
+    float* __restrict__ t = temp + (size_t)b * N;
+    const int per = (N + 1023) / 1024;                // contiguous chunk per thread keeps index order == thread order
+    const int k0 = tid * per, k1 = min(N, k0 + per);
+    for (int k = k0; k < k1; ++k) {
+        float v = 1e10f;
+        if (skip_near_origin) {
+            const float x = p[k * 3], y = p[k * 3 + 1], z = p[k * 3 + 2];
+            if (__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)) <= 1e-3f) v = -1.0f;
+        }
+        t[k] = v;
+    }
+    float cx = p[0], cy = p[1], cz = p[2];
+    if (tid == 0) { idx_out[(size_t)b * G] = 0; if (centers_out) { float* c = centers_out + (size_t)b * G * 3; c[0] = cx; c[1] = cy; c[2] = cz; } }
+    for (int it = 1; it < G; ++it) {
+        float best = -2.0f; int bi = 0;
+        for (int k = k0; k < k1; ++k) {
+            const float d = sqdist3(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], cx, cy, cz);
+            const float v = fminf(t[k], d);
+            t[k] = v;
+            if (v > best) { best = v; bi = k; }
+        }
+        const float wmax = wave_max_f32(best, -3.0f);
+        const int wl = first_lane(__ballot(best == wmax));
+        const int widx = __builtin_amdgcn_readlane(bi, wl);
+        const int par = it & 1;
+        if (lane == 0) { s_val[par][wave] = wmax; s_idx[par][wave] = widx; }
+        __syncthreads();
+        float gv = s_val[par][0]; int gi = s_idx[par][0];
+        for (int w = 1; w < 16; ++w) { const float v = s_val[par][w]; if (v > gv) { gv = v; gi = s_idx[par][w]; } }
+        cx = p[gi * 3]; cy = p[gi * 3 + 1]; cz = p[gi * 3 + 2];
+        if (tid == 0) { idx_out[(size_t)b * G + it] = gi; if (centers_out) { float* c = centers_out + ((size_t)b * G + it) * 3; c[0] = cx; c[1] = cy; c[2] = cz; } }
+    }
+}
+
+template <int WAVES, int PPL>
+static int launch_fps(const float* xyz, int B, int N, int G, int32_t* idx, float* centers, int skip, hipStream_t s) {
+    const size_t cloud_bytes = (size_t)N * 3 * sizeof(float);
+    const int lds_cloud = cloud_bytes <= 128 * 1024 ? 1 : 0;
+    const size_t smem = 4 * WAVES * sizeof(float) + (lds_cloud ? cloud_bytes : 0);
+    auto k = fps_kernel<WAVES, PPL>;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3(B), dim3(WAVES * 64), smem, s, xyz, N, G, idx, centers, skip, lds_cloud);
+    ACT_LAUNCH_CHECK();
+    return 0;
+}
+
+static float* g_fps_temp = nullptr; static size_t g_fps_temp_n = 0;
+
+extern "C" int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_out, float* centers_out,
+                           int skip_near_origin, act_stream_t stream) {
+    if (!xyz || !idx_out) return ACT_E_NULLPTR;
+    if (B < 0 || N <= 0 || G < 0) return ACT_E_BADARG;
+    if (B == 0 || G == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // algorithmic bytes: read xyz once, write idx (+ centers)  [SURVEY 8d]
+    ActProfScope ps(KID_FPS, s, 0.0, (double)B * (12.0 * N + 4.0 * G + (centers_out ? 12.0 * G : 0.0)));
+    if (N <= 256)   return launch_fps<1, 4>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+    if (N <= 1024)  return launch_fps<4, 4>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+    if (N <= 2048)  return launch_fps<4, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+    if (N <= 4096)  return launch_fps<8, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+    if (N <= 8192)  return launch_fps<16, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+    if (N <= 16384) return launch_fps<16, 16>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+    // very large clouds: running distances in a library-owned global buffer (grown on demand, outside capture)
+    const size_t need = (size_t)B * N;
+    if (need > g_fps_temp_n) {
+        if (g_fps_temp) hipFree(g_fps_temp);
+        hipError_t e = hipMalloc(&g_fps_temp, need * sizeof(float));
+        if (e != hipSuccess) { g_fps_temp = nullptr; g_fps_temp_n = 0; return (int)e; }
+        g_fps_temp_n = need;
+    }
+    hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, s, xyz, N, G, idx_out, centers_out, g_fps_temp, skip_near_origin);
+    ACT_LAUNCH_CHECK();
+    return 0;
+}
+
+// =========================================== kNN + group ==========================================
+// one wave per query; PPL reference points per lane (contiguous), N <= 64*PPL
+template <int PPL>
+__global__ __launch_bounds__(256) void knn_group_kernel(const float* __restrict__ ref, const float* __restrict__ query,
+                                                        int B, int N, int Q, int K, int64_t* __restrict__ idx_out,
+                                                        int idx_kq, float* __restrict__ nbr_out,
+                                                        float* __restrict__ dist_out) {
+    const int lane = threadIdx.x & 63;
+    const long long qid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // b*Q + q
+    if (qid >= (long long)B * Q) return;                 // whole wave exits together
+    const int b = (int)(qid / Q), q = (int)(qid % Q);
+    const float* __restrict__ r = ref + (size_t)b * N * 3;
+    const float qx = query[qid * 3 + 0], qy = query[qid * 3 + 1], qz = query[qid * 3 + 2];
+    const float INF = __int_as_float(0x7f800000);
+    const int base = lane * PPL;
+
+    float d[PPL];
+    float lmin = INF; int lj = 0;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const int k = base + j;
+        float v = INF;
+        if (k < N) v = sqdist3(r[k * 3 + 0], r[k * 3 + 1], r[k * 3 + 2], qx, qy, qz);
+        d[j] = v;
+        if (v < lmin) { lmin = v; lj = j; }
+    }
+    int my_idx = 0; float my_d = 0.f;
+    for (int round = 0; round < K; ++round) {
+        const float m = wave_min_f32(lmin, INF);
+        const int wl = first_lane(__ballot(lmin == m));
+        const int widx = __builtin_amdgcn_readlane(base + lj, wl);
+        if (lane == round) { my_idx = widx; my_d = m; }
+        if (lane == wl) {                                // retire the winner, refresh this lane's minimum
+            float nm = INF; int nj = 0;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                const float v = (j == lj) ? INF : d[j];
+                d[j] = v;
+                if (v < nm) { nm = v; nj = j; }
+            }
+            lmin = nm; lj = nj;
+        }
+    }
+    if (lane < K) {
+        const size_t o = idx_kq ? ((size_t)b * K + lane) * Q + q : (size_t)qid * K + lane;
+        idx_out[o] = (int64_t)my_idx;
+        if (dist_out) dist_out[o] = __fsqrt_rn(my_d);
+        if (nbr_out) {
+            float* __restrict__ w = nbr_out + ((size_t)qid * K + lane) * 3;
+            w[0] = __fsub_rn(r[my_idx * 3 + 0], qx);
+            w[1] = __fsub_rn(r[my_idx * 3 + 1], qy);
+            w[2] = __fsub_rn(r[my_idx * 3 + 2], qz);
+        }
+    }
+}
+
+template <int PPL>
+static int launch_knn(const float* ref, const float* query, int B, int N, int Q, int K, int64_t* idx, int idx_kq,
+                      float* nbr, float* dist, hipStream_t s) {
+    const long long nq = (long long)B * Q;
+    const int wpb = 4;
+    hipLaunchKernelGGL(knn_group_kernel<PPL>, dim3((unsigned)((nq + wpb - 1) / wpb)), dim3(wpb * 64), 0, s, ref, query,
+                       B, N, Q, K, idx, idx_kq, nbr, dist);
+    ACT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int act_knn_group_f32(const float* ref, const float* query, int B, int N, int Q, int K, int64_t* idx_out,
+                                 int idx_kq, float* nbr_out, float* dist_out, act_stream_t stream) {
+    if (!ref || !query || !idx_out) return ACT_E_NULLPTR;
+    if (B < 0 || N <= 0 || Q < 0 || K <= 0 || K > 64 || K > N || N > 64 * 128) return ACT_E_BADARG;
+    if (B == 0 || Q == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // algorithmic bytes per cloud: 12N + 12Q + 8QK (+12QK neighbourhood) (+4QK dist)   [SURVEY 8d]
+    ActProfScope ps(KID_KNN_GROUP, s, 0.0,
+                    (double)B * (12.0 * N + 12.0 * Q + 8.0 * Q * K + (nbr_out ? 12.0 * Q * K : 0.0) + (dist_out ? 4.0 * Q * K : 0.0)));
+#define KNN_CASE(P) if (N <= 64 * P) return launch_knn<P>(ref, query, B, N, Q, K, idx_out, idx_kq, nbr_out, dist_out, s)
+    KNN_CASE(1); KNN_CASE(2); KNN_CASE(4); KNN_CASE(8); KNN_CASE(16); KNN_CASE(32); KNN_CASE(64); KNN_CASE(128);
+#undef KNN_CASE
+    return ACT_E_BADARG;
+}
+
+// ============================================ gather ==============================================
+__global__ void gather_points_kernel(const float* __restrict__ feat, const int32_t* __restrict__ idx, int C, int N, int S,
+                                     float* __restrict__ out, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(i % S); const long long bc = i / S; const int b = (int)(bc / C);
+        out[i] = feat[bc * N + idx[(size_t)b * S + s]];
+    }
+}
+// deterministic scatter-add: one thread per (b,c,n) scans the S sampled indices (S is small: G)
+__global__ void gather_points_bwd_kernel(const float* __restrict__ go, const int32_t* __restrict__ idx, int C, int N, int S,
+                                         float* __restrict__ gf, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N); const long long bc = i / N; const int b = (int)(bc / C);
+        const int32_t* __restrict__ id = idx + (size_t)b * S;
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) if (id[s] == n) acc += go[bc * S + s];
+        gf[i] = acc;
+    }
+}
+static inline unsigned grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block; if (g > 2048 * 4) g = 2048 * 4; if (g < 1) g = 1; return (unsigned)g;
+}
+extern "C" int act_gather_points_f32(const float* feat, const int32_t* idx, int B, int C, int N, int S, float* out, act_stream_t stream) {
+    if (!feat || !idx || !out) return ACT_E_NULLPTR;
+    const long long total = (long long)B * C * S; if (total == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GATHER, s, 0.0, 8.0 * total + 4.0 * B * S);
+    hipLaunchKernelGGL(gather_points_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, feat, idx, C, N, S, out, total);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_gather_points_bwd_f32(const float* go, const int32_t* idx, int B, int C, int N, int S, float* gf, act_stream_t stream) {
+    if (!go || !idx || !gf) return ACT_E_NULLPTR;
+    const long long total = (long long)B * C * N; if (total == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GATHER_BWD, s, 0.0, 4.0 * total + 4.0 * B * C * S);
+    hipLaunchKernelGGL(gather_points_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, go, idx, C, N, S, gf, total);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+// ======================================== augmentation ============================================
+__global__ void scale_translate_kernel(float* __restrict__ pc, const float* __restrict__ scale, const float* __restrict__ shift,
+                                       int N, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3); const int b = (int)(i / (3LL * N));
+        pc[i] = __fadd_rn(__fmul_rn(pc[i], scale[b * 3 + c]), shift[b * 3 + c]);
+    }
+}
+extern "C" int act_scale_translate_f32(float* pc, const float* scale, const float* shift, int B, int N, act_stream_t stream) {
+    if (!pc || !scale || !shift) return ACT_E_NULLPTR;
+    const long long total = (long long)B * N * 3; if (total == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_AUGMENT, s, 0.0, 8.0 * total);
+    hipLaunchKernelGGL(scale_translate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, pc, scale, shift, N, total);
+    ACT_LAUNCH_CHECK(); return 0;
+}

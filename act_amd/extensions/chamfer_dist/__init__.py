@@ -1,0 +1,91 @@
+"""Drop-in for ``extensions.chamfer_dist`` (extensions/chamfer_dist/__init__.py:13-84) and the
+pybind module ``chamfer`` it wraps (chamfer_cuda.cpp:12-39), backed by act_chamfer_{fwd,bwd}_f32.
+Unlike the reference, errors raise, inputs are validated, the launch is on the current stream and the
+backward is deterministic."""
+import torch
+
+from ... import _C
+
+
+def _check(xyz1, xyz2):
+    for t in (xyz1, xyz2):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3 or t.shape[-1] != 3:
+            raise RuntimeError("chamfer: expected float32 CUDA tensors of shape [B, n, 3]")
+    if xyz1.shape[0] != xyz2.shape[0]:
+        raise RuntimeError("chamfer: batch sizes differ")
+
+
+class chamfer:          # namespace standing in for the compiled ``chamfer`` module
+    @staticmethod
+    def forward(xyz1, xyz2):
+        _check(xyz1, xyz2)
+        xyz1 = xyz1.contiguous(); xyz2 = xyz2.contiguous()
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        dev = xyz1.device
+        dist1 = torch.empty(B, n, dtype=torch.float32, device=dev); dist2 = torch.empty(B, m, dtype=torch.float32, device=dev)
+        idx1 = torch.empty(B, n, dtype=torch.int32, device=dev); idx2 = torch.empty(B, m, dtype=torch.int32, device=dev)
+        _C.check(_C.lib.act_chamfer_fwd_f32(_C.ptr(xyz1), _C.ptr(xyz2), B, n, m, _C.ptr(dist1), _C.ptr(dist2),
+                                            _C.ptr(idx1), _C.ptr(idx2), _C.stream()), "act_chamfer_fwd_f32")
+        return [dist1, dist2, idx1, idx2]
+
+    @staticmethod
+    def backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2):
+        _check(xyz1, xyz2)
+        xyz1 = xyz1.contiguous(); xyz2 = xyz2.contiguous()
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        g1 = grad_dist1.contiguous(); g2 = grad_dist2.contiguous()
+        gx1 = torch.empty_like(xyz1); gx2 = torch.empty_like(xyz2)
+        _C.check(_C.lib.act_chamfer_bwd_f32(_C.ptr(xyz1), _C.ptr(xyz2), _C.ptr(idx1), _C.ptr(idx2), _C.ptr(g1), _C.ptr(g2),
+                                            B, n, m, _C.ptr(gx1), _C.ptr(gx2), _C.stream()), "act_chamfer_bwd_f32")
+        return [gx1, gx2]
+
+
+class ChamferFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        dist1, dist2, idx1, idx2 = chamfer.forward(xyz1, xyz2)
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        return dist1, dist2
+
+    @staticmethod
+    def backward(ctx, grad_dist1, grad_dist2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        grad_xyz1, grad_xyz2 = chamfer.backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
+        return grad_xyz1, grad_xyz2
+
+
+def _drop_zeros(xyz1, xyz2):
+    non_zeros1 = torch.sum(xyz1, dim=2).ne(0)
+    non_zeros2 = torch.sum(xyz2, dim=2).ne(0)
+    return xyz1[non_zeros1].unsqueeze(dim=0), xyz2[non_zeros2].unsqueeze(dim=0)
+
+
+class _ChamferBase(torch.nn.Module):
+    def __init__(self, ignore_zeros=False):
+        super().__init__()
+        self.ignore_zeros = ignore_zeros
+
+    def _dists(self, xyz1, xyz2):
+        if xyz1.size(0) == 1 and self.ignore_zeros:
+            xyz1, xyz2 = _drop_zeros(xyz1, xyz2)
+        return ChamferFunction.apply(xyz1, xyz2)
+
+
+class ChamferDistanceL2(_ChamferBase):
+    def forward(self, xyz1, xyz2):
+        dist1, dist2 = self._dists(xyz1, xyz2)
+        return torch.mean(dist1) + torch.mean(dist2)
+
+
+class ChamferDistanceL2_split(_ChamferBase):
+    def forward(self, xyz1, xyz2):
+        dist1, dist2 = self._dists(xyz1, xyz2)
+        return torch.mean(dist1), torch.mean(dist2)
+
+
+class ChamferDistanceL1(_ChamferBase):
+    def forward(self, xyz1, xyz2):
+        dist1, dist2 = self._dists(xyz1, xyz2)
+        return (torch.mean(torch.sqrt(dist1)) + torch.mean(torch.sqrt(dist2))) / 2

@@ -1,0 +1,191 @@
+"""GPU parity (through the C ABI): FPS / kNN-group / gather / Chamfer / augmentation vs the CPU oracle,
+the committed golden vectors, and size-independent properties at BASELINE.json's full sizes.
+Bar: bit-exact for indices, neighbourhoods and distances (same fp32 expression, no FMA)."""
+import ctypes
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden
+from tests.golden.fill import clouds, fill_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    import act_amd._C as C          # fails loudly if libact_hip.so is missing
+    assert C.lib.act_arch() == b"gfx950"
+    return torch.device("cuda:0")
+
+
+def _group_hip(pts_np, G, M, dev):
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    from act_amd.knn_cuda import knn_group
+    xyz = torch.from_numpy(pts_np).to(dev)
+    fidx, center = pu.furthest_point_sample_with_centers(xyz, G)
+    kidx, nbr, dist = knn_group(xyz, center, M, want_nbr=True, want_dist=True)
+    torch.cuda.synchronize()
+    return fidx.cpu().numpy(), center.cpu().numpy(), kidx.cpu().numpy(), nbr.cpu().numpy(), dist.cpu().numpy()
+
+
+def test_group_against_golden(dev):
+    g = golden("g1_group")
+    fidx, center, kidx, nbr, _ = _group_hip(clouds(0, 4, 1024), 64, 32, dev)
+    assert fidx.dtype == np.int32 and kidx.dtype == np.int64
+    assert np.array_equal(fidx, g["fps_idx"])                 # reference in-tree FPS, start 0
+    assert np.array_equal(center, g["center"])
+    assert np.array_equal(kidx, g["knn_idx"])
+    assert np.array_equal(nbr, g["neighborhood"])
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    big = pu.furthest_point_sample(torch.from_numpy(clouds(1, 2, 4096)).to(dev), 256).cpu().numpy()
+    assert np.array_equal(big, g["fps_idx_big"])
+
+
+@pytest.mark.parametrize("B,N,G,M", [(3, 64, 8, 4), (2, 100, 10, 7), (5, 256, 32, 16), (2, 777, 33, 32), (4, 1024, 64, 32),
+                                     (2, 2048, 128, 32), (1, 3000, 50, 64), (2, 8192, 64, 64), (1, 20000, 16, 8)])
+def test_group_against_oracle(dev, oracle_c, B, N, G, M):
+    pts = clouds(100 + N, B, N)
+    fidx, center, kidx, nbr, dist = _group_hip(pts, G, M, dev)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    c = np.zeros((B, G, 3), np.float32); nb = np.zeros((B, G, M, 3), np.float32)
+    f = np.zeros((B, G), np.int32); k = np.zeros((B, G, M), np.int64)
+    assert oracle_c.oracle_group_f32(P(pts), B, N, G, M, P(c), P(nb), P(f), P(k)) == 0
+    assert np.array_equal(fidx, f) and np.array_equal(center, c)
+    assert np.array_equal(kidx, k) and np.array_equal(nbr, nb)
+    d = np.zeros((B, G, M), np.float32)
+    oracle_c.oracle_knn_f32(P(pts), P(c), B, N, G, M, P(k), P(d))
+    assert np.array_equal(dist, d)
+
+
+def test_group_full_size_properties(dev):
+    """BASELINE configs[1] (B=128,N=1024,G=64,M=32) and the stress geometry (N=8192,G=512,M=64)."""
+    from oracle import point_ops as OP
+    for (B, N, G, M, nchk) in [(128, 1024, 64, 32, 128), (32, 8192, 512, 64, 2)]:
+        pts = clouds(7, B, N)
+        fidx, center, kidx, nbr, dist = _group_hip(pts, G, M, dev)
+        assert (fidx[:, 0] == 0).all()
+        assert all(len(set(r.tolist())) == G for r in fidx)                      # FPS indices unique
+        assert np.array_equal(kidx[:, :, 0], fidx.astype(np.int64))              # a centre is its own nearest point
+        assert (nbr[:, :, 0, :] == 0).all() and (dist[:, :, 0] == 0).all()
+        assert (np.diff(dist, axis=-1) >= 0).all()                               # ascending distances
+        assert np.array_equal(center, pts[np.arange(B)[:, None], fidx])
+        assert np.array_equal(nbr, pts[np.arange(B)[:, None, None], kidx] - center[:, :, None, :])
+        # spot-check full clouds against the numpy oracle
+        sel = np.linspace(0, B - 1, nchk).astype(int)
+        nb_o, c_o, f_o, k_o = OP.group_ref(pts[sel], G, M)
+        assert np.array_equal(fidx[sel], f_o) and np.array_equal(kidx[sel], k_o) and np.array_equal(nbr[sel], nb_o)
+
+
+def test_fps_ties_duplicates_and_skip_flag(dev, oracle_c):
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    from oracle import point_ops as OP
+    pts = clouds(11, 4, 512)
+    pts[:, 100:200] = pts[:, 0:100]                       # exact duplicates -> exact ties
+    pts[:, 300] = 0.0; pts[:, 301] = 0.01                 # inside the |p|^2 <= 1e-3 ball
+    x = torch.from_numpy(pts).to(dev)
+    assert np.array_equal(pu.furthest_point_sample(x, 64).cpu().numpy(), OP.fps_ref(pts, 64))
+    assert np.array_equal(pu.furthest_point_sample(x, 64, skip_near_origin=True).cpu().numpy(),
+                          OP.fps_ref(pts, 64, skip_near_origin=True))
+    # all points identical: every step ties at 0 -> index 0
+    same = torch.zeros(2, 128, 3, device=dev) + 0.5
+    assert (pu.furthest_point_sample(same, 8).cpu().numpy() == 0).all()
+    # G == 1, G == N
+    assert pu.furthest_point_sample(x, 1).cpu().numpy().tolist() == [[0]] * 4
+    full = pu.furthest_point_sample(x[:, :64].contiguous(), 64).cpu().numpy()
+    assert np.array_equal(full, OP.fps_ref(pts[:, :64], 64))
+
+
+def test_knn_module_layouts_and_dgcnn_graph(dev):
+    from act_amd.knn_cuda import KNN
+    from oracle import point_ops as OP
+    pts = clouds(12, 3, 300); q = clouds(13, 3, 20)
+    d_o, i_o = OP.knn_ref(pts, q, 9)
+    d, i = KNN(k=9, transpose_mode=True)(torch.from_numpy(pts).to(dev), torch.from_numpy(q).to(dev))
+    assert i.dtype == torch.int64 and tuple(i.shape) == (3, 20, 9)
+    assert np.array_equal(i.cpu().numpy(), i_o) and np.array_equal(d.cpu().numpy(), d_o)
+    # transpose_mode=False: [B,3,N] in, [B,k,Q] out, contiguous (models/dvae.py:68-72 does idx.view(-1))
+    c = clouds(14, 5, 64)
+    ct = torch.from_numpy(c).to(dev).transpose(1, 2).contiguous()
+    d2, i2 = KNN(k=4, transpose_mode=False)(ct, ct)
+    assert tuple(i2.shape) == (5, 4, 64) and i2.is_contiguous()
+    _, i_o2 = OP.knn_ref(c, c, 4)
+    assert np.array_equal(i2.cpu().numpy(), i_o2.transpose(0, 2, 1))
+    with pytest.raises(Exception):
+        KNN(k=65, transpose_mode=True)(torch.from_numpy(pts).to(dev), torch.from_numpy(q).to(dev))
+
+
+def test_gather_operation_fwd_bwd(dev):
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    feat = fill_tensor("gat.f", (3, 5, 40), "code").to(dev).requires_grad_(True)
+    idx = torch.tensor([[0, 3, 3, 39, 7], [1, 1, 1, 1, 1], [5, 4, 3, 2, 1]], dtype=torch.int32, device=dev)
+    out = pu.gather_operation(feat, idx)
+    ref = torch.gather(feat.detach(), 2, idx.long().unsqueeze(1).expand(-1, 5, -1))
+    assert torch.equal(out, ref)
+    w = fill_tensor("gat.w", (3, 5, 5), "code").to(dev)
+    (out * w).sum().backward()
+    gref = torch.zeros_like(feat).scatter_add_(2, idx.long().unsqueeze(1).expand(-1, 5, -1), w)
+    assert torch.allclose(feat.grad, gref, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,n,m", [(4, 64, 128), (16, 8, 32), (16, 32, 32), (3, 1, 5), (2, 300, 1500), (1, 2048, 1024), (8192, 8, 32)])
+def test_chamfer_fwd_bwd(dev, B, n, m):
+    from act_amd.extensions.chamfer_dist import chamfer, ChamferFunction
+    from oracle import point_ops as OP
+    x = clouds(20 + n, B, n); y = clouds(21 + m, B, m)
+    if n > 4:
+        y[:, 1] = y[:, 0]                                    # duplicate target -> tie -> lowest index must win
+    xt = torch.from_numpy(x).to(dev); yt = torch.from_numpy(y).to(dev)
+    d1, d2, i1, i2 = chamfer.forward(xt, yt)
+    r = OP.chamfer_fwd_ref(x, y)
+    assert i1.dtype == torch.int32
+    for a, b in zip((d1, d2, i1, i2), r):
+        assert np.array_equal(a.cpu().numpy(), b)
+    g1 = fill_tensor(f"ch.g1.{B}.{n}", (B, n), "code").numpy(); g2 = fill_tensor(f"ch.g2.{B}.{m}", (B, m), "code").numpy()
+    gx1, gx2 = chamfer.backward(xt, yt, i1, i2, torch.from_numpy(g1).to(dev), torch.from_numpy(g2).to(dev))
+    ox1, ox2 = OP.chamfer_bwd_ref(x, y, r[2], r[3], g1, g2)
+    assert np.abs(gx1.cpu().numpy() - ox1).max() <= 1e-4 * max(1, np.abs(ox1).max())
+    assert np.abs(gx2.cpu().numpy() - ox2).max() <= 1e-4 * max(1, np.abs(ox2).max())
+    # deterministic backward (the reference's atomicAdd scatter is not)
+    gx1b, _ = chamfer.backward(xt, yt, i1, i2, torch.from_numpy(g1).to(dev), torch.from_numpy(g2).to(dev))
+    assert torch.equal(gx1, gx1b)
+
+
+def test_chamfer_modules_against_golden(dev):
+    from act_amd.extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2, ChamferDistanceL2_split
+    g = golden("g5_chamfer")
+    x = fill_tensor("g5.x", (4, 64, 3), "code").to(dev).requires_grad_(True); y = fill_tensor("g5.y", (4, 128, 3), "code").to(dev)
+    l1 = ChamferDistanceL1()(x, y); l2 = ChamferDistanceL2()(x, y)
+    assert abs(l1.item() - g["l1"]) <= 1e-4 and abs(l2.item() - g["l2"]) <= 1e-4
+    a, b = ChamferDistanceL2_split()(x, y)
+    assert abs((a + b).item() - g["l2"]) <= 1e-4
+    l1.backward()
+    assert torch.isfinite(x.grad).all()
+    # zero on identical clouds, symmetric under swap
+    assert ChamferDistanceL2()(y, y).item() == 0
+    assert abs(ChamferDistanceL1()(y, x.detach()).item() - g["l1"]) <= 1e-4
+    # errors raise instead of being printed
+    with pytest.raises(RuntimeError):
+        ChamferDistanceL2()(x.detach().cpu(), y)
+
+
+def test_scale_translate(dev):
+    import act_amd._C as C
+    g = golden("g9_augment")
+    pc = torch.from_numpy(clouds(9, 2, 128)).to(dev)
+    sc = torch.from_numpy(g["scale"].astype(np.float32)).to(dev); sh = torch.from_numpy(g["shift"].astype(np.float32)).to(dev)
+    C.check(C.lib.act_scale_translate_f32(C.ptr(pc), C.ptr(sc), C.ptr(sh), 2, 128, C.stream()), "aug")
+    assert np.abs(pc.cpu().numpy() - g["out"]).max() <= 1e-6
+
+
+def test_profiler_reports_launches(dev):
+    import act_amd._C as C
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    C.prof_reset(); C.prof_enable(True)
+    x = torch.from_numpy(clouds(3, 8, 1024)).to(dev)
+    for _ in range(3):
+        pu.furthest_point_sample(x, 64)
+    C.prof_enable(False)
+    t = C.prof_table()
+    assert t["fps"]["launches"] == 3 and t["fps"]["ms"] > 0 and t["fps"]["bytes"] == 3 * 8 * (12 * 1024 + 4 * 64)
