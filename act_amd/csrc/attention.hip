@@ -1,0 +1,337 @@
+// attention.hip -- fused multi-head self-attention for the short sequences of ACT (S = 14 / 64 / 128 tokens,
+// head_dim 64; models/act.py:57-69 == utils/transformer_layers.py:170-182):  softmax(q k^T * hd^-1/2) v.
+//
+// Forward (MFMA, fp32 exact): the packed projection output qkv [B,S,3,H,hd] is consumed in place and the result is
+// written in the [B,S,H*hd] layout the output projection GEMM reads -- no permutes, no S x S matrix in memory.
+// One wave owns 32 query rows of one (cloud, head).  It computes the TRANSPOSED score tile S^T = K Q^T with
+// v_mfma_f32_32x32x2_f32 so that, in the MFMA C/D layout, every lane ends up holding all scores of ONE query
+// (its lane&31) for 16 keys per 32-key tile: softmax is then a pure in-register reduction plus a single
+// lane^32 exchange, and the probabilities are already in the B-operand layout of the second product
+// O^T = V^T P^T.  K and V are staged once per (cloud, head) in LDS ([key][hd+4]: conflict-free b128 A-operand
+// reads for K, conflict-free b32 reads for V); Q rows are loaded straight into registers.
+//
+// Backward (student only: S = 14 and 64): one workgroup per (cloud, head), everything resident in LDS,
+// P recomputed from the saved log-sum-exp, register-blocked 4x4 VALU micro-tiles; writes dqkv in the packed layout.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int HD, int JT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                       float* __restrict__ lse, int B, int S, int H, float scale) {
+    constexpr int LDK = HD + 4;
+    constexpr int PAIRS = (JT == 1) ? 4 : (JT == 2 ? 2 : 1);       // (cloud, head) pairs per workgroup
+    constexpr int ROWS = JT * 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];    // [PAIRS][2][ROWS][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long npairs = (long long)B * H;
+    const long long pair0 = (long long)blockIdx.x * PAIRS;
+    const int rs = 3 * H * HD;                                      // qkv row stride (floats)
+
+    // ---- stage K and V of every pair of this workgroup (zero rows beyond S)
+    for (int idx = tid; idx < PAIRS * ROWS * (HD / 4); idx += 256) {
+        const int c4 = idx % (HD / 4);
+        const int row = (idx / (HD / 4)) % ROWS;
+        const int pl = idx / ((HD / 4) * ROWS);
+        const long long pr = pair0 + pl;
+        float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
+        if (pr < npairs && row < S) {
+            const int b = (int)(pr / H), h = (int)(pr % H);
+            const float* base = qkv + ((size_t)b * S + row) * rs + h * HD + c4 * 4;
+            kx = *reinterpret_cast<const float4*>(base + H * HD);
+            vx = *reinterpret_cast<const float4*>(base + 2 * H * HD);
+        }
+        float* ks = smem + ((size_t)(pl * 2 + 0) * ROWS + row) * LDK + c4 * 4;
+        float* vs = smem + ((size_t)(pl * 2 + 1) * ROWS + row) * LDK + c4 * 4;
+        *reinterpret_cast<float4*>(ks) = kx;
+        *reinterpret_cast<float4*>(vs) = vx;
+    }
+    __syncthreads();
+
+    const int pl = wave / JT, qt = wave % JT;
+    const long long pr = pair0 + pl;
+    if (pl >= PAIRS || pr >= npairs || qt * 32 >= S) return;        // idle wave (no further barriers below)
+    const int b = (int)(pr / H), h = (int)(pr % H);
+    const float* Ks = smem + (size_t)(pl * 2 + 0) * ROWS * LDK;
+    const float* Vs = smem + (size_t)(pl * 2 + 1) * ROWS * LDK;
+    const int ql = lane & 31, half = lane >> 5;
+    const int q = qt * 32 + ql;
+
+    // ---- Q operand: lane (q, half) holds Q[q][half*HD/2 + s], s = 0..HD/2-1
+    float qreg[HD / 2];
+    {
+        const float* qp = qkv + ((size_t)b * S + min(q, S - 1)) * rs + h * HD + half * (HD / 2);
+#pragma unroll
+        for (int s4 = 0; s4 < HD / 8; ++s4) {
+            float4 t = *reinterpret_cast<const float4*>(qp + s4 * 4);
+            if (q >= S) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            qreg[s4 * 4 + 0] = t.x; qreg[s4 * 4 + 1] = t.y; qreg[s4 * 4 + 2] = t.z; qreg[s4 * 4 + 3] = t.w;
+        }
+    }
+    // ---- S^T tiles: acc[jt][r] = score(key = jt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
+    f32x16 acc[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+        const float* kp = Ks + (size_t)(jt * 32 + ql) * LDK + half * (HD / 2);
+#pragma unroll
+        for (int s4 = 0; s4 < HD / 8; ++s4) {
+            const float4 a = *reinterpret_cast<const float4*>(kp + s4 * 4);
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[s4 * 4 + 0], acc[jt], 0, 0, 0);
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[s4 * 4 + 1], acc[jt], 0, 0, 0);
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[s4 * 4 + 2], acc[jt], 0, 0, 0);
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[s4 * 4 + 3], acc[jt], 0, 0, 0);
+        }
+    }
+    // ---- softmax over keys (registers + one lane^32 exchange)
+    float m = -3.0e38f;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float v = key < S ? acc[jt][r] : -3.0e38f;
+            acc[jt][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(scale * (acc[jt][r] - m));      // masked keys: exp(-huge) == 0
+            acc[jt][r] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 32);
+    const float inv_l = 1.0f / l;
+    // ---- O^T = V^T P^T : o[dt][r] = out(d = dt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // this half-wave's k index for step r
+            const float* vp = Vs + (size_t)key * LDK + ql;
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], acc[jt][r], o[dt], 0, 0, 0);
+        }
+    if (q < S) {
+        float* op = out + ((size_t)b * S + q) * (H * HD) + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 t;
+                t.x = o[dt][g * 4 + 0] * inv_l; t.y = o[dt][g * 4 + 1] * inv_l;
+                t.z = o[dt][g * 4 + 2] * inv_l; t.w = o[dt][g * 4 + 3] * inv_l;
+                *reinterpret_cast<float4*>(op + dt * 32 + 8 * g + 4 * half) = t;
+            }
+        if (lse && half == 0) lse[((size_t)b * H + h) * S + q] = scale * m + __logf(l);
+    }
+}
+
+// -------------------------------------------------------------------------------- backward (VALU, LDS resident)
+// thread micro-tile helper: rows {ri + u*RS}, cols {ci + v*CS}
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                       const float* __restrict__ dout, const float* __restrict__ lse,
+                                                       float* __restrict__ dqkv, int B, int S, int H, float scale) {
+    constexpr int LD = HD + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int S4 = (S + 3) & ~3;                       // padded sequence (zero rows)
+    const int LDP = S4 + 4;
+    float* Qs = smem;                                   // [S4][LD]
+    float* Ks = Qs + (size_t)S4 * LD;
+    float* Vs = Ks + (size_t)S4 * LD;
+    float* Os = Vs + (size_t)S4 * LD;                   // dO
+    float* Ps = Os + (size_t)S4 * LD;                   // [S4][LDP]  P then dS
+    float* Dl = Ps + (size_t)S4 * LDP;                  // [S4] D[q], then [S4] lse
+    float* Ll = Dl + S4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int rs = 3 * H * HD;
+    const int rq = S4 / 4;                              // micro-tile strides
+
+    for (int idx = tid; idx < S4 * (HD / 4); idx += 256) {
+        const int c4 = idx % (HD / 4), row = idx / (HD / 4);
+        float4 qx = make_float4(0.f, 0.f, 0.f, 0.f), kx = qx, vx = qx, ox = qx;
+        if (row < S) {
+            const float* base = qkv + ((size_t)b * S + row) * rs + h * HD + c4 * 4;
+            qx = *reinterpret_cast<const float4*>(base);
+            kx = *reinterpret_cast<const float4*>(base + H * HD);
+            vx = *reinterpret_cast<const float4*>(base + 2 * H * HD);
+            ox = *reinterpret_cast<const float4*>(dout + ((size_t)b * S + row) * (H * HD) + h * HD + c4 * 4);
+        }
+        *reinterpret_cast<float4*>(Qs + (size_t)row * LD + c4 * 4) = qx;
+        *reinterpret_cast<float4*>(Ks + (size_t)row * LD + c4 * 4) = kx;
+        *reinterpret_cast<float4*>(Vs + (size_t)row * LD + c4 * 4) = vx;
+        *reinterpret_cast<float4*>(Os + (size_t)row * LD + c4 * 4) = ox;
+    }
+    // D[q] = sum_d dO[q][d] * O[q][d]   (one wave per row)
+    for (int row = wave; row < S4; row += 4) {
+        float acc = 0.f;
+        if (row < S)
+            for (int d = lane; d < HD; d += 64)
+                acc += dout[((size_t)b * S + row) * (H * HD) + h * HD + d] * out[((size_t)b * S + row) * (H * HD) + h * HD + d];
+        acc = wave_sum_f32(acc);
+        if (lane == 0) { Dl[row] = acc; Ll[row] = row < S ? lse[((size_t)b * H + h) * S + row] : 0.f; }
+    }
+    __syncthreads();
+
+    // ---- P[q][k] = exp(scale * q.k - lse[q])
+    for (int mt = tid; mt < rq * rq; mt += 256) {
+        const int ki = mt % rq, qi = mt / rq;
+        float acc[4][4] = {};
+        for (int d = 0; d < HD; d += 4) {
+            float4 a[4], bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Qs + (size_t)(qi + u * rq) * LD + d);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Ks + (size_t)(ki + v * rq) * LD + d);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int qq = qi + u * rq, kk = ki + v * rq;
+                Ps[(size_t)qq * LDP + kk] = (qq < S && kk < S) ? __expf(scale * acc[u][v] - Ll[qq]) : 0.f;
+            }
+    }
+    __syncthreads();
+    float* dq_base = dqkv + (size_t)b * S * rs + h * HD;
+    // ---- dV[k][d] = sum_q P[q][k] dO[q][d]
+    for (int mt = tid; mt < rq * (HD / 4); mt += 256) {
+        const int di = mt % (HD / 4), ki = mt / (HD / 4);
+        float acc[4][4] = {};
+        for (int qq = 0; qq < S; ++qq) {
+            float p[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) p[u] = Ps[(size_t)qq * LDP + ki + u * rq];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) g[v] = Os[(size_t)qq * LD + di + v * (HD / 4)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += p[u] * g[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kk = ki + u * rq;
+            if (kk < S)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dq_base[(size_t)kk * rs + 2 * H * HD + di + v * (HD / 4)] = acc[u][v];
+        }
+    }
+    __syncthreads();
+    // ---- dS = P * (dP - D) * scale, dP[q][k] = sum_d dO[q][d] V[k][d]   (in place over P)
+    for (int mt = tid; mt < rq * rq; mt += 256) {
+        const int ki = mt % rq, qi = mt / rq;
+        float acc[4][4] = {};
+        for (int d = 0; d < HD; d += 4) {
+            float4 a[4], bb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Os + (size_t)(qi + u * rq) * LD + d);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Vs + (size_t)(ki + v * rq) * LD + d);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int qq = qi + u * rq, kk = ki + v * rq;
+                const size_t o = (size_t)qq * LDP + kk;
+                Ps[o] = Ps[o] * (acc[u][v] - Dl[qq]) * scale;
+            }
+    }
+    __syncthreads();
+    // ---- dQ[q][d] = sum_k dS[q][k] K[k][d] ;  dK[k][d] = sum_q dS[q][k] Q[q][d]
+    for (int mt = tid; mt < 2 * rq * (HD / 4); mt += 256) {
+        const bool is_k = mt >= rq * (HD / 4);
+        const int m2 = is_k ? mt - rq * (HD / 4) : mt;
+        const int di = m2 % (HD / 4), ri = m2 / (HD / 4);
+        float acc[4][4] = {};
+        const float* X = is_k ? Qs : Ks;
+        for (int t = 0; t < S; ++t) {
+            float p[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                p[u] = is_k ? Ps[(size_t)t * LDP + ri + u * rq] : Ps[(size_t)(ri + u * rq) * LDP + t];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) g[v] = X[(size_t)t * LD + di + v * (HD / 4)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += p[u] * g[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = ri + u * rq;
+            if (rr < S)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dq_base[(size_t)rr * rs + (is_k ? H * HD : 0) + di + v * (HD / 4)] = acc[u][v];
+        }
+    }
+}
+
+template <int HD>
+static int launch_attn_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, float scale, hipStream_t s) {
+    const int JT = (S + 31) / 32;
+    const int pairs = JT == 1 ? 4 : (JT == 2 ? 2 : 1);
+    const size_t smem = (size_t)pairs * 2 * JT * 32 * (HD + 4) * sizeof(float);
+    const long long np = (long long)B * H;
+    const unsigned grid = (unsigned)((np + pairs - 1) / pairs);
+#define FWD(J) { auto k = attn_fwd_kernel<HD, J>; \
+        if (smem > 48 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; } \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, qkv, out, lse, B, S, H, scale); }
+    switch (JT) { case 1: FWD(1) break; case 2: FWD(2) break; case 3: FWD(3) break; case 4: FWD(4) break; default: return ACT_E_BADARG; }
+#undef FWD
+    ACT_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int act_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int S, int H, int head_dim, float scale,
+                                     act_stream_t stream) {
+    if (!qkv || !out) return ACT_E_NULLPTR;
+    if (B < 0 || S <= 0 || H <= 0 || S > 128 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_ATTN_FWD, s, 4.0 * B * H * (double)S * S * head_dim, 16.0 * B * S * (double)H * head_dim);
+    return head_dim == 64 ? launch_attn_fwd<64>(qkv, out, lse, B, S, H, scale, s) : launch_attn_fwd<32>(qkv, out, lse, B, S, H, scale, s);
+}
+
+extern "C" int act_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                     int B, int S, int H, int head_dim, float scale, act_stream_t stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv) return ACT_E_NULLPTR;
+    if (B < 0 || S <= 0 || H <= 0 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
+    if (B == 0) return 0;
+    const int S4 = (S + 3) & ~3;
+    const size_t smem = ((size_t)4 * S4 * (head_dim + 4) + (size_t)S4 * (S4 + 4) + 2 * S4) * sizeof(float);
+    if (smem > 160 * 1024) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)S * S * head_dim, 28.0 * B * S * (double)H * head_dim);
+#define BWD(HD) { auto k = attn_bwd_kernel<HD>; \
+        if (smem > 48 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; } \
+        hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(256), smem, s, qkv, out, dout, lse, dqkv, B, S, H, scale); }
+    if (head_dim == 64) BWD(64) else BWD(32)
+#undef BWD
+    ACT_LAUNCH_CHECK();
+    return 0;
+}

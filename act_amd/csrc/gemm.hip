@@ -1,0 +1,289 @@
+// gemm.hip -- fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32) with fused epilogues.
+//
+// One kernel family serves every dense product on the ACT hot path:
+//   Linear / Conv1d(k=1) forward   C[M,N] = A[M,K] . W[N,K]^T      (a_kmajor=1, b_kmajor=1)
+//   input gradient                 dX[M,K'] = dY[M,N'] . W[N',K']   (a_kmajor=1, b_kmajor=0)
+//   weight gradient                dW[N',K'] = dY[T,N']^T . X[T,K'] (a_kmajor=0, b_kmajor=0, split-K over T)
+// (reference ops: nn.Linear in models/act.py:25-69, Conv1d(k=1) in models/dvae.py:185-215, timm ViT blocks.)
+//
+// Tiling for 64-wide wavefronts: a 256-thread workgroup (4 waves as 2x2) owns a BM x BN tile, each wave a
+// (BM/2)x(BN/2) sub-tile made of 32x32 MFMA accumulators.  Operands are staged through LDS as [k][row]
+// (row contiguous, +4 pad) so every MFMA operand fetch is a conflict-free ds_read_b32 of 32 consecutive
+// dwords per half-wave; K-contiguous global operands are transposed on the LDS write, row-contiguous ones are
+// stored with ds_write_b128.  Global loads for tile t+1 are issued before the MFMAs of tile t (register
+// staging, double-buffered LDS, one barrier per K-tile).  Workgroup ids are remapped so each XCD (own L2)
+// works on a compact band of tiles.  The epilogue fuses bias, GELU / ReLU (+ saving the pre-activation),
+// activation-gradient multiply, per-row scale (DropPath gate) and residual add.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GEMM_BK 16
+
+struct GemmParams {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc;
+    int k_per_split;                 // K range per blockIdx.z (== K when no split)
+    float* partial;                  // split-K workspace [splits][M][N] (C untouched) or null
+    act_gemm_epilogue_t epi;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, float v, int row, int col) {
+    v *= e.alpha;
+    if (e.bias) v += e.bias[col];
+    switch (e.act) {
+        case ACT_EPI_GELU:      if (e.aux) e.aux[(size_t)row * e.ldaux + col] = v; v = gelu_f(v); break;
+        case ACT_EPI_RELU:      v = fmaxf(v, 0.f); break;
+        case ACT_EPI_MUL_GELU_GRAD: v *= gelu_grad_f(e.aux[(size_t)row * e.ldaux + col]); break;
+        case ACT_EPI_MUL_RELU_MASK: v = e.aux[(size_t)row * e.ldaux + col] > 0.f ? v : 0.f; break;
+        default: break;
+    }
+    if (e.rowscale) v *= e.rowscale[row / e.rows_per_scale];
+    if (e.res) v += e.res[(size_t)row * e.ldr + col];
+    return v;
+}
+
+template <int BM, int BN, bool A_K, bool B_K, bool VEC>
+__global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
+    constexpr int BK = GEMM_BK;
+    constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
+    constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 accumulators per wave
+    constexpr int NA = BM / 64, NB = BN / 64;          // float4 loads per thread per operand per K-tile
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware remap: workgroup b is dispatched to XCD b%8; give each XCD a contiguous band of tiles
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile_m = wg / p.tiles_n, tile_n = wg % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int ntiles = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[NA], rb[NB];
+
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + 256 * i;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (A_K) {                                   // A stored [M][K]
+                const int row = m0 + (v >> 2), kk = k0 + (v & 3) * 4;
+                if (row < p.M) {
+                    const float* src = p.A + (size_t)row * p.lda + kk;
+                    if (VEC) { if (kk < kend) x = *reinterpret_cast<const float4*>(src); }
+                    else { if (kk < kend) x.x = src[0]; if (kk + 1 < kend) x.y = src[1]; if (kk + 2 < kend) x.z = src[2]; if (kk + 3 < kend) x.w = src[3]; }
+                }
+            } else {                                     // A stored [K][M]
+                const int kk = k0 + v / (BM / 4), row = m0 + (v % (BM / 4)) * 4;
+                if (kk < kend) {
+                    const float* src = p.A + (size_t)kk * p.lda + row;
+                    if (VEC) { if (row < p.M) x = *reinterpret_cast<const float4*>(src); }
+                    else { if (row < p.M) x.x = src[0]; if (row + 1 < p.M) x.y = src[1]; if (row + 2 < p.M) x.z = src[2]; if (row + 3 < p.M) x.w = src[3]; }
+                }
+            }
+            ra[i] = x;
+        }
+    };
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int v = tid + 256 * i;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (B_K) {                                   // B stored [N][K]
+                const int row = n0 + (v >> 2), kk = k0 + (v & 3) * 4;
+                if (row < p.N) {
+                    const float* src = p.B + (size_t)row * p.ldb + kk;
+                    if (VEC) { if (kk < kend) x = *reinterpret_cast<const float4*>(src); }
+                    else { if (kk < kend) x.x = src[0]; if (kk + 1 < kend) x.y = src[1]; if (kk + 2 < kend) x.z = src[2]; if (kk + 3 < kend) x.w = src[3]; }
+                }
+            } else {                                     // B stored [K][N]
+                const int kk = k0 + v / (BN / 4), row = n0 + (v % (BN / 4)) * 4;
+                if (kk < kend) {
+                    const float* src = p.B + (size_t)kk * p.ldb + row;
+                    if (VEC) { if (row < p.N) x = *reinterpret_cast<const float4*>(src); }
+                    else { if (row < p.N) x.x = src[0]; if (row + 1 < p.N) x.y = src[1]; if (row + 2 < p.N) x.z = src[2]; if (row + 3 < p.N) x.w = src[3]; }
+                }
+            }
+            rb[i] = x;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int v = tid + 256 * i;
+            if (A_K) {
+                float* d = &As[buf][((v & 3) * 4) * LDA_S + (v >> 2)];
+                d[0] = ra[i].x; d[LDA_S] = ra[i].y; d[2 * LDA_S] = ra[i].z; d[3 * LDA_S] = ra[i].w;
+            } else {
+                *reinterpret_cast<float4*>(&As[buf][(v / (BM / 4)) * LDA_S + (v % (BM / 4)) * 4]) = ra[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int v = tid + 256 * i;
+            if (B_K) {
+                float* d = &Bs[buf][((v & 3) * 4) * LDB_S + (v >> 2)];
+                d[0] = rb[i].x; d[LDB_S] = rb[i].y; d[2 * LDB_S] = rb[i].z; d[3 * LDB_S] = rb[i].w;
+            } else {
+                *reinterpret_cast<float4*>(&Bs[buf][(v / (BN / 4)) * LDB_S + (v % (BN / 4)) * 4]) = rb[i];
+            }
+        }
+    };
+
+    if (ntiles > 0) {
+        load_a(kbeg); load_b(kbeg);
+        store_lds(0);
+        __syncthreads();
+    }
+    const int a_off = wm * (BM / 2) + (lane & 31), b_off = wn * (BN / 2) + (lane & 31), khalf = lane >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) { load_a(kbeg + (t + 1) * BK); load_b(kbeg + (t + 1) * BK); }
+        const float* as = As[buf];
+        const float* bs = Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = as[(kk + khalf) * LDA_S + a_off + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = bs[(kk + khalf) * LDB_S + b_off + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + col_l;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.partial) {
+                    p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v = epilogue_apply(p.epi, v, row, col);
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.epi.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
+// split-K reduction + epilogue (deterministic: fixed summation order over splits)
+__global__ void sgemm_splitk_reduce(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
+                                    const act_gemm_epilogue_t epi) {
+    const long long total = (long long)M * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + i];
+        const int row = (int)(i / N), col = (int)(i % N);
+        v = epilogue_apply(epi, v, row, col);
+        float* c = C + (size_t)row * ldc + col;
+        if (epi.accumulate) v += *c;
+        *c = v;
+    }
+}
+
+template <int BM, int BN>
+static void launch_variant(const GemmParams& p, int ak, int bk, bool vec, dim3 grid, hipStream_t s) {
+#define L(AK, BKK, V) hipLaunchKernelGGL((sgemm_kernel<BM, BN, AK, BKK, V>), grid, dim3(256), 0, s, p)
+    if (ak && bk)       { if (vec) L(true, true, true);   else L(true, true, false); }
+    else if (ak && !bk) { if (vec) L(true, false, true);  else L(true, false, false); }
+    else if (!ak && !bk){ if (vec) L(false, false, true); else L(false, false, false); }
+    else                { if (vec) L(false, true, true);  else L(false, true, false); }
+#undef L
+}
+
+extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                             float* C, int ldc, const act_gemm_epilogue_t* epi_in, float* workspace, size_t workspace_bytes,
+                             act_stream_t stream) {
+    if (!A || !B || !C) return ACT_E_NULLPTR;
+    if (M < 0 || N < 0 || K < 0) return ACT_E_BADARG;
+    if (M == 0 || N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    if (epi_in) p.epi = *epi_in;
+    else { p.epi = act_gemm_epilogue_t{}; p.epi.alpha = 1.0f; }
+    if (p.epi.rowscale && p.epi.rows_per_scale <= 0) return ACT_E_BADARG;
+    if ((p.epi.act == ACT_EPI_MUL_GELU_GRAD || p.epi.act == ACT_EPI_MUL_RELU_MASK) && !p.epi.aux) return ACT_E_NULLPTR;
+
+    const int kid = (a_kmajor && b_kmajor) ? KID_GEMM_NT : (a_kmajor ? KID_GEMM_NN : KID_GEMM_TN);
+    ActProfScope ps(kid, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+
+    // vector path: every float4 is fully in range or fully out, and 16-byte aligned
+    const bool vec = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && (lda & 3) == 0 &&
+                     (ldb & 3) == 0 && (a_kmajor ? (K & 3) == 0 : (M & 3) == 0) && (b_kmajor ? (K & 3) == 0 : (N & 3) == 0);
+
+    // tile shape: fill the 256 CUs; prefer the big tile when it still gives >= 1 wave of workgroups
+    int BM = 128, BN = 128;
+    auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (tiles(128, 128) < 192) { BM = 64; BN = 64; if (tiles(128, 64) >= 256) { BM = 128; BN = 64; } }
+    p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    const long long nt = (long long)p.tiles_m * p.tiles_n;
+
+    // split-K when the tile grid cannot fill the chip and K is long (weight gradients: K = tokens)
+    int splits = 1;
+    if (nt < 256 && K >= 1024 && workspace) {
+        splits = (int)((512 + nt - 1) / nt);
+        const int maxs = K / 256; if (splits > maxs) splits = maxs;
+        if (splits > 64) splits = 64;
+        while (splits > 1 && (size_t)splits * M * N * sizeof(float) > workspace_bytes) --splits;
+        if (splits < 1) splits = 1;
+    }
+    int kps = K;
+    if (splits > 1) { kps = (K + splits - 1) / splits; kps = (kps + GEMM_BK - 1) / GEMM_BK * GEMM_BK; splits = (K + kps - 1) / kps; }
+    p.k_per_split = kps;
+    p.partial = splits > 1 ? workspace : nullptr;
+    if (K == 0) { p.k_per_split = 0; }
+
+    dim3 grid((unsigned)nt, 1, (unsigned)splits);
+    if (BM == 128 && BN == 128) launch_variant<128, 128>(p, a_kmajor, b_kmajor, vec, grid, s);
+    else if (BM == 128)         launch_variant<128, 64>(p, a_kmajor, b_kmajor, vec, grid, s);
+    else                        launch_variant<64, 64>(p, a_kmajor, b_kmajor, vec, grid, s);
+    ACT_LAUNCH_CHECK();
+    if (splits > 1) {
+        const long long total = (long long)M * N;
+        long long g = (total + 255) / 256; if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(sgemm_splitk_reduce, dim3((unsigned)g), dim3(256), 0, s, workspace, splits, M, N, C, ldc, p.epi);
+        ACT_LAUNCH_CHECK();
+    }
+    return 0;
+}

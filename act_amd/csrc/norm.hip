@@ -1,0 +1,273 @@
+// norm.hip -- row-wise fused kernels around the GEMMs of a Transformer block (gfx950):
+//   * pos-add + LayerNorm forward   (models/act.py:87-90,109-112: x = blk(x + pos); blk: x + attn(norm1(x)) ...)
+//   * LayerNorm backward (dx fused with the residual-stream gradient; dgamma/dbeta two-stage, deterministic)
+//   * column sums (bias gradients)
+//   * cosine distillation loss forward / backward (models/act.py:1243-1254, lightly NegativeCosineSimilarity)
+// One wave per row: a row of D=384/768 floats sits in registers (float4 per lane), statistics come from DPP
+// wave reductions, nothing is staged through LDS.  All kernels are HBM-bound: one read + one write per element.
+#include "common.h"
+
+#define LN_MAXV 8          // float4 per lane: D <= 64*4*8 = 2048
+
+// y = LN(x + pos) * gamma + beta ; optionally stores xin = x + pos (needed for the residual) ; mean/rstd for backward.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ xin_out, float* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int T, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int nv = D >> 2;                                // float4 per row
+    const float4* __restrict__ xr = reinterpret_cast<const float4*>(x + (size_t)row * D);
+    const float4* __restrict__ pr = pos ? reinterpret_cast<const float4*>(pos + (size_t)row * D) : nullptr;
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 a = xr[c];
+            if (pr) { const float4 b = pr[c]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+            v[i] = a;
+            s += (a.x + a.y) + (a.z + a.w);
+        } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float mean = wave_sum_f32(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float var = wave_sum_f32(q) / (float)D;
+    const float rstd = rsqrtf(var + eps);
+    float4* __restrict__ yr = reinterpret_cast<float4*>(y + (size_t)row * D);
+    float4* __restrict__ xo = xin_out ? reinterpret_cast<float4*>(xin_out + (size_t)row * D) : nullptr;
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 g = g4[c], b = b4[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            yr[c] = o;
+            if (xo) xo[c] = v[i];
+        }
+    }
+    if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
+}
+
+// dx = dres + rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) ; per-block partial dgamma/dbeta
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xin,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, float* __restrict__ part_dg,
+                                                            float* __restrict__ part_db, int T, int D, int rows_per_block) {
+    __shared__ float sred[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gamma);
+    float4 ag[LN_MAXV], ab[LN_MAXV];                   // this lane's dgamma / dbeta accumulators
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(T, r0 + rows_per_block);
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float4* __restrict__ dyr = reinterpret_cast<const float4*>(dy + (size_t)row * D);
+        const float4* __restrict__ xr = reinterpret_cast<const float4*>(xin + (size_t)row * D);
+        const float mu = mean[row], rs = rstd[row];
+        float4 h[LN_MAXV], w[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 d = dyr[c], x = xr[c], g = g4[c];
+                float4 xh; xh.x = (x.x - mu) * rs; xh.y = (x.y - mu) * rs; xh.z = (x.z - mu) * rs; xh.w = (x.w - mu) * rs;
+                float4 dg; dg.x = d.x * g.x; dg.y = d.y * g.y; dg.z = d.z * g.z; dg.w = d.w * g.w;
+                h[i] = xh; w[i] = dg;
+                s1 += (dg.x + dg.y) + (dg.z + dg.w);
+                s2 += (dg.x * xh.x + dg.y * xh.y) + (dg.z * xh.z + dg.w * xh.w);
+                ag[i].x += d.x * xh.x; ag[i].y += d.y * xh.y; ag[i].z += d.z * xh.z; ag[i].w += d.w * xh.w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+            }
+        }
+        const float m1 = wave_sum_f32(s1) / (float)D, m2 = wave_sum_f32(s2) / (float)D;
+        float4* __restrict__ dxr = reinterpret_cast<float4*>(dx + (size_t)row * D);
+        const float4* __restrict__ drr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * D) : nullptr;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                float4 o;
+                o.x = rs * (w[i].x - m1 - h[i].x * m2); o.y = rs * (w[i].y - m1 - h[i].y * m2);
+                o.z = rs * (w[i].z - m1 - h[i].z * m2); o.w = rs * (w[i].w - m1 - h[i].w * m2);
+                if (drr) { const float4 r = drr[c]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+                dxr[c] = o;
+            }
+        }
+    }
+    // combine the 4 waves' partials through LDS-free global partial rows: [gridDim.x*4][D]
+    if (part_dg) {
+        float4* __restrict__ pg = reinterpret_cast<float4*>(part_dg + ((size_t)blockIdx.x * 4 + wave) * D);
+        float4* __restrict__ pb = reinterpret_cast<float4*>(part_db + ((size_t)blockIdx.x * 4 + wave) * D);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) { const int c = lane + 64 * i; if (c < nv) { pg[c] = ag[i]; pb[c] = ab[i]; } }
+    }
+    (void)sred;
+}
+
+// out[c] (+)= sum_r in[r][c]   -- two-stage, fixed order (deterministic).  stage 1: partial[blk][c]
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ in, int R, int C, int ld, int rows_per_block,
+                                                     float* __restrict__ partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += in[(size_t)r * ld + c];
+    partial[(size_t)blockIdx.y * C + c] = acc;
+}
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out,
+                                                     int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += partial[(size_t)p * C + c];
+    out[c] = accumulate ? out[c] + acc : acc;
+}
+
+// cosine distillation loss: rows [R,D] ; loss = mean_r (1 - cos(s_r, t_r)), cos with torch's eps semantics
+// (x.y / max(|x|*|y|, eps)).  Stores per-row dot/norms for the backward.
+__global__ __launch_bounds__(256) void cosine_fwd_kernel(const float* __restrict__ s, const float* __restrict__ t, int R, int D,
+                                                         float eps, float* __restrict__ row_loss, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float dot = 0.f, ss = 0.f, tt = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float a = s[(size_t)row * D + c], b = t[(size_t)row * D + c];
+        dot += a * b; ss += a * a; tt += b * b;
+    }
+    dot = wave_sum_f32(dot); ss = wave_sum_f32(ss); tt = wave_sum_f32(tt);
+    const float denom = fmaxf(sqrtf(ss * tt), eps);
+    if (lane == 0) {
+        row_loss[row] = 1.0f - dot / denom;
+        stats[row * 3 + 0] = dot; stats[row * 3 + 1] = ss; stats[row * 3 + 2] = tt;
+    }
+}
+// d loss / d s_r = -gscale * ( t/denom - dot * s * tt / denom^3 )   (denom = sqrt(ss*tt), clamped region has zero 2nd term)
+__global__ __launch_bounds__(256) void cosine_bwd_kernel(const float* __restrict__ s, const float* __restrict__ t,
+                                                         const float* __restrict__ stats, const float* __restrict__ gout,
+                                                         int R, int D, float eps, float inv_rows, float* __restrict__ ds) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float dot = stats[row * 3 + 0], ss = stats[row * 3 + 1], tt = stats[row * 3 + 2];
+    const float nrm = sqrtf(ss * tt);
+    const float g = -gout[0] * inv_rows;
+    float ca, cb;
+    if (nrm > eps) { ca = 1.0f / nrm; cb = dot * tt / (nrm * nrm * nrm); }
+    else { ca = 1.0f / eps; cb = 0.f; }
+    for (int c = lane; c < D; c += 64) {
+        const float a = s[(size_t)row * D + c], b = t[(size_t)row * D + c];
+        ds[(size_t)row * D + c] = g * (b * ca - a * cb);
+    }
+}
+// mean of a vector (deterministic, single block) -> out[0]
+__global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    const int per = (n + 1023) / 1024, k0 = threadIdx.x * per, k1 = min(n, k0 + per);
+    for (int k = k0; k < k1; ++k) acc += v[k];
+    acc = wave_sum_f32(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { float tot = 0.f; for (int w = 0; w < 16; ++w) tot += sh[w]; out[0] = tot / (float)n; }
+}
+
+extern "C" int act_layernorm_fwd_f32(const float* x, const float* pos, const float* gamma, const float* beta, float* xin_out,
+                                     float* y, float* mean, float* rstd, int T, int D, float eps, act_stream_t stream) {
+    if (!x || !gamma || !beta || !y) return ACT_E_NULLPTR;
+    if (T < 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV) return ACT_E_BADARG;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_LAYERNORM_FWD, s, 0.0, 4.0 * T * (double)D * (2 + (pos ? 1 : 0) + (xin_out ? 1 : 0)));
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, pos, gamma, beta, xin_out, y, mean, rstd, T, D, eps);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" size_t act_layernorm_bwd_workspace(int T, int D) {
+    const int rpb = 64; const int nblk = (T + rpb - 1) / rpb;
+    return (size_t)nblk * 4 * D * 2 * sizeof(float);
+}
+
+extern "C" int act_layernorm_bwd_f32(const float* dy, const float* xin, const float* gamma, const float* mean, const float* rstd,
+                                     const float* dres, float* dx, float* dgamma, float* dbeta, int accumulate_params,
+                                     float* workspace, size_t workspace_bytes, int T, int D, act_stream_t stream) {
+    if (!dy || !xin || !gamma || !mean || !rstd || !dx) return ACT_E_NULLPTR;
+    if (T < 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV) return ACT_E_BADARG;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int rpb = 64; const int nblk = (T + rpb - 1) / rpb;
+    const bool params = dgamma && dbeta;
+    if (params && (!workspace || workspace_bytes < act_layernorm_bwd_workspace(T, D))) return ACT_E_BADARG;
+    ActProfScope ps(KID_LAYERNORM_BWD, s, 0.0, 4.0 * T * (double)D * (3 + (dres ? 1 : 0)));
+    float* pg = params ? workspace : nullptr;
+    float* pb = params ? workspace + (size_t)nblk * 4 * D : nullptr;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, s, dy, xin, gamma, mean, rstd, dres, dx, pg, pb, T, D, rpb);
+    ACT_LAUNCH_CHECK();
+    if (params) {
+        hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, s, pg, nblk * 4, D, dgamma, accumulate_params);
+        hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, s, pb, nblk * 4, D, dbeta, accumulate_params);
+        ACT_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" size_t act_colsum_workspace(int R, int C) {
+    int parts = (R + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
+    return (size_t)parts * C * sizeof(float);
+}
+
+extern "C" int act_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumulate, float* workspace,
+                              size_t workspace_bytes, act_stream_t stream) {
+    if (!in || !out || !workspace) return ACT_E_NULLPTR;
+    if (R < 0 || C <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    int parts = (R + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
+    if (workspace_bytes < (size_t)parts * C * sizeof(float)) return ACT_E_BADARG;
+    const int rpb = (R + parts - 1) / parts > 0 ? (R + parts - 1) / parts : 1;
+    ActProfScope ps(KID_COLSUM, s, 0.0, 4.0 * R * (double)C);
+    hipLaunchKernelGGL(colsum_stage1, dim3((C + 255) / 256, parts), dim3(256), 0, s, in, R, C, ld, rpb, workspace);
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, workspace, parts, C, out, accumulate);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int act_cosine_loss_fwd_f32(const float* student, const float* teacher, int R, int D, float eps, float* loss_out,
+                                       float* row_loss, float* stats, act_stream_t stream) {
+    if (!student || !teacher || !loss_out || !row_loss || !stats) return ACT_E_NULLPTR;
+    if (R <= 0 || D <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_COSINE_FWD, s, 0.0, 8.0 * R * (double)D);
+    hipLaunchKernelGGL(cosine_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, s, student, teacher, R, D, eps, row_loss, stats);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, row_loss, R, loss_out);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int act_cosine_loss_bwd_f32(const float* student, const float* teacher, const float* stats, const float* grad_loss,
+                                       int R, int D, float eps, float* grad_student, act_stream_t stream) {
+    if (!student || !teacher || !stats || !grad_loss || !grad_student) return ACT_E_NULLPTR;
+    if (R <= 0 || D <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_COSINE_BWD, s, 0.0, 12.0 * R * (double)D);
+    hipLaunchKernelGGL(cosine_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, s, student, teacher, stats, grad_loss, R, D, eps,
+                       1.0f / (float)R, grad_student);
+    ACT_LAUNCH_CHECK(); return 0;
+}

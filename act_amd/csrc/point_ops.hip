@@ -234,6 +234,45 @@ __global__ __launch_bounds__(256) void knn_group_kernel(const float* __restrict_
     }
 }
 
+
+// fallback for N > 8192: nothing is kept in registers; each of the K rounds rescans the lane's chunk for the
+// smallest (distance, index) pair lexicographically greater than the previous winner.
+__global__ __launch_bounds__(256) void knn_group_big_kernel(const float* __restrict__ ref, const float* __restrict__ query,
+                                                            int B, int N, int Q, int K, int64_t* __restrict__ idx_out,
+                                                            int idx_kq, float* __restrict__ nbr_out,
+                                                            float* __restrict__ dist_out) {
+    const int lane = threadIdx.x & 63;
+    const long long qid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qid >= (long long)B * Q) return;
+    const int b = (int)(qid / Q), q = (int)(qid % Q);
+    const float* __restrict__ r = ref + (size_t)b * N * 3;
+    const float qx = query[qid * 3 + 0], qy = query[qid * 3 + 1], qz = query[qid * 3 + 2];
+    const float INF = __int_as_float(0x7f800000);
+    const int per = (N + 63) / 64, k0 = lane * per, k1 = min(N, k0 + per);
+    float last_d = -1.0f; int last_i = -1;
+    for (int round = 0; round < K; ++round) {
+        float lmin = INF; int li = 0;
+        for (int k = k0; k < k1; ++k) {
+            const float v = sqdist3(r[k * 3 + 0], r[k * 3 + 1], r[k * 3 + 2], qx, qy, qz);
+            const bool after = (v > last_d) || (v == last_d && k > last_i);
+            if (after && v < lmin) { lmin = v; li = k; }
+        }
+        const float m = wave_min_f32(lmin, INF);
+        const int wl = first_lane(__ballot(lmin == m));
+        const int widx = __builtin_amdgcn_readlane(li, wl);
+        last_d = m; last_i = widx;
+        if (lane == 0) {
+            const size_t o = idx_kq ? ((size_t)b * K + round) * Q + q : (size_t)qid * K + round;
+            idx_out[o] = (int64_t)widx;
+            if (dist_out) dist_out[o] = __fsqrt_rn(m);
+            if (nbr_out) {
+                float* __restrict__ w = nbr_out + ((size_t)qid * K + round) * 3;
+                w[0] = __fsub_rn(r[widx * 3 + 0], qx); w[1] = __fsub_rn(r[widx * 3 + 1], qy); w[2] = __fsub_rn(r[widx * 3 + 2], qz);
+            }
+        }
+    }
+}
+
 template <int PPL>
 static int launch_knn(const float* ref, const float* query, int B, int N, int Q, int K, int64_t* idx, int idx_kq,
                       float* nbr, float* dist, hipStream_t s) {
@@ -248,7 +287,8 @@ static int launch_knn(const float* ref, const float* query, int B, int N, int Q,
 extern "C" int act_knn_group_f32(const float* ref, const float* query, int B, int N, int Q, int K, int64_t* idx_out,
                                  int idx_kq, float* nbr_out, float* dist_out, act_stream_t stream) {
     if (!ref || !query || !idx_out) return ACT_E_NULLPTR;
-    if (B < 0 || N <= 0 || Q < 0 || K <= 0 || K > 64 || K > N || N > 64 * 128) return ACT_E_BADARG;
+    if (B < 0 || N <= 0 || Q < 0 || K <= 0 || K > N) return ACT_E_BADARG;
+    if (K > 64 && N <= 64 * 128) return ACT_E_BADARG;      // register path keeps the K winners one per lane
     if (B == 0 || Q == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // algorithmic bytes per cloud: 12N + 12Q + 8QK (+12QK neighbourhood) (+4QK dist)   [SURVEY 8d]
@@ -257,7 +297,13 @@ extern "C" int act_knn_group_f32(const float* ref, const float* query, int B, in
 #define KNN_CASE(P) if (N <= 64 * P) return launch_knn<P>(ref, query, B, N, Q, K, idx_out, idx_kq, nbr_out, dist_out, s)
     KNN_CASE(1); KNN_CASE(2); KNN_CASE(4); KNN_CASE(8); KNN_CASE(16); KNN_CASE(32); KNN_CASE(64); KNN_CASE(128);
 #undef KNN_CASE
-    return ACT_E_BADARG;
+    {
+        const long long nq = (long long)B * Q;
+        hipLaunchKernelGGL(knn_group_big_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, ref, query, B, N, Q, K,
+                           idx_out, idx_kq, nbr_out, dist_out);
+        ACT_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 // ============================================ gather ==============================================

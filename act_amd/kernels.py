@@ -1,0 +1,314 @@
+"""Host-side plumbing over the C ABI: raw launch wrappers + the autograd Functions the model mirror uses.
+
+Nothing here computes on the host: every function allocates outputs with torch (device memory, caching
+allocator) and launches kernels of libact_hip.so on the current HIP stream.
+"""
+import ctypes
+
+import torch
+
+from . import _C
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK = 0, 1, 2, 3, 4
+
+
+class GemmEpilogue(ctypes.Structure):
+    _fields_ = [("alpha", _f), ("act", _i), ("accumulate", _i), ("rows_per_scale", _i), ("ldr", _i), ("ldaux", _i),
+                ("bias", _vp), ("rowscale", _vp), ("res", _vp), ("aux", _vp)]
+
+
+_C._declare({
+    "act_sgemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, ctypes.POINTER(GemmEpilogue), _vp, _sz, _vp],
+    "act_layernorm_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "act_layernorm_bwd_workspace": [_i, _i],
+    "act_layernorm_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _vp],
+    "act_colsum_workspace": [_i, _i],
+    "act_colsum_f32": [_vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp],
+    "act_attention_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "act_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
+    "act_cosine_loss_fwd_f32": [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "act_cosine_loss_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp],
+})
+_C.lib.act_layernorm_bwd_workspace.restype = _sz
+_C.lib.act_colsum_workspace.restype = _sz
+for _n in ("act_sgemm_f32", "act_layernorm_fwd_f32", "act_layernorm_bwd_workspace", "act_layernorm_bwd_f32",
+           "act_colsum_workspace", "act_colsum_f32", "act_attention_fwd_f32", "act_attention_bwd_f32",
+           "act_cosine_loss_fwd_f32", "act_cosine_loss_bwd_f32"):
+    _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
+
+lib, ptr, stream, check = _C.lib, _C.ptr, _C.stream, _C.check
+
+# ---- persistent scratch (split-K partials, LN / colsum partial rows): one buffer per device ----------
+_WS = {}
+_WS_BYTES = 64 << 20
+
+
+def workspace(device, nbytes=_WS_BYTES):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    w = _WS.get(key)
+    if w is None or w.numel() * 4 < nbytes:
+        w = torch.empty(max(nbytes, _WS_BYTES) // 4, dtype=torch.float32, device=device)
+        _WS[key] = w
+    return w
+
+
+def _f32c(t, name="tensor"):
+    if t.dtype != torch.float32:
+        raise _C.ActHipError(f"{name}: expected float32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---- raw wrappers ---------------------------------------------------------------------------------------
+def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, res=None, rowscale=None,
+         rows_per_scale=0, out=None, accumulate=False, alpha=1.0):
+    """C[M,N] = epilogue(op(a) @ op(b)); a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N]."""
+    a = _f32c(a, "a"); b = _f32c(b, "b")
+    if a_kmajor:
+        M, K = a.shape
+    else:
+        K, M = a.shape
+    if b_kmajor:
+        N, Kb = b.shape
+    else:
+        Kb, N = b.shape
+    if K != Kb:
+        raise _C.ActHipError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    e = GemmEpilogue(alpha=alpha, act=act, accumulate=int(accumulate), rows_per_scale=int(rows_per_scale),
+                     ldr=(res.stride(0) if res is not None else 0), ldaux=(aux.stride(0) if aux is not None else 0),
+                     bias=ptr(bias), rowscale=ptr(rowscale), res=ptr(res), aux=ptr(aux))
+    ws = workspace(a.device)
+    check(lib.act_sgemm_f32(int(a_kmajor), int(b_kmajor), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
+                            out.stride(0), ctypes.byref(e), ptr(ws), ws.numel() * 4, stream()), "act_sgemm_f32")
+    return out
+
+
+def layernorm_fwd(x, pos, gamma, beta, eps, want_xin=True, want_stats=True):
+    x = _f32c(x)
+    T, D = x.shape
+    pos = _f32c(pos) if pos is not None else None
+    y = torch.empty_like(x)
+    xin = torch.empty_like(x) if (pos is not None and want_xin) else None
+    mean = torch.empty(T, dtype=torch.float32, device=x.device) if want_stats else None
+    rstd = torch.empty(T, dtype=torch.float32, device=x.device) if want_stats else None
+    check(lib.act_layernorm_fwd_f32(ptr(x), ptr(pos), ptr(gamma), ptr(beta), ptr(xin), ptr(y), ptr(mean), ptr(rstd), T, D,
+                                    float(eps), stream()), "act_layernorm_fwd_f32")
+    return y, (xin if xin is not None else x), mean, rstd
+
+
+def layernorm_bwd(dy, xin, gamma, mean, rstd, dres=None, want_params=True):
+    dy = _f32c(dy)
+    T, D = dy.shape
+    dx = torch.empty_like(dy)
+    dg = torch.empty(D, dtype=torch.float32, device=dy.device) if want_params else None
+    db = torch.empty(D, dtype=torch.float32, device=dy.device) if want_params else None
+    ws = workspace(dy.device, lib.act_layernorm_bwd_workspace(T, D)) if want_params else None
+    check(lib.act_layernorm_bwd_f32(ptr(dy), ptr(xin), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db), 0,
+                                    ptr(ws), (ws.numel() * 4 if ws is not None else 0), T, D, stream()), "act_layernorm_bwd_f32")
+    return dx, dg, db
+
+
+def colsum(x):
+    x = _f32c(x)
+    R, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = workspace(x.device, lib.act_colsum_workspace(R, C))
+    check(lib.act_colsum_f32(ptr(x), R, C, x.stride(0), ptr(out), 0, ptr(ws), ws.numel() * 4, stream()), "act_colsum_f32")
+    return out
+
+
+def attention_fwd(qkv, B, S, H, hd, want_lse=True):
+    out = torch.empty(B * S, H * hd, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, H, S, dtype=torch.float32, device=qkv.device) if want_lse else None
+    check(lib.act_attention_fwd_f32(ptr(qkv), ptr(out), ptr(lse), B, S, H, hd, float(hd) ** -0.5, stream()), "act_attention_fwd_f32")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B, S, H, hd):
+    dqkv = torch.empty_like(qkv)
+    check(lib.act_attention_bwd_f32(ptr(qkv), ptr(out), ptr(_f32c(dout)), ptr(lse), ptr(dqkv), B, S, H, hd, float(hd) ** -0.5,
+                                    stream()), "act_attention_bwd_f32")
+    return dqkv
+
+
+# ---- autograd Functions -----------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x @ w^T + b on [T,in] rows (nn.Linear / Conv1d k=1)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        x2 = _f32c(x).reshape(-1, shp[-1])
+        y = gemm(x2, w, True, True, bias=b)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        ctx.shp = shp
+        return y.reshape(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = _f32c(dy).reshape(-1, w.shape[0])
+        dx = gemm(dy2, w, True, False).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
+        dw = gemm(dy2, x2, False, False) if ctx.needs_input_grad[1] else None
+        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    return LinearFn.apply(x, w, b)
+
+
+class MlpFn(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) with the GELU fused in fc1's epilogue and gelu' fused in fc2's input-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        shp = x.shape
+        x2 = _f32c(x).reshape(-1, shp[-1])
+        hpre = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.float32, device=x.device)
+        a = gemm(x2, w1, True, True, bias=b1, act=EPI_GELU, aux=hpre)
+        y = gemm(a, w2, True, True, bias=b2)
+        ctx.save_for_backward(x2, w1, w2, hpre, a)
+        ctx.shp = shp
+        return y.reshape(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, hpre, a = ctx.saved_tensors
+        dy2 = _f32c(dy).reshape(-1, w2.shape[0])
+        dh = gemm(dy2, w2, True, False, act=EPI_MUL_GELU_GRAD, aux=hpre)
+        dw2 = gemm(dy2, a, False, False) if ctx.needs_input_grad[3] else None
+        db2 = colsum(dy2) if ctx.needs_input_grad[4] else None
+        dx = gemm(dh, w1, True, False).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
+        dw1 = gemm(dh, x2, False, False) if ctx.needs_input_grad[1] else None
+        db1 = colsum(dh) if ctx.needs_input_grad[2] else None
+        return dx, dw1, db1, dw2, db2
+
+
+def mlp(x, w1, b1, w2, b2):
+    return MlpFn.apply(x, w1, b1, w2, b2)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        shp = x.shape
+        x2 = _f32c(x).reshape(-1, shp[-1])
+        y, _, mean, rstd = layernorm_fwd(x2, None, gamma, beta, eps)
+        ctx.save_for_backward(x2, gamma, mean, rstd)
+        ctx.shp = shp
+        return y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, mean, rstd = ctx.saved_tensors
+        dy2 = _f32c(dy).reshape(x2.shape)
+        want = ctx.needs_input_grad[1]
+        dx, dg, db = layernorm_bwd(dy2, x2, gamma, mean, rstd, None, want_params=want)
+        return dx.reshape(ctx.shp), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class BlockFn(torch.autograd.Function):
+    """One pre-LN Transformer block applied to (x + pos)  -- models/act.py:72-90 called as blk(x + pos) (:109-112).
+
+    forward : xin = x+pos ; x1 = xin + g1*(proj(attn(LN1(xin)))+b) ; x2 = x1 + g2*(fc2(gelu(fc1(LN2(x1))))+b)
+    g1/g2 are the per-sample DropPath gates (floor(keep+U)/keep) or None.  7 launches forward.
+    """
+
+    @staticmethod
+    def forward(ctx, x, pos, gate1, gate2, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, train_w):
+        B, S, D = x.shape
+        hd = D // heads
+        x2d = _f32c(x).reshape(B * S, D)
+        pos2d = _f32c(pos).reshape(B * S, D) if pos is not None else None
+        need_grad = any(ctx.needs_input_grad)
+        n1, xin, mean1, rstd1 = layernorm_fwd(x2d, pos2d, n1w, n1b, eps, want_stats=need_grad)
+        qkv = gemm(n1, wqkv, True, True, bias=bqkv)
+        att, lse = attention_fwd(qkv, B, S, heads, hd, want_lse=need_grad)
+        x1 = gemm(att, wproj, True, True, bias=bproj, rowscale=gate1, rows_per_scale=S, res=xin)
+        n2, _, mean2, rstd2 = layernorm_fwd(x1, None, n2w, n2b, eps, want_stats=need_grad)
+        hpre = torch.empty(B * S, w1.shape[0], dtype=torch.float32, device=x.device) if need_grad else None
+        a = gemm(n2, w1, True, True, bias=b1, act=EPI_GELU, aux=hpre)
+        x2 = gemm(a, w2, True, True, bias=b2, rowscale=gate2, rows_per_scale=S, res=x1)
+        if need_grad:
+            ctx.save_for_backward(xin, mean1, rstd1, n1, qkv, att, lse, x1, mean2, rstd2, n2, hpre, a, gate1, gate2,
+                                  n1w, wqkv, wproj, n2w, w1, w2)
+            ctx.dims = (B, S, D, heads, hd)
+            ctx.has_bqkv = bqkv is not None
+            ctx.has_pos = pos is not None
+            ctx.train_w = train_w
+        return x2.reshape(B, S, D)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (xin, mean1, rstd1, n1, qkv, att, lse, x1, mean2, rstd2, n2, hpre, a, gate1, gate2,
+         n1w, wqkv, wproj, n2w, w1, w2) = ctx.saved_tensors
+        B, S, D, heads, hd = ctx.dims
+        tw = ctx.train_w
+        dx2 = _f32c(dx2).reshape(B * S, D)
+        dy2 = dx2 if gate2 is None else scale_rows(dx2, gate2, S)
+        dh = gemm(dy2, w2, True, False, act=EPI_MUL_GELU_GRAD, aux=hpre)
+        dw2 = gemm(dy2, a, False, False) if tw else None
+        db2 = colsum(dy2) if tw else None
+        dn2 = gemm(dh, w1, True, False)
+        dw1 = gemm(dh, n2, False, False) if tw else None
+        db1 = colsum(dh) if tw else None
+        dx1, dg2, dbt2 = layernorm_bwd(dn2, x1, n2w, mean2, rstd2, dres=dx2, want_params=tw)
+        dy1 = dx1 if gate1 is None else scale_rows(dx1, gate1, S)
+        datt = gemm(dy1, wproj, True, False)
+        dwproj = gemm(dy1, att, False, False) if tw else None
+        dbproj = colsum(dy1) if tw else None
+        dqkv = attention_bwd(qkv, att, datt, lse, B, S, heads, hd)
+        dn1 = gemm(dqkv, wqkv, True, False)
+        dwqkv = gemm(dqkv, n1, False, False) if tw else None
+        dbqkv = colsum(dqkv) if (tw and ctx.has_bqkv) else None
+        dxin, dg1, dbt1 = layernorm_bwd(dn1, xin, n1w, mean1, rstd1, dres=dx1, want_params=tw)
+        dxin = dxin.reshape(B, S, D)
+        return (dxin, dxin if ctx.has_pos else None, None, None, dg1, dbt1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbt2,
+                dw1, db1, dw2, db2, None, None, None)
+
+
+def scale_rows(x, gate, rows_per_scale):
+    """x[r,:] * gate[r // rows_per_scale]  (DropPath gate on a gradient)."""
+    T, D = x.shape
+    return (x.view(-1, rows_per_scale, D) * gate.view(-1, 1, 1)).view(T, D)
+
+
+class CosineLossFn(torch.autograd.Function):
+    """mean over rows of 1 - cos(student, teacher)   (models/act.py:1243-1254 with loss='cosine')."""
+
+    @staticmethod
+    def forward(ctx, student, teacher):
+        D = student.shape[-1]
+        s2 = _f32c(student).reshape(-1, D)
+        t2 = _f32c(teacher).reshape(-1, D)
+        R = s2.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=s2.device)
+        row = torch.empty(R, dtype=torch.float32, device=s2.device)
+        stats = torch.empty(R, 3, dtype=torch.float32, device=s2.device)
+        check(lib.act_cosine_loss_fwd_f32(ptr(s2), ptr(t2), R, D, 1e-8, ptr(loss), ptr(row), ptr(stats), stream()),
+              "act_cosine_loss_fwd_f32")
+        ctx.save_for_backward(s2, t2, stats)
+        ctx.shp = student.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        s2, t2, stats = ctx.saved_tensors
+        R, D = s2.shape
+        ds = torch.empty_like(s2)
+        check(lib.act_cosine_loss_bwd_f32(ptr(s2), ptr(t2), ptr(stats), ptr(_f32c(g).reshape(-1)), R, D, 1e-8, ptr(ds), stream()),
+              "act_cosine_loss_bwd_f32")
+        return ds.reshape(ctx.shp), None
+
+
+def cosine_distill_loss(student, teacher):
+    return CosineLossFn.apply(student, teacher)

@@ -10,6 +10,7 @@
 #ifndef ACT_HIP_H
 #define ACT_HIP_H
 #include <stdint.h>
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -40,7 +41,7 @@ int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_out, float* 
 
 /* knn_cuda.KNN(k).forward fused with Group's gather + centre subtraction
  * (models/dvae.py:159,172-182; DGCNN graph k=4 models/dvae.py:23,68).
- * ref [B,N,3], query [B,Q,3], K <= 64 -> idx int64 ([B,Q,K], or [B,K,Q] when idx_kq != 0:
+ * ref [B,N,3], query [B,Q,3], K <= 64 (any K when N > 8192) -> idx int64 ([B,Q,K], or [B,K,Q] when idx_kq != 0:
  * transpose_mode=False layout), ascending (distance, index).
  * nbr_out  (nullable) [B,Q,K,3] = ref[idx] - query      dist_out (nullable) sqrt distance, idx layout. */
 int act_knn_group_f32(const float* ref, const float* query, int B, int N, int Q, int K,
@@ -64,6 +65,65 @@ int act_chamfer_fwd_f32(const float* xyz1, const float* xyz2, int B, int n, int 
 int act_chamfer_bwd_f32(const float* xyz1, const float* xyz2, const int32_t* idx1, const int32_t* idx2,
                         const float* grad_dist1, const float* grad_dist2, int B, int n, int m,
                         float* grad_xyz1, float* grad_xyz2, act_stream_t stream);
+
+
+/* ---- dense fp32 GEMM on the matrix cores with fused epilogue -------------------------------- */
+/* C[M,N] (+)= epilogue( alpha * opA(A)[M,K] . opB(B)[K,N] )
+ *   a_kmajor=1: A stored [M][K] (lda>=K)   a_kmajor=0: A stored [K][M] (lda>=M)
+ *   b_kmajor=1: B stored [N][K] (ldb>=K)   b_kmajor=0: B stored [K][N] (ldb>=N)
+ * nn.Linear / Conv1d(k=1) forward = (1,1) with B = weight [out,in] (models/act.py:25-69, models/dvae.py:185-215);
+ * input gradient = (1,0); weight gradient = (0,0) with K = number of rows (split-K through `workspace`).
+ * epilogue order: v = alpha*acc; v += bias[col]; activation; v *= rowscale[row / rows_per_scale]; v += res[row,col];
+ * if accumulate: v += C[row,col].   (rowscale = DropPath gate/keep per sample, res = residual stream.)
+ *   ACT_EPI_GELU          : if aux != NULL the pre-activation is stored to aux[row,col]; v = gelu_erf(v)
+ *   ACT_EPI_MUL_GELU_GRAD : v *= gelu'(aux[row,col])        ACT_EPI_MUL_RELU_MASK: v = aux[row,col] > 0 ? v : 0
+ * workspace (nullable): scratch for split-K partials, workspace_bytes long; never allocated here. */
+enum { ACT_EPI_NONE = 0, ACT_EPI_GELU = 1, ACT_EPI_RELU = 2, ACT_EPI_MUL_GELU_GRAD = 3, ACT_EPI_MUL_RELU_MASK = 4 };
+typedef struct {
+    float        alpha;            /* 1.0f */
+    int          act;              /* ACT_EPI_* */
+    int          accumulate;       /* C += result */
+    int          rows_per_scale;   /* rows sharing one rowscale entry (tokens per sample) */
+    int          ldr, ldaux;       /* leading dimensions of res / aux */
+    const float* bias;             /* [N] or NULL */
+    const float* rowscale;         /* [ceil(M / rows_per_scale)] or NULL */
+    const float* res;              /* [M, ldr] or NULL */
+    float*       aux;              /* [M, ldaux] or NULL */
+} act_gemm_epilogue_t;
+int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                  float* C, int ldc, const act_gemm_epilogue_t* epilogue, float* workspace, size_t workspace_bytes,
+                  act_stream_t stream);
+
+/* ---- row-wise fused kernels of a Transformer block ------------------------------------------- */
+/* xin = x + pos (pos nullable); y = LayerNorm(xin) * gamma + beta  (models/act.py:87-90 with the
+ * `x = blk(x + pos)` of :109-112,140-143 fused in).  xin_out / mean / rstd are nullable. D % 4 == 0, D <= 2048. */
+int act_layernorm_fwd_f32(const float* x, const float* pos, const float* gamma, const float* beta, float* xin_out,
+                          float* y, float* mean, float* rstd, int T, int D, float eps, act_stream_t stream);
+/* dx = dres (nullable, residual-stream gradient) + LayerNorm backward of dy; dgamma/dbeta (nullable) summed over
+ * rows in a fixed order through `workspace` (act_layernorm_bwd_workspace bytes). */
+size_t act_layernorm_bwd_workspace(int T, int D);
+int act_layernorm_bwd_f32(const float* dy, const float* xin, const float* gamma, const float* mean, const float* rstd,
+                          const float* dres, float* dx, float* dgamma, float* dbeta, int accumulate_params,
+                          float* workspace, size_t workspace_bytes, int T, int D, act_stream_t stream);
+/* out[c] (+)= sum_r in[r, c]  (bias gradients); deterministic two-stage. */
+size_t act_colsum_workspace(int R, int C);
+int act_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumulate, float* workspace,
+                   size_t workspace_bytes, act_stream_t stream);
+
+/* Fused multi-head self-attention (models/act.py:57-69): qkv [B,S,3,H,hd] packed as the qkv Linear writes it,
+ * out [B,S,H*hd] as the proj Linear reads it, lse [B,H,S] (nullable) = log-sum-exp of the scaled scores.
+ * forward: S <= 128, hd in {32,64}.  backward (recomputes P from lse): S4*(4*(hd+4)+S4+6)*4 bytes of LDS <= 160 KiB. */
+int act_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int S, int H, int head_dim, float scale,
+                          act_stream_t stream);
+int act_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                          int B, int S, int H, int head_dim, float scale, act_stream_t stream);
+
+/* Cosine distillation loss (models/act.py:1243-1254; lightly NegativeCosineSimilarity(dim=1, eps=1e-8)):
+ * loss = mean over rows of 1 - cos(student_r, teacher_r).  row_loss [R], stats [R,3] are scratch kept for backward. */
+int act_cosine_loss_fwd_f32(const float* student, const float* teacher, int R, int D, float eps, float* loss_out,
+                            float* row_loss, float* stats, act_stream_t stream);
+int act_cosine_loss_bwd_f32(const float* student, const float* teacher, const float* stats, const float* grad_loss,
+                            int R, int D, float eps, float* grad_student, act_stream_t stream);
 
 #ifdef __cplusplus
 }
