@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void knn_group_kernel(const float* __restrict_
     if (lane < K) {
         const size_t o = idx_kq ? ((size_t)b * K + lane) * Q + q : (size_t)qid * K + lane;
         idx_out[o] = (int64_t)my_idx;
-        if (dist_out) dist_out[o] = __fsqrt_rn(my_d);
+        if (dist_out) dist_out[o] = sqrtf(my_d);
         if (nbr_out) {
             float* __restrict__ w = nbr_out + ((size_t)qid * K + lane) * 3;
             w[0] = __fsub_rn(r[my_idx * 3 + 0], qx);
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void knn_group_big_kernel(const float* __restr
         if (lane == 0) {
             const size_t o = idx_kq ? ((size_t)b * K + round) * Q + q : (size_t)qid * K + round;
             idx_out[o] = (int64_t)widx;
-            if (dist_out) dist_out[o] = __fsqrt_rn(m);
+            if (dist_out) dist_out[o] = sqrtf(m);
             if (nbr_out) {
                 float* __restrict__ w = nbr_out + ((size_t)qid * K + round) * 3;
                 w[0] = __fsub_rn(r[widx * 3 + 0], qx); w[1] = __fsub_rn(r[widx * 3 + 1], qy); w[2] = __fsub_rn(r[widx * 3 + 2], qz);

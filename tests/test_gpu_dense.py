@@ -1,0 +1,235 @@
+"""GPU parity (through the C ABI): fp32 MFMA GEMM + fused epilogues, LayerNorm fwd/bwd, fused attention fwd/bwd,
+the fused Transformer block and the cosine loss -- against float64 CPU math, the CPU oracle and the goldens.
+Tolerance: 1e-4 (north_star) relative to max(1, |ref|max) unless stated."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden
+from tests.golden.fill import fill_module, fill_tensor
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def K():
+    assert torch.cuda.is_available()
+    import act_amd.kernels as K
+    return K
+
+
+def _rel(a, ref):
+    a = a.detach().double().cpu(); ref = ref.detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return ((a - ref).abs().max() / max(1.0, ref.abs().max())).item()
+
+
+def _rnd(name, *shape):
+    return fill_tensor(name, shape, "code")
+
+
+@pytest.mark.parametrize("M,N,K_", [(256, 384, 384), (1792, 1152, 384), (100, 70, 33), (1, 5, 3), (257, 130, 19), (4096, 768, 3072),
+                                    (8192, 128, 3), (64, 64, 16), (300, 512, 8)])
+def test_gemm_layouts(K, M, N, K_):
+    a = _rnd(f"ga{M}{K_}", M, K_); b = _rnd(f"gb{N}{K_}", N, K_)
+    ref = a.double() @ b.double().t()
+    scale = max(1.0, ref.abs().max().item())
+    ad, bd = a.cuda(), b.cuda()
+    for ak, bk in [(True, True), (True, False), (False, False), (False, True)]:
+        A = ad if ak else ad.t().contiguous()
+        Bm = bd if bk else bd.t().contiguous()
+        c = K.gemm(A, Bm, ak, bk)
+        err = (c.double().cpu() - ref).abs().max().item() / scale
+        assert err <= 2e-5 * max(1, K_ / 256) ** 0.5 + 1e-6, (ak, bk, err)
+
+
+def test_gemm_splitk_weight_gradient_shape(K):
+    T, O, I = 16384, 384, 256
+    dy = _rnd("sk.dy", T, O).cuda(); x = _rnd("sk.x", T, I).cuda()
+    dw = K.gemm(dy, x, False, False)                       # dW[O,I] = dy^T x, K = T -> split-K path
+    ref = dy.double().cpu().t() @ x.double().cpu()
+    assert _rel(dw, ref) <= 1e-5
+    dw2 = K.gemm(dy, x, False, False)
+    assert torch.equal(dw, dw2)                            # deterministic
+
+
+def test_gemm_epilogues(K):
+    M, N, Kd, S = 256, 192, 128, 32
+    a = _rnd("e.a", M, Kd).cuda(); w = (_rnd("e.w", N, Kd) * 0.1).cuda(); bias = _rnd("e.b", N).cuda()
+    res = _rnd("e.r", M, N).cuda(); gate = (torch.arange(M // S) % 2).float().cuda() / 0.9
+    base = (a.double() @ w.double().t()).cpu()
+    # bias + GELU (+ pre-activation saved)
+    aux = torch.empty(M, N, device="cuda")
+    y = K.gemm(a, w, bias=bias, act=K.EPI_GELU, aux=aux)
+    pre = base + bias.double().cpu()
+    assert _rel(aux, pre) <= 1e-5 and _rel(y, torch.nn.functional.gelu(pre)) <= 1e-5
+    # bias + per-sample scale + residual
+    y = K.gemm(a, w, bias=bias, rowscale=gate, rows_per_scale=S, res=res)
+    ref = res.double().cpu() + gate.double().cpu().repeat_interleave(S)[:, None] * pre
+    assert _rel(y, ref) <= 1e-5
+    # multiply by gelu'(aux)
+    h = _rnd("e.h", M, N).cuda()
+    y = K.gemm(a, w, act=K.EPI_MUL_GELU_GRAD, aux=h)
+    hd = h.double().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(hd).sum().backward()
+    assert _rel(y, base * hd.grad) <= 1e-5
+    # relu, relu mask, accumulate, alpha
+    assert _rel(K.gemm(a, w, act=K.EPI_RELU), base.clamp_min(0)) <= 1e-5
+    assert _rel(K.gemm(a, w, act=K.EPI_MUL_RELU_MASK, aux=h), base * (h.double().cpu() > 0)) <= 1e-5
+    c = res.clone()
+    K.gemm(a, w, out=c, accumulate=True, alpha=0.5)
+    assert _rel(c, res.double().cpu() + 0.5 * base) <= 1e-5
+
+
+@pytest.mark.parametrize("T,D,eps", [(1792, 384, 1e-5), (300, 768, 1e-6), (7, 64, 1e-5), (33, 128, 1e-5), (5, 2048, 1e-5)])
+def test_layernorm_fwd_bwd(K, T, D, eps):
+    x = _rnd(f"ln.x{T}", T, D); pos = _rnd(f"ln.p{T}", T, D) * 0.3
+    g = 1 + 0.1 * _rnd(f"ln.g{D}", D); b = 0.1 * _rnd(f"ln.b{D}", D)
+    dy = _rnd(f"ln.dy{T}", T, D); dres = _rnd(f"ln.dr{T}", T, D)
+    xd = (x + pos).double().requires_grad_(True); gd = g.double().requires_grad_(True); bd = b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xd, (D,), gd, bd, eps)
+    (yr * dy.double()).sum().backward()
+    y, xin, mean, rstd = K.layernorm_fwd(x.cuda(), pos.cuda(), g.cuda(), b.cuda(), eps)
+    assert _rel(y, yr) <= 2e-5 and _rel(xin, x + pos) <= 1e-6
+    dx, dg, db = K.layernorm_bwd(dy.cuda(), xin, g.cuda(), mean, rstd, dres=dres.cuda())
+    assert _rel(dx, xd.grad + dres.double()) <= 5e-5
+    assert _rel(dg, gd.grad) <= 5e-5 and _rel(db, bd.grad) <= 5e-5
+    # autograd wrapper without pos
+    xt = x.cuda().requires_grad_(True); gt = g.cuda().requires_grad_(True); bt = b.cuda().requires_grad_(True)
+    (K.layer_norm(xt, gt, bt, eps) * dy.cuda()).sum().backward()
+    x2 = x.double().requires_grad_(True)
+    (torch.nn.functional.layer_norm(x2, (D,), g.double(), b.double(), eps) * dy.double()).sum().backward()
+    assert _rel(xt.grad, x2.grad) <= 5e-5
+
+
+def _attn_ref(qkv, B, S, H, hd):
+    q, k, v = qkv.double().view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    a = torch.softmax((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1)
+    return (a @ v).transpose(1, 2).reshape(B * S, H * hd)
+
+
+@pytest.mark.parametrize("B,S,H,hd", [(3, 14, 6, 64), (2, 64, 6, 64), (2, 128, 12, 64), (5, 33, 2, 64), (2, 100, 3, 64), (9, 1, 2, 64),
+                                      (2, 16, 2, 32), (3, 128, 2, 32), (128, 14, 6, 64)])
+def test_attention_forward(K, B, S, H, hd):
+    qkv = _rnd(f"at{B}{S}{H}", B * S, 3 * H * hd)
+    out, lse = K.attention_fwd(qkv.cuda(), B, S, H, hd)
+    assert _rel(out, _attn_ref(qkv, B, S, H, hd)) <= 2e-5
+    q, k, _ = qkv.double().view(B, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    assert _rel(lse, torch.logsumexp((q @ k.transpose(-2, -1)) * hd ** -0.5, dim=-1)) <= 2e-5
+
+
+def test_attention_forward_large_logits(K):
+    """softmax must be max-subtracted: scores of a few hundred must not overflow."""
+    B, S, H, hd = 2, 64, 2, 64
+    qkv = _rnd("atbig", B * S, 3 * H * hd) * 6.0
+    out, _ = K.attention_fwd(qkv.cuda(), B, S, H, hd)
+    assert torch.isfinite(out).all() and _rel(out, _attn_ref(qkv, B, S, H, hd)) <= 5e-5
+
+
+@pytest.mark.parametrize("B,S,H,hd", [(3, 14, 6, 64), (2, 64, 6, 64), (4, 33, 2, 64), (2, 16, 2, 32), (2, 1, 1, 64)])
+def test_attention_backward(K, B, S, H, hd):
+    qkv = _rnd(f"ab{B}{S}{H}", B * S, 3 * H * hd); do = _rnd(f"abd{B}{S}{H}", B * S, H * hd)
+    qd = qkv.double().requires_grad_(True)
+    (_attn_ref(qd, B, S, H, hd) * do.double()).sum().backward()
+    qg = qkv.cuda()
+    out, lse = K.attention_fwd(qg, B, S, H, hd)
+    dqkv = K.attention_bwd(qg, out, do.cuda(), lse, B, S, H, hd)
+    assert _rel(dqkv, qd.grad) <= 5e-5
+
+
+def _load_block(blk_oracle):
+    sd = blk_oracle.state_dict()
+    g = lambda k: sd[k].cuda() if k in sd else None
+    return dict(n1w=g("norm1.weight"), n1b=g("norm1.bias"), wqkv=g("attn.qkv.weight"), bqkv=g("attn.qkv.bias"),
+                wproj=g("attn.proj.weight"), bproj=g("attn.proj.bias"), n2w=g("norm2.weight"), n2b=g("norm2.bias"),
+                w1=g("mlp.fc1.weight"), b1=g("mlp.fc1.bias"), w2=g("mlp.fc2.weight"), b2=g("mlp.fc2.bias"))
+
+
+def _run_block(K, p, x, pos, g1, g2, heads, eps):
+    names = ["n1w", "n1b", "wqkv", "bqkv", "wproj", "bproj", "n2w", "n2b", "w1", "b1", "w2", "b2"]
+    return K.BlockFn.apply(x, pos, g1, g2, *[p[n] for n in names], heads, eps, True)
+
+
+def test_block_against_golden_and_oracle(K):
+    from oracle import layers as L
+    g = golden("g3_block")
+    blk = fill_module(L.Block(384, 6), "g3.blk.")
+    p = _load_block(blk)
+    for v in p.values():
+        if v is not None:
+            v.requires_grad_(True)
+    x = fill_tensor("g3.x", (2, 14, 384), "code").cuda().requires_grad_(True)
+    y = _run_block(K, p, x, None, None, None, 6, 1e-5)
+    assert _rel(y, torch.from_numpy(g["y"])) <= TOL
+    (y * fill_tensor("g3.w", (2, 14, 384), "code").cuda()).sum().backward()
+    assert _rel(x.grad, torch.from_numpy(g["dx"])) <= TOL
+    name_map = {"norm1.weight": "n1w", "norm1.bias": "n1b", "attn.qkv.weight": "wqkv", "attn.proj.weight": "wproj",
+                "attn.proj.bias": "bproj", "norm2.weight": "n2w", "norm2.bias": "n2b", "mlp.fc1.weight": "w1",
+                "mlp.fc1.bias": "b1", "mlp.fc2.weight": "w2", "mlp.fc2.bias": "b2"}
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        got = p[name_map[str(n)]].grad.norm().item()
+        assert abs(got - v) <= TOL * max(1.0, v), (n, got, v)
+    # teacher-style block: qkv bias, eps 1e-6, S=128
+    blk_t = fill_module(L.Block(128, 2, qkv_bias=True, eps=1e-6), "g3.blkt.")
+    yt = _run_block(K, _load_block(blk_t), fill_tensor("g3.xt", (2, 128, 128), "code").cuda(), None, None, None, 2, 1e-6)
+    assert _rel(yt, torch.from_numpy(golden("g3_block_teacher")["y"])) <= TOL
+
+
+def test_block_with_pos_and_droppath_vs_oracle(K):
+    from oracle import layers as L
+    torch.manual_seed(0)
+    B, S, D, H = 6, 64, 128, 2
+    blk = fill_module(L.Block(D, H, drop_path=0.25, tag="t"), "blkdp.").train()
+    x = _rnd("bd.x", B, S, D); pos = _rnd("bd.p", B, S, D) * 0.2; w = _rnd("bd.w", B, S, D)
+    draws = L.Draws(record=True)
+    xo = x.clone().requires_grad_(True); po = pos.clone().requires_grad_(True)
+    yo = blk(xo + po, draws)
+    (yo * w).sum().backward()
+    keep = 0.75
+    g1 = (torch.floor(keep + draws.table["t.attn"]) / keep).cuda(); g2 = (torch.floor(keep + draws.table["t.mlp"]) / keep).cuda()
+    assert 0 < (g1 == 0).sum() + (g2 == 0).sum() < 2 * B            # both outcomes exercised
+    p = _load_block(blk)
+    for v in p.values():
+        if v is not None:
+            v.requires_grad_(True)
+    xg = x.cuda().requires_grad_(True); pg = pos.cuda().requires_grad_(True)
+    y = _run_block(K, p, xg, pg, g1, g2, H, 1e-5)
+    assert _rel(y, yo) <= TOL
+    (y * w.cuda()).sum().backward()
+    assert _rel(xg.grad, xo.grad) <= TOL and _rel(pg.grad, po.grad) <= TOL
+    od = dict(blk.named_parameters())
+    for on, pn in [("attn.qkv.weight", "wqkv"), ("mlp.fc1.weight", "w1"), ("mlp.fc2.bias", "b2"), ("norm1.weight", "n1w"),
+                   ("attn.proj.bias", "bproj"), ("norm2.bias", "n2b")]:
+        assert _rel(p[pn].grad, od[on].grad) <= TOL, on
+
+
+def test_mlp_linear_autograd(K):
+    x = _rnd("ml.x", 50, 3); w1 = _rnd("ml.w1", 128, 3); b1 = _rnd("ml.b1", 128) * 0.1
+    w2 = _rnd("ml.w2", 384, 128) * 0.1; b2 = _rnd("ml.b2", 384) * 0.1; dy = _rnd("ml.dy", 50, 384)
+    ts = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ref = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(ts[0], ts[1], ts[2])), ts[3], ts[4])
+    (ref * dy.double()).sum().backward()
+    tg = [t.cuda().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    y = K.mlp(*tg)
+    assert _rel(y, ref) <= 2e-5
+    (y * dy.cuda()).sum().backward()
+    for a, b in zip(tg, ts):
+        assert _rel(a.grad, b.grad) <= 5e-5
+    # plain linear on a 3-D input
+    x3 = _rnd("ml.x3", 4, 7, 128).cuda().requires_grad_(True); wl = w2.cuda().requires_grad_(True)
+    yl = K.linear(x3, wl, None)
+    assert _rel(yl, x3.detach().double().cpu() @ w2.double().t()) <= 2e-5
+    yl.sum().backward()
+    assert _rel(wl.grad, x3.detach().double().cpu().reshape(-1, 128).sum(0)[None, :].expand(384, -1)) <= 5e-5
+
+
+def test_cosine_loss(K):
+    s = fill_tensor("g6.s", (4, 51, 384), "code"); t = fill_tensor("g6.t", (4, 51, 384), "code")
+    sg = s.cuda().requires_grad_(True)
+    loss = K.cosine_distill_loss(sg, t.cuda())
+    assert abs(loss.item() - float(golden("g6_cosine")["loss"])) <= 1e-5
+    (loss * 3.0).backward()
+    sd = s.double().requires_grad_(True)
+    (3.0 * (1 - torch.nn.functional.cosine_similarity(sd, t.double(), dim=-1, eps=1e-8)).mean()).backward()
+    assert _rel(sg.grad, sd.grad) <= 1e-5
