@@ -311,4 +311,4 @@ class CosineLossFn(torch.autograd.Function):
 
 
 def cosine_distill_loss(student, teacher):
-    return CosineLossFn.apply(student, teacher)
+    return CosineLossFn.apply(student, teacher).reshape(())

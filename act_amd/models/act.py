@@ -1,0 +1,302 @@
+"""Stage-II masked point modeling with cross-modal teacher distillation (reference: models/act.py).
+
+Same public classes / state_dict keys as the reference for this path: ``Mlp``, ``Attention``, ``Block``,
+``TransformerEncoder``, ``TransformerDecoder``, ``VisableOnlyMaskTransformer``, ``ACT_PointDistillation``.
+Every block runs as ONE fused autograd Function over the HIP kernels (act_amd.kernels.BlockFn); masks, DropPath
+gates and token compaction are generated on the device with static shapes, so a training step has no
+device->host synchronisation (the reference has five boolean-index syncs + a 128-iteration loss loop).
+"""
+import torch
+import torch.nn as nn
+
+from .. import kernels as K
+from ..utils.draws import Draws
+from ..utils.logger import print_log
+from .build import MODELS
+from .dvae import Group, Encoder, ACTPromptedDiscreteVAEwithVIT, trunc_normal_
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if drop != 0.:
+            raise NotImplementedError("dropout inside Mlp is 0 on the ACT path (models/act.py:98)")
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward(self, x):
+        return K.mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        if attn_drop != 0. or proj_drop != 0. or qk_scale is not None:
+            raise NotImplementedError("attention dropout / custom scale are unused on the ACT path")
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Block(nn.Module):
+    """pre-LN block; ``forward(x, pos)`` computes blk(x + pos) of the reference (models/act.py:72-90,109-112)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.drop_prob = float(drop_path)
+        self.drop_path = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+
+    def gates(self, B, device, draws, tag):
+        """per-sample DropPath gates floor(keep + U) / keep for the two residual branches (or None)."""
+        if self.drop_prob == 0. or not self.training:
+            return None, None
+        keep = 1.0 - self.drop_prob
+        out = []
+        for branch in ("attn", "mlp"):
+            mk = lambda: torch.rand(B, dtype=torch.float32, device=device)
+            u = draws.get(f"{tag}.{branch}", mk) if draws is not None else mk()
+            out.append(torch.floor(keep + u.to(device)) / keep)
+        return out
+
+    def forward(self, x, pos=None, draws=None, tag="blk"):
+        g1, g2 = self.gates(x.shape[0], x.device, draws, tag)
+        a, m = self.attn, self.mlp
+        return K.BlockFn.apply(x, pos, g1, g2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                               a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
+                               m.fc2.bias, a.num_heads, self.norm1.eps, True)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, embed_dim=768, depth=4, num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate,
+                  drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
+            for i in range(depth)])
+
+    def forward(self, x, pos, draws=None, tag="enc"):
+        for i, block in enumerate(self.blocks):
+            x = block(x, pos, draws, f"{tag}.{i}")
+        return x
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, embed_dim=384, depth=4, num_heads=6, mlp_ratio=4., qkv_bias=False, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate,
+                  drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.head = nn.Identity()
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, x, pos, return_token_num, draws=None, tag="dec"):
+        for i, block in enumerate(self.blocks):
+            x = block(x, pos, draws, f"{tag}.{i}")
+        x = x[:, -return_token_num:].contiguous()          # only the mask tokens are predicted
+        return K.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+def random_mask(B, G, num_mask, device):
+    """exactly ``num_mask`` ones per row, sampled on the device (models/act.py:244-267 uses host numpy)."""
+    order = torch.rand(B, G, device=device).argsort(dim=1)
+    mask = torch.zeros(B, G, dtype=torch.bool, device=device)
+    mask.scatter_(1, order[:, :num_mask], True)
+    return mask
+
+
+def split_indices(mask, num_mask):
+    """stable compaction without a host sync: -> (visible idx [B,G-nm] ascending, masked idx [B,nm] ascending)."""
+    order = torch.argsort(mask.to(torch.int8), dim=1, stable=True)
+    G = mask.shape[1]
+    return order[:, :G - num_mask], order[:, G - num_mask:]
+
+
+def take_rows(x, idx):
+    """x [B,G,C], idx [B,n] -> [B,n,C]  (== x[bool_mask].reshape(B,-1,C) for a fixed count per row)."""
+    return torch.gather(x, 1, idx.unsqueeze(-1).expand(-1, -1, x.shape[-1]))
+
+
+class VisableOnlyMaskTransformer(nn.Module):
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.config = config
+        tc = config.transformer_config
+        self.mask_ratio = tc.mask_ratio
+        self.embed_dim = tc.embed_dim
+        self.cls_dim = tc.cls_dim
+        self.depth = tc.depth
+        self.drop_path_rate = tc.drop_path_rate
+        self.num_heads = tc.num_heads
+        print_log(f'[args] {tc}', logger='Transformer')
+        self.encoder_dims = config.dvae_config.encoder_dims
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.reduce_dim = nn.Linear(self.encoder_dims, self.embed_dim) if self.encoder_dims != self.embed_dim else nn.Identity()
+        self.mask_type = tc.mask_type
+        if self.mask_type != 'rand':
+            raise NotImplementedError("only mask_type 'rand' (cfgs/pretrain/pretrain_act_distill.yaml) is on this path")
+        self.cls_token = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(embed_dim=self.embed_dim, depth=self.depth, drop_path_rate=dpr, num_heads=self.num_heads)
+        self.norm = nn.LayerNorm(self.embed_dim)
+        self.num_tokens = config.dvae_config.num_tokens
+        self.lm_head = nn.Linear(self.embed_dim, self.num_tokens)
+        self.cls_head = nn.Sequential(nn.Linear(self.embed_dim, self.cls_dim), nn.GELU(), nn.Linear(self.cls_dim, self.cls_dim))
+        trunc_normal_(self.cls_token, std=.02)
+        trunc_normal_(self.cls_pos, std=.02)
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, (nn.Linear, nn.Conv1d)):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _mask_center_rand(self, center, noaug=False, draws=None):
+        B, G, _ = center.shape
+        if noaug or self.mask_ratio == 0:
+            return torch.zeros(B, G, dtype=torch.bool, device=center.device)
+        self.num_mask = int(self.mask_ratio * G)
+        mk = lambda: random_mask(B, G, self.num_mask, center.device)
+        return (draws.get("mask", mk) if draws is not None else mk()).to(center.device)
+
+    def forward(self, neighborhood, center, register_shallow_hook=-1, only_cls_tokens=False, noaug=False, draws=None):
+        bool_masked_pos = self._mask_center_rand(center, noaug=noaug, draws=draws)          # B G
+        B, G, _ = center.shape
+        num_mask = 0 if (noaug or self.mask_ratio == 0) else self.num_mask
+        tokens = self.encoder(neighborhood)                                                 # B G C
+        if not isinstance(self.reduce_dim, nn.Identity):
+            tokens = K.linear(tokens, self.reduce_dim.weight, self.reduce_dim.bias)
+        vis_idx, _ = split_indices(bool_masked_pos, num_mask)
+        x_vis = take_rows(tokens, vis_idx)
+        pe = self.pos_embed
+        pos = K.mlp(take_rows(center, vis_idx), pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias)
+        x_vis = torch.cat((self.cls_token.expand(B, -1, -1), x_vis), dim=1)
+        pos = torch.cat((self.cls_pos.expand(B, -1, -1), pos), dim=1)
+        x_vis = self.blocks(x_vis, pos, draws)
+        x_vis = K.layer_norm(x_vis, self.norm.weight, self.norm.bias, self.norm.eps)
+        if only_cls_tokens:
+            ch = self.cls_head
+            return K.mlp(x_vis[:, 0].contiguous(), ch[0].weight, ch[0].bias, ch[2].weight, ch[2].bias)
+        return x_vis[:, 1:], bool_masked_pos
+
+
+@MODELS.register_module()
+class ACT_PointDistillation(nn.Module):
+    """ACT Stage II: student encoder on visible patches + mask-token decoder regress the frozen teacher's
+    features with a cosine loss (models/act.py:1099-1258)."""
+
+    def __init__(self, config):
+        super().__init__()
+        print_log('[ACT] build Transformer for feature distillation pretraining', logger='ACT')
+        self.config = config
+        tc = config.transformer_config
+        self.mask_ratio = tc.mask_ratio
+        self.embed_dim = tc.embed_dim
+        self.ACT_encoder = VisableOnlyMaskTransformer(config)
+        self.group_size = config.dvae_config.group_size
+        self.num_group = config.dvae_config.num_group
+        self.proj_type = tc.proj
+        self.drop_path_rate = tc.drop_path_rate
+        self.decoder_depth = tc.decoder_depth
+        self.decoder_num_heads = tc.decoder_num_heads
+        self.cls_loss = tc.cls_loss
+        if self.cls_loss:
+            raise NotImplementedError("cls_loss=False in cfgs/pretrain/pretrain_act_distill.yaml; the shallow-hook branch is off this path")
+        self.build_tokenizer(config.dvae_config)
+        print_log(f'[ACT] divide point cloud into G{self.num_group} x S{self.group_size} points ...', logger='ACT')
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        if self.proj_type == 'linear':
+            self.proj_head = nn.Linear(self.embed_dim, config.dvae_config.tokens_dims)
+        elif self.proj_type == 'conv':
+            self.proj_head = nn.Sequential(nn.Conv1d(self.embed_dim, self.embed_dim, 1))
+        else:
+            self.proj_head = nn.Identity()
+        self.build_masked_decoder()
+        self.loss_type = config.loss
+        if self.loss_type != 'cosine':
+            raise NotImplementedError("only loss: cosine (the ACT recipe) is on this path")
+
+    def build_tokenizer(self, cfg):
+        self.dvae_tokenizer = ACTPromptedDiscreteVAEwithVIT(cfg)
+        dvae_ckpt = cfg.get("ckpt", None)
+        if dvae_ckpt and str(dvae_ckpt).lower() not in ("none", "random", ""):
+            ckpt = torch.load(dvae_ckpt, map_location='cpu')
+            base_ckpt = {k.replace("module.", ""): v for k, v in ckpt['base_model'].items()}
+            self.dvae_tokenizer.load_state_dict(base_ckpt, strict=True)
+            print_log(f'[dVAE] Successful Loading the ckpt for dvae from {dvae_ckpt}', logger='ACT')
+        else:
+            print_log('[dVAE] ckpt: none -> randomly initialised teacher (synthetic benchmark / tests)', logger='ACT')
+        for param in self.dvae_tokenizer.parameters():
+            param.requires_grad = False
+
+    def build_masked_decoder(self):
+        if self.mask_ratio > 0.:
+            print_log('[ACT] build masked decoder for feature prediction ...', logger='ACT')
+            self.mask_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
+            self.decoder_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
+            dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.decoder_depth)]
+            self.ACT_decoder = TransformerDecoder(embed_dim=self.embed_dim, depth=self.decoder_depth, drop_path_rate=dpr,
+                                                  num_heads=self.decoder_num_heads)
+            trunc_normal_(self.mask_token, std=.02)
+        else:
+            raise NotImplementedError("mask_ratio == 0 (no masked decoder) is off the ACT Stage-II path")
+
+    def forward_eval(self, pts):
+        with torch.no_grad():
+            neighborhood, center = self.group_divider(pts)
+            return self.ACT_encoder(neighborhood, center, only_cls_tokens=True, noaug=True)
+
+    def forward(self, pts, noaug=False, draws=None, **kwargs):
+        if noaug:
+            return self.forward_eval(pts)
+        neighborhood, center = self.group_divider(pts)
+        x_vis, mask = self.ACT_encoder(neighborhood, center, draws=draws)
+        B, _, C = x_vis.shape
+        with torch.no_grad():
+            teacher_feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
+        num_mask = self.ACT_encoder.num_mask
+        vis_idx, msk_idx = split_indices(mask, num_mask)
+        dp = self.decoder_pos_embed
+        # decoder_pos_embed of [visible (ascending), masked (ascending)] centres in one launch pair
+        pos_full = K.mlp(take_rows(center, torch.cat((vis_idx, msk_idx), dim=1)), dp[0].weight, dp[0].bias, dp[2].weight, dp[2].bias)
+        x_full = torch.cat([x_vis, self.mask_token.expand(B, num_mask, -1)], dim=1)
+        x_rec = self.ACT_decoder(x_full, pos_full, num_mask, draws=draws)
+        if self.proj_type == 'linear':
+            student_feat = K.linear(x_rec, self.proj_head.weight, self.proj_head.bias)
+        elif self.proj_type == 'conv':
+            c = self.proj_head[0]
+            student_feat = K.linear(x_rec, c.weight.view(c.weight.shape[0], -1), c.bias)
+        else:
+            student_feat = x_rec
+        teacher_feat = take_rows(teacher_feat, msk_idx)
+        assert teacher_feat.shape == student_feat.shape
+        return K.cosine_distill_loss(student_feat, teacher_feat)

@@ -1,0 +1,375 @@
+"""Point-patch tokenizer and the frozen cross-modal teacher (reference: models/dvae.py).
+
+Same class names, constructor arguments, forward signatures and ``state_dict`` keys as the reference
+(``Group``, ``Encoder``, ``DGCNN``, ``Decoder``, ``ACTPromptedDiscreteVAEwithVIT``); the arithmetic runs in
+the HIP kernels of libact_hip.so via act_amd.kernels / act_amd.knn_cuda / act_amd.pointnet2_ops.
+GPU only: a CPU tensor raises (there is no fallback path).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import kernels as K
+from ..knn_cuda import KNN, knn_group
+from ..pointnet2_ops import pointnet2_utils
+from ..extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+from ..utils.draws import Draws
+from .build import MODELS
+
+knn = KNN(k=4, transpose_mode=False)          # module-level DGCNN graph operator, as in models/dvae.py:23
+
+
+def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
+    return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)
+
+
+class Group(nn.Module):
+    """FPS centres -> kNN neighbourhoods -> centred patches (models/dvae.py:154-183), two launches."""
+
+    def __init__(self, num_group, group_size):
+        super().__init__()
+        self.num_group = num_group
+        self.group_size = group_size
+        self.knn = KNN(k=self.group_size, transpose_mode=True)
+
+    def forward(self, xyz):
+        """xyz [B,N,3] -> neighborhood [B,G,M,3] (centred), center [B,G,3]"""
+        xyz = xyz.contiguous()
+        with torch.no_grad():
+            _, center = pointnet2_utils.furthest_point_sample_with_centers(xyz, self.num_group)
+            _, neighborhood, _ = knn_group(xyz, center, self.group_size, want_nbr=True)
+        return neighborhood, center
+
+
+def _w2d(conv):
+    """[out, in, 1(,1)] conv weight viewed as the [out, in] matrix of the equivalent Linear."""
+    w = conv.weight
+    return w.view(w.shape[0], w.shape[1])
+
+
+class Encoder(nn.Module):
+    """mini-PointNet patch embedding (models/dvae.py:185-215) on rows [B*G*n, C].
+
+    second_conv[0] acts on cat(global.expand, local): W[:, :256] . global is identical for the n points of a
+    group, so it is computed once per group and broadcast (exact in real arithmetic, 25% fewer FLOPs)."""
+
+    def __init__(self, encoder_channel):
+        super().__init__()
+        self.encoder_channel = encoder_channel
+        self.first_conv = nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                        nn.Conv1d(128, 256, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                         nn.Conv1d(512, self.encoder_channel, 1))
+
+    @staticmethod
+    def _bn(x, bn, training):
+        if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training or not bn.track_running_stats,
+                            bn.momentum, bn.eps)
+
+    def forward(self, point_groups):
+        bs, g, n, _ = point_groups.shape
+        x = point_groups.reshape(bs * g * n, 3)
+        c1, bn1, _, c2 = self.first_conv
+        c3, bn2, _, c4 = self.second_conv
+        h = K.linear(x, _w2d(c1), c1.bias)
+        h = F.relu(self._bn(h, bn1, self.training))
+        h = K.linear(h, _w2d(c2), c2.bias)                               # [R,256]
+        fg = h.view(bs * g, n, 256).max(dim=1)[0]                        # [BG,256]
+        w3 = _w2d(c3)
+        gw = K.linear(fg, w3[:, :256], c3.bias)                          # per-group half of the 512->512 conv
+        h = K.linear(h, w3[:, 256:], None).view(bs * g, n, 512) + gw.unsqueeze(1)
+        h = F.relu(self._bn(h.view(bs * g * n, 512), bn2, self.training))
+        h = K.linear(h, _w2d(c4), c4.bias)
+        out = h.view(bs * g, n, self.encoder_channel).max(dim=1)[0]
+        return out.reshape(bs, g, self.encoder_channel)
+
+
+class DGCNN(nn.Module):
+    """4 x (kNN(k=4) graph feature -> 1x1 conv -> GroupNorm(4) -> LeakyReLU(0.2) -> max_k) + 1x1 conv head
+    (models/dvae.py:26-117).
+
+    conv(cat(x_j - x_i, x_i)) = Wa x_j + (Wb - Wa) x_i, so each edge-conv layer is ONE GEMM over the B*G points
+    (not over the B*G*k edges) followed by a gather: 4x fewer FLOPs than the reference formulation."""
+
+    def __init__(self, encoder_channel, output_channel):
+        super().__init__()
+        self.input_trans = nn.Conv1d(encoder_channel, 128, 1)
+
+        def layer(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.GroupNorm(4, cout),
+                                 nn.LeakyReLU(negative_slope=0.2))
+        self.layer1 = layer(256, 256)
+        self.layer2 = layer(512, 512)
+        self.layer3 = layer(1024, 512)
+        self.layer4 = layer(1024, 1024)
+        self.layer5 = nn.Sequential(nn.Conv1d(2304, output_channel, kernel_size=1, bias=False),
+                                    nn.GroupNorm(4, output_channel), nn.LeakyReLU(negative_slope=0.2))
+
+    @staticmethod
+    def graph_index(coor):
+        """coor [B,G,3] -> idx int64 [B,k=4,G] (KNN(k=4, transpose_mode=False) layout)."""
+        idx, _, _ = knn_group(coor.contiguous(), coor.contiguous(), 4, idx_kq=True)
+        return idx
+
+    @staticmethod
+    def _edge_layer(f, idx, layer, B, G):
+        conv, gn, _ = layer
+        w = _w2d(conv)
+        cin = w.shape[1] // 2
+        wa, wb = w[:, :cin], w[:, cin:]
+        yz = K.linear(f, torch.cat((wa, wb - wa), dim=0), None)          # [BG, 2*Cout]
+        cout = w.shape[0]
+        y = yz[:, :cout].reshape(B, G, cout)
+        z = yz[:, cout:].reshape(B, 1, G, cout)
+        nb = y[torch.arange(B, device=f.device).view(B, 1, 1), idx]      # [B,k,G,Cout]
+        pre = (nb + z).permute(0, 3, 2, 1)                               # [B,Cout,G,k]
+        act = F.leaky_relu(F.group_norm(pre, 4, gn.weight, gn.bias, gn.eps), 0.2)
+        return act.max(dim=-1)[0].transpose(1, 2).reshape(B * G, cout)   # rows [BG,Cout]
+
+    def forward(self, f, coor, idx=None):
+        """f [B,G,C], coor [B,G,3] -> [B,G,C']"""
+        B, G, C = f.shape
+        if idx is None:
+            with torch.no_grad():
+                idx = self.graph_index(coor)
+        x = K.linear(f.reshape(B * G, C), _w2d(self.input_trans), self.input_trans.bias)
+        feats = []
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            x = self._edge_layer(x, idx, layer, B, G)
+            feats.append(x)
+        conv, gn, _ = self.layer5
+        h = K.linear(torch.cat(feats, dim=1), _w2d(conv), None)          # [BG, C']
+        h = h.view(B, G, -1).transpose(1, 2)                             # [B,C',G]
+        h = F.leaky_relu(F.group_norm(h, 4, gn.weight, gn.bias, gn.eps), 0.2)
+        return h.transpose(1, 2)
+
+
+class Decoder(nn.Module):
+    """FoldingNet decoder (models/dvae.py:217-275)."""
+
+    def __init__(self, encoder_channel, num_fine):
+        super().__init__()
+        self.num_fine = num_fine
+        self.grid_size = 2
+        self.num_coarse = self.num_fine // 4
+        assert num_fine % 4 == 0
+        self.mlp = nn.Sequential(nn.Linear(encoder_channel, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 1024),
+                                 nn.ReLU(inplace=True), nn.Linear(1024, 3 * self.num_coarse))
+        self.final_conv = nn.Sequential(nn.Conv1d(encoder_channel + 3 + 2, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                        nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True), nn.Conv1d(512, 3, 1))
+        lin = torch.linspace(-0.05, 0.05, steps=self.grid_size, dtype=torch.float)
+        a = lin.view(1, self.grid_size).expand(self.grid_size, self.grid_size).reshape(1, -1)
+        b = lin.view(self.grid_size, 1).expand(self.grid_size, self.grid_size).reshape(1, -1)
+        self.folding_seed = torch.cat([a, b], dim=0).view(1, 2, self.grid_size ** 2)
+
+    def forward(self, feature_global):
+        """feature_global [B,G,C] -> coarse [B,G,M/4,3], fine [B,G,M,3]"""
+        bs, g, c = feature_global.shape
+        fgl = feature_global.reshape(bs * g, c)
+        m = self.mlp
+        h = F.relu(K.linear(fgl, m[0].weight, m[0].bias))
+        h = F.relu(K.linear(h, m[2].weight, m[2].bias))
+        coarse = K.linear(h, m[4].weight, m[4].bias).reshape(bs * g, self.num_coarse, 3)
+        S = self.grid_size ** 2
+        rep = coarse.unsqueeze(2).expand(-1, -1, S, -1).reshape(bs * g * self.num_fine, 3)      # rows (group, point)
+        seed = self.folding_seed.to(fgl.device).view(2, S).t()                                   # [S,2]
+        seed = seed.unsqueeze(0).expand(bs * g * self.num_coarse, -1, -1).reshape(bs * g * self.num_fine, 2)
+        c1, bn1, _, c2, bn2, _, c3 = self.final_conv
+        w1 = _w2d(c1)
+        # conv over cat(feature_global, seed, point): the feature_global part is constant per group
+        gw = K.linear(fgl, w1[:, :c], c1.bias)                                                  # [BG,512]
+        h = K.linear(torch.cat((seed, rep), dim=1), w1[:, c:], None).view(bs * g, self.num_fine, 512) + gw.unsqueeze(1)
+        h = F.relu(Encoder._bn(h.view(-1, 512), bn1, self.training))
+        h = F.relu(Encoder._bn(K.linear(h, _w2d(c2), c2.bias), bn2, self.training))
+        fine = K.linear(h, _w2d(c3), c3.bias) + rep
+        return coarse.reshape(bs, g, self.num_coarse, 3), fine.reshape(bs, g, self.num_fine, 3)
+
+
+class _FrozenBlock(nn.Module):
+    """parameter container with the timm ViT block key names (norm1, attn.qkv/proj, norm2, mlp.fc1/fc2)."""
+
+    def __init__(self, dim, heads, qkv_bias=True, eps=1e-6):
+        super().__init__()
+        self.num_heads, self.eps = heads, eps
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = nn.Module()
+        self.attn.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn.proj = nn.Linear(dim, dim)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = nn.Module()
+        self.mlp.fc1 = nn.Linear(dim, dim * 4)
+        self.mlp.fc2 = nn.Linear(dim * 4, dim)
+
+    def forward(self, x, pos=None, gate1=None, gate2=None, train_w=False):
+        a, m = self.attn, self.mlp
+        return K.BlockFn.apply(x, pos, gate1, gate2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias,
+                               a.proj.weight, a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias,
+                               m.fc2.weight, m.fc2.bias, self.num_heads, self.eps, train_w)
+
+
+_VIT_GEOMETRY = {            # timm names -> (depth, heads); width must equal config.visual_embed_dim
+    "vit_base_patch16_384": (12, 12), "vit_base_patch16_224": (12, 12), "vit_small_patch16_384": (12, 6),
+    "vit_small_patch16_224": (12, 6), "deit_base_distilled_patch16_384": (12, 12),
+}
+
+
+@MODELS.register_module()
+class ACTPromptedDiscreteVAEwithVIT(nn.Module):
+    """Stage-I autoencoder / Stage-II frozen teacher (models/dvae.py:360-615).
+
+    The pretrained image Transformer is represented by its ``blocks`` + ``norm`` (what the reference keeps,
+    :405-410) with timm's key names; weights come from the dVAE checkpoint (``ckpt``), never from the network.
+    Optional config keys (absent from the reference YAML): ``visual_embed_depth`` / ``visual_embed_heads``
+    override the geometry implied by ``visual_embed_type``."""
+
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.group_size = config.group_size
+        self.num_group = config.num_group
+        self.encoder_dims = config.encoder_dims
+        self.tokens_dims = config.tokens_dims
+        self.visual_embed_type = config.visual_embed_type
+        self.visual_embed_dim = config.visual_embed_dim
+        self.freeze_visual_embed = config.freeze_visual_embed
+        self.num_prompt_token = config.num_prompt_token
+        self.use_deep_prompt = config.use_deep_prompt
+        self.decoder_dims = config.decoder_dims
+        self.num_tokens = config.num_tokens
+        if not self.use_deep_prompt or self.num_prompt_token <= 0:
+            raise NotImplementedError("only the deep-prompt configuration of the ACT recipe is on this path")
+
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.dgcnn_1 = DGCNN(encoder_channel=self.encoder_dims, output_channel=self.num_tokens)
+        self.codebook = nn.Parameter(torch.randn(self.num_tokens, self.tokens_dims))
+        self.dgcnn_2 = DGCNN(encoder_channel=self.tokens_dims, output_channel=self.decoder_dims)
+        self.decoder = Decoder(encoder_channel=self.decoder_dims, num_fine=self.group_size)
+        self.build_loss_func()
+        self.build_visual_embedding(config)
+
+    def build_visual_embedding(self, config):
+        depth, heads = _VIT_GEOMETRY.get(self.visual_embed_type, (12, 12))
+        depth = int(config.get("visual_embed_depth", depth))
+        heads = int(config.get("visual_embed_heads", heads))
+        D = self.visual_embed_dim
+        blocks = nn.Sequential(*[_FrozenBlock(D, heads) for _ in range(depth)])
+        self.visual_embed = nn.Sequential(blocks, nn.LayerNorm(D, eps=1e-6))
+        self.visual_embed_depth = depth
+        self.proj_pre = nn.Linear(self.tokens_dims, D)
+        self.visual_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, D))
+        self.proj_post = nn.Linear(D, self.tokens_dims)
+        self.visual_prompt_proj = nn.Identity()
+        self.prompt_dropout = nn.Dropout(0.1)
+        Pn = self.num_prompt_token
+        self.visual_prompt_token = nn.Parameter(torch.zeros(1, Pn, D))
+        self.visual_prompt_pos = nn.Parameter(torch.randn(1, Pn, D))
+        trunc_normal_(self.visual_prompt_token, std=.02)
+        trunc_normal_(self.visual_prompt_pos, std=.02)
+        self.deep_prompt_tokens = nn.Parameter(torch.zeros(depth - 1, Pn, D))
+        self.deep_prompt_pos = nn.Parameter(torch.randn(depth - 1, Pn, D))
+        trunc_normal_(self.deep_prompt_tokens, std=.02)
+        trunc_normal_(self.deep_prompt_pos, std=.02)
+        if self.freeze_visual_embed:
+            for param in self.visual_embed.parameters():
+                param.requires_grad = False
+
+    def build_loss_func(self):
+        self.loss_func_cdl1 = ChamferDistanceL1()
+        self.loss_func_cdl2 = ChamferDistanceL2()
+
+    # ---- losses (Stage I) ------------------------------------------------------------------------
+    def recon_loss(self, ret, gt):
+        whole_coarse, whole_fine, coarse, fine, group_gt, _ = ret
+        bs, g, _, _ = coarse.shape
+        coarse = coarse.reshape(bs * g, -1, 3).contiguous()
+        fine = fine.reshape(bs * g, -1, 3).contiguous()
+        group_gt = group_gt.reshape(bs * g, -1, 3).contiguous()
+        return self.loss_func_cdl1(coarse, group_gt) + self.loss_func_cdl1(fine, group_gt)
+
+    def get_loss(self, ret, gt):
+        loss_recon = self.recon_loss(ret, gt)
+        logits = ret[-1]
+        mean_softmax = F.softmax(logits, dim=-1).mean(dim=1)
+        log_qy = torch.log(mean_softmax)
+        log_uniform = torch.log(torch.tensor([1. / self.num_tokens], device=gt.device))
+        loss_klv = F.kl_div(log_qy, log_uniform.expand(log_qy.size(0), log_qy.size(1)), None, None, 'batchmean', log_target=True)
+        return loss_recon, loss_klv
+
+    # ---- prompt-tuned frozen Transformer ---------------------------------------------------------
+    def _drop(self, t, draws, key):
+        p = self.prompt_dropout.p
+        if not self.training or p == 0:
+            return t
+        if draws is not None and draws.has(key):
+            return t * draws.get(key, None).to(t.dtype) / (1.0 - p)
+        if draws is not None and draws.record:
+            keep = draws.get(key, lambda: (torch.rand_like(t) >= p).to(t.dtype))
+            return t * keep / (1.0 - p)
+        return F.dropout(t, p, True)
+
+    def visual_embedding(self, input, center, draws=None):
+        return self.visual_embedding_deep_prompt(input, center, draws=draws)
+
+    def visual_embedding_deep_prompt(self, input, center, permute_feature=False, draws=None):
+        """models/dvae.py:536-576 (+ incorporate_prompt :485-498): prompts replaced (not appended) at layers 1..L-1."""
+        B, G, _ = input.shape
+        Pn = self.num_prompt_token
+        vp = self.visual_pos_embed
+        pos_tok = K.mlp(center, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias)                 # [B,G,D]
+        feature = K.linear(input, self.proj_pre.weight, self.proj_pre.bias)
+        train_w = not self.freeze_visual_embed
+        hidden = torch.cat((self._drop(self.visual_prompt_token.expand(B, -1, -1), draws, "prompt.0"), feature), dim=1)
+        pos = torch.cat((self.visual_prompt_pos.expand(B, -1, -1), pos_tok), dim=1)
+        blocks = self.visual_embed[0]
+        for i in range(self.visual_embed_depth):
+            if i > 0:
+                prm = self._drop(self.deep_prompt_tokens[i - 1].expand(B, -1, -1), draws, f"prompt.{i}")
+                hidden = torch.cat((prm, hidden[:, Pn:, :]), dim=1)
+                pos = torch.cat((self.deep_prompt_pos[i - 1].expand(B, -1, -1), pos_tok), dim=1)
+            hidden = blocks[i](hidden, pos, None, None, train_w)
+        nrm = self.visual_embed[1]
+        feature = K.layer_norm(hidden[:, Pn:].contiguous(), nrm.weight, nrm.bias, nrm.eps)
+        return K.linear(feature, self.proj_post.weight, self.proj_post.bias)
+
+    # ---- tokenizer ----------------------------------------------------------------------------------
+    def _gumbel_codes(self, logits, tau, hard, draws):
+        if draws is not None:
+            g = draws.get("gumbel", lambda: -torch.empty_like(logits).exponential_().log())
+        else:
+            g = -torch.empty_like(logits).exponential_().log()
+        y = (logits + g) / tau
+        if hard:
+            index = y.argmax(dim=-1)                       # one-hot x codebook == row gather (models/dvae.py:587-588)
+            return F.embedding(index, self.codebook)
+        return K.linear(y.softmax(dim=-1), self.codebook.t().contiguous(), None)
+
+    def forward_tokenizer(self, neighborhood, center):
+        gt_logits = self.dgcnn_1(self.encoder(neighborhood), center)
+        return gt_logits.argmax(-1).long()
+
+    def forward_tokenizer_features(self, neighborhood, center, return_global=True, draws=None):
+        with torch.no_grad():
+            idx = DGCNN.graph_index(center)                # the k=4 graph is identical for all 8 edge-conv layers
+        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
+        sampled = self._gumbel_codes(logits, 1.0, True, draws)
+        feature = self.visual_embedding(sampled, center, draws)
+        if return_global:
+            feature = self.dgcnn_2(feature, center, idx)
+        return feature
+
+    def forward(self, inp, temperature=1., hard=False, draws=None, **kwargs):
+        neighborhood, center = self.group_divider(inp)
+        with torch.no_grad():
+            idx = DGCNN.graph_index(center)
+        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
+        sampled = self._gumbel_codes(logits, temperature, hard, draws)
+        sampled = self.visual_embedding(sampled, center, draws)
+        feature = self.dgcnn_2(sampled, center, idx)
+        coarse, fine = self.decoder(feature)
+        with torch.no_grad():
+            whole_fine = (fine + center.unsqueeze(2)).reshape(inp.size(0), -1, 3)
+            whole_coarse = (coarse + center.unsqueeze(2)).reshape(inp.size(0), -1, 3)
+        assert fine.size(2) == self.group_size
+        return (whole_coarse, whole_fine, coarse, fine, neighborhood, logits)

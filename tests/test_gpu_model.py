@@ -1,0 +1,175 @@
+"""GPU parity of the model mirror (act_amd.models) against the goldens produced by the reference's own modules and
+against the CPU oracle with every random draw replayed (mask, DropPath, gumbel, prompt dropout)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden
+from tests.golden.fill import fill_module, fill_tensor, clouds, TINY_STAGE2, TINY_B, TINY_N
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _rel(a, ref):
+    a = torch.as_tensor(a).detach().double().cpu(); ref = torch.as_tensor(ref).detach().double().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return ((a - ref).abs().max() / max(1.0, ref.abs().max())).item()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _gumbel_noise(shape):
+    torch.manual_seed(777)
+    return -torch.empty(shape).exponential_().log()
+
+
+def _tiny(dev, prefix="g4."):
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    torch.manual_seed(0)
+    model = build_model_from_cfg(EasyDict(TINY_STAGE2))
+    fill_module(model, prefix)
+    return model.to(dev).train()
+
+
+def test_registry_contract():
+    from act_amd.models import build_model_from_cfg, MODELS
+    from act_amd.utils.config import EasyDict
+    assert "ACT_PointDistillation" in MODELS and "ACTPromptedDiscreteVAEwithVIT" in MODELS
+    with pytest.raises(KeyError):
+        build_model_from_cfg(EasyDict(NAME="NoSuchModel"))
+    with pytest.raises(KeyError):
+        build_model_from_cfg(EasyDict(foo=1))
+
+
+def test_encoder_and_transformer_encoder_golden(dev):
+    from act_amd.models.dvae import Encoder
+    from act_amd.models.act import TransformerEncoder
+    g = golden("g2_encoder")
+    nb = torch.from_numpy(golden("g1_group")["neighborhood"]).to(dev)
+    enc = fill_module(Encoder(128), "g2.enc.").to(dev)
+    tenc = fill_module(TransformerEncoder(embed_dim=128, depth=2, num_heads=2, drop_path_rate=0.0), "g2.tenc.").to(dev)
+    pos = fill_tensor("g2.pos", (4, 64, 128), "b").to(dev)
+    enc.train(); tok = enc(nb)
+    assert _rel(tok, g["tok_train"]) <= TOL
+    assert _rel(enc.first_conv[1].running_mean, g["bn1_running_mean"]) <= TOL
+    assert _rel(enc.first_conv[1].running_var, g["bn1_running_var"]) <= TOL
+    enc.eval(); assert _rel(enc(nb), g["tok_eval"]) <= TOL
+    assert _rel(tenc(tok, pos), g["out"]) <= TOL
+
+
+def test_stage2_tiny_golden_loss_grads_adamw(dev):
+    from act_amd.utils.draws import Draws
+    from act_amd.tools import builder
+    g = golden("g4_stage2")
+    model = _tiny(dev)
+    model.dvae_tokenizer.prompt_dropout.p = 0.0
+    pts = torch.from_numpy(clouds(4, TINY_B, TINY_N)).to(dev)
+    draws = Draws({"mask": torch.from_numpy(g["mask"]), "gumbel": _gumbel_noise((TINY_B, 16, 64))}, device=dev)
+    with torch.no_grad():
+        nb, c = model.group_divider(pts)
+        assert _rel(model.dvae_tokenizer.forward_tokenizer_features(nb, c, draws=draws), g["teacher_feat"]) <= TOL
+    loss = model(pts, draws=draws)
+    assert abs(loss.item() - g["loss"][0]) <= TOL
+    loss.backward()
+    pd = dict(model.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= TOL * max(1.0, v), n
+    assert _rel(pd["ACT_encoder.blocks.blocks.0.attn.qkv.weight"].grad, g["grad_qkv0"]) <= TOL
+    groups = builder.add_weight_decay(model, 0.05)
+    assert [len(groups[0]["params"]), len(groups[1]["params"])] == g["n_param_groups"].tolist()
+    opt = torch.optim.AdamW(groups, lr=1e-3, weight_decay=0.05)
+    opt.step(); model.zero_grad()
+    loss2 = model(pts, draws=draws); loss2.backward(); opt.step()
+    assert abs(loss2.item() - g["loss"][1]) <= TOL
+    for n, v in zip(g["grad_names"][:3], g["norms_after_2_steps"]):
+        assert abs(pd[str(n)].detach().norm().item() - v) <= TOL * max(1.0, v)
+
+
+def test_stage2_tiny_vs_oracle_all_draws_active(dev):
+    """drop_path 0.3 + prompt dropout 0.1 + mask + gumbel: record in the oracle, replay in the HIP path."""
+    import copy
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    cfg = copy.deepcopy(TINY_STAGE2)
+    cfg["transformer_config"]["drop_path_rate"] = 0.3
+    torch.manual_seed(1)
+    oracle = fill_module(OM.ACT_PointDistillation(OM.edict(cfg)), "dp.").train()
+    model = build_model_from_cfg(EasyDict(cfg))
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model.to(dev).train()
+    pts = torch.from_numpy(clouds(5, 4, TINY_N))
+    rec = OL.Draws(record=True)
+    lo = oracle(pts, rec); lo.backward()
+    assert any(k.startswith("enc.1") for k in rec.table) and any(k.startswith("prompt.") for k in rec.table)
+    lg = model(pts.to(dev), draws=Draws(rec.table, device=dev)); lg.backward()
+    assert abs(lg.item() - lo.item()) <= TOL
+    od = dict(oracle.named_parameters())
+    for n, p in model.named_parameters():
+        if p.requires_grad and od[n].grad is not None and p.grad is not None:
+            assert _rel(p.grad, od[n].grad) <= 2e-4, n
+
+
+def test_stage2_full_geometry_vs_oracle(dev):
+    """configs[1] geometry (N=1024, G=64, M=32, d=384 x 12, ViT-B teacher) at B=2 against the CPU oracle."""
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import cfg_from_yaml_file
+    from act_amd.utils.draws import Draws
+    cfg = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml").model
+    cfg.dvae_config.ckpt = "none"
+    torch.manual_seed(2)
+    oracle = OM.ACT_PointDistillation(OM.edict(cfg)).train()
+    model = build_model_from_cfg(cfg)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model.to(dev).train()
+    pts = torch.from_numpy(clouds(6, 2, 1024))
+    rec = OL.Draws(record=True)
+    lo = oracle(pts, rec); lo.backward()
+    lg = model(pts.to(dev), draws=Draws(rec.table, device=dev)); lg.backward()
+    assert abs(lg.item() - lo.item()) <= TOL, (lg.item(), lo.item())
+    od = dict(oracle.named_parameters())
+    for n in ["ACT_encoder.blocks.blocks.11.mlp.fc1.weight", "ACT_encoder.encoder.first_conv.0.weight", "mask_token",
+              "ACT_decoder.blocks.0.attn.qkv.weight", "proj_head.bias", "ACT_encoder.pos_embed.2.weight"]:
+        assert _rel(dict(model.named_parameters())[n].grad, od[n].grad) <= 2e-4, n
+
+
+def test_stage1_tiny_golden(dev):
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    g = golden("g7_stage1")
+    torch.manual_seed(0)
+    cfg = EasyDict(TINY_STAGE2["dvae_config"]); cfg.NAME = "ACTPromptedDiscreteVAEwithVIT"
+    vae = fill_module(build_model_from_cfg(cfg), "g7.").to(dev).train()
+    vae.prompt_dropout.p = 0.0
+    pts = torch.from_numpy(clouds(4, TINY_B, TINY_N)).to(dev)
+    ret = vae(pts, temperature=0.7, hard=False, draws=Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}, device=dev))
+    assert _rel(ret[2], g["coarse"]) <= TOL and _rel(ret[3], g["fine"]) <= TOL and _rel(ret[5], g["logits"]) <= 2e-4
+    assert _rel(ret[1], g["whole_fine"]) <= TOL
+    lr, lk = vae.get_loss(ret, pts)
+    assert abs(lr.item() - g["loss"][0]) <= TOL and abs(lk.item() - g["loss"][1]) <= TOL
+    (lr + 0.1 * lk).backward()
+    pd = dict(vae.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 2e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)
+
+
+def test_no_host_sync_in_training_step(dev):
+    """the Stage-II step must not synchronise with the host (reference: 5 boolean-index syncs + loss loop)."""
+    model = _tiny(dev)
+    pts = torch.from_numpy(clouds(4, TINY_B, TINY_N)).to(dev)
+    model(pts).backward()                      # warm-up (allocations, workspace)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        model(pts).backward()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")

@@ -133,7 +133,7 @@ def test_gather_operation_fwd_bwd(dev):
 def test_chamfer_fwd_bwd(dev, B, n, m):
     from act_amd.extensions.chamfer_dist import chamfer, ChamferFunction
     from oracle import point_ops as OP
-    x = clouds(20 + n, B, n); y = clouds(21 + m, B, m)
+    x = clouds(20 + n, B, max(n, 2))[:, :n].copy(); y = clouds(21 + m, B, m)
     if n > 4:
         y[:, 1] = y[:, 0]                                    # duplicate target -> tie -> lowest index must win
     xt = torch.from_numpy(x).to(dev); yt = torch.from_numpy(y).to(dev)
