@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- Stage-II ACT pretraining step throughput on MI355X (BASELINE.json metric, configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = augmentation + forward + backward + AdamW update of ACT_PointDistillation on a synthetic batch of
+B=128 clouds x 1024 points per GPU (64 groups x 32 neighbours, 12-layer d=384 student, frozen ViT-B teacher),
+fp32, random weights, inputs resident in HBM.  Rank 0 prints ONE JSON line: whole-job clouds/s, plus
+  roofline      live hipEvent timing of the dominant HIP kernel (instrumented pass after the timed region)
+  cpu_baseline  the CPU oracle (pure-PyTorch restatement of the reference path) timed on the host cores (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0               # HBM3E spec (6290 GB/s measured-achievable)
+
+
+def synthetic_clouds(B, N, seed, device):
+    """pc_norm'd gaussian clouds (datasets/ShapeNet55Dataset.py:45-51 semantics), generated on the host once."""
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.randn(B, N, 3, generator=g)
+    pts = pts - pts.mean(dim=1, keepdim=True)
+    pts = pts / pts.norm(dim=2).max(dim=1)[0].view(B, 1, 1)
+    return pts.to(device)
+
+
+def cpu_baseline(cfg_model, seconds_budget=25.0, B=8):
+    """Stage-II step (fwd+bwd+AdamW) of the CPU oracle on the host cores; bounded sample."""
+    from oracle import models as OM
+    torch.manual_seed(0)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    model = OM.ACT_PointDistillation(OM.edict(cfg_model)).train()
+    opt = torch.optim.AdamW(OM.param_groups(model, 0.05), lr=1e-3, weight_decay=0.05)
+    pts = synthetic_clouds(B, 1024, 99, "cpu")
+
+    def step():
+        loss = model(pts)
+        loss.backward()
+        opt.step(); opt.zero_grad()
+    step()                                             # warm-up
+    t0 = time.time(); n = 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
+        step(); n += 1
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "clouds/s", "cores": threads, "kind": "port",
+            "sample": f"{n} Stage-II steps (fwd+bwd+AdamW) of the pure-PyTorch CPU oracle at B={B}, N=1024, same geometry"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="clouds per GPU (configs[1]: 128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-instrument", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP kernels are the product path; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")        # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import act_amd._C as C
+    from act_amd.models import build_model_from_cfg
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import freeze_unused_heads, train_step, wrap_ddp, _Single
+    from act_amd.utils.config import cfg_from_yaml_file
+    from act_amd.utils.logger import get_logger
+    import logging
+    for n in ("ACT", "Transformer"):
+        get_logger(n).setLevel(logging.ERROR)
+
+    config = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml")
+    config.model.dvae_config.ckpt = "none"
+    torch.manual_seed(0)                                # identical initial weights on every rank
+    model = build_model_from_cfg(config.model)
+    freeze_unused_heads(model)
+    model.to(device).train()
+    ns = argparse.Namespace(local_rank=local_rank, use_gpu=True)
+    wrapped = wrap_ddp(model, ns) if world > 1 else _Single(model)
+    optimizer, _ = builder.build_opti_sche(wrapped, config)
+    torch.manual_seed(1234 + rank)                      # per-rank draws (main.py:67 seed + local_rank)
+
+    B, N = args.batch, 1024
+    pool = [synthetic_clouds(B, N, 1234 + rank * 100 + i, device) for i in range(4)]
+
+    def step(i):
+        return train_step(wrapped, optimizer, pool[i % len(pool)].clone(), config)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    loss_val = float(loss.item())
+
+    out = {
+        "metric": "stage2_pretrain_point_clouds_per_sec", "value": B * world * args.steps / elapsed, "unit": "clouds/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: ACT Stage-II pretrain step (pretrain_act_distill.yaml geometry): "
+                               "B=128 clouds/GPU x 1024 pts, 64 groups x 32 nbrs, 12L d=384 student + 2L decoder, "
+                               "frozen 12L ViT-B teacher (random init), aug+fwd+bwd+AdamW",
+                   "clouds_per_gpu": B, "points_per_cloud": N, "parallelism": f"dp{world}", "final_loss": loss_val},
+    }
+
+    if rank == 0 and not args.no_instrument:
+        # ---- instrumented pass: hipEvents around every launch of libact_hip.so on the launch stream --------------
+        C.prof_reset(); C.prof_enable(True)
+        nprof = 3
+        for i in range(nprof):
+            step(i)
+        torch.cuda.synchronize()
+        C.prof_enable(False)
+        table = C.prof_table()
+        tot_ms = sum(v["ms"] for v in table.values())
+        kernels = {}
+        for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+            avg_ms = v["ms"] / v["launches"]
+            e = {"ms_per_step": v["ms"] / nprof, "launches_per_step": v["launches"] / nprof, "avg_us": 1e3 * avg_ms}
+            if v["flops"] > 0:
+                e["tflops"] = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            if v["bytes"] > 0:
+                e["alg_GBs"] = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            kernels[k] = e
+        dom = next(iter(kernels))
+        dv = table[dom]
+        if dv["flops"] > 0:
+            ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "avg_launch_us": 1e3 * dv["ms"] / dv["launches"], "launches_per_step": dv["launches"] / nprof}
+        else:
+            ach = dv["bytes"] / (dv["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                               "avg_launch_us": 1e3 * dv["ms"] / dv["launches"], "launches_per_step": dv["launches"] / nprof}
+        out["kernels"] = kernels
+        out["hip_kernel_ms_per_step"] = tot_ms / nprof
+        # ---- FPS + kNN "Group" throughput (BASELINE metric part 2), hipEvents on the current stream ------------------
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        grp = model.group_divider
+        for _ in range(3):
+            grp(pool[0])
+        reps = 20
+        ev0.record()
+        for _ in range(reps):
+            grp(pool[0])
+        ev1.record(); torch.cuda.synchronize()
+        gms = ev0.elapsed_time(ev1) / reps
+        fps_b, knn_b = 13312.0 * B, 54016.0 * B                    # algorithmic bytes / cloud
+        out["group_fps_knn"] = {"Mpts_per_s": B * N / (gms * 1e-3) / 1e6, "ms": gms,
+                                "alg_GBs": (fps_b + knn_b) / (gms * 1e-3) / 1e9, "frac_hbm": (fps_b + knn_b) / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(config.model)
+        except Exception as e:                           # the baseline is a report, never a reason to lose the bench line
+            out["cpu_baseline"] = {"value": None, "unit": "clouds/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
