@@ -70,7 +70,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dx, float* __restrict__ part_dg,
                                                             float* __restrict__ part_db, int T, int D, int rows_per_block) {
-    __shared__ float sred[4][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
     const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gamma);
@@ -114,32 +113,56 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
-    // combine the 4 waves' partials through LDS-free global partial rows: [gridDim.x*4][D]
+    // combine the 4 waves' partials in LDS (fixed order) -> one partial row per workgroup: [gridDim.x][D]
     if (part_dg) {
-        float4* __restrict__ pg = reinterpret_cast<float4*>(part_dg + ((size_t)blockIdx.x * 4 + wave) * D);
-        float4* __restrict__ pb = reinterpret_cast<float4*>(part_db + ((size_t)blockIdx.x * 4 + wave) * D);
+        extern __shared__ __attribute__((aligned(16))) float sacc[];      // [2][4][D]
+        float4* sg = reinterpret_cast<float4*>(sacc) + (size_t)wave * nv;
+        float4* sb = reinterpret_cast<float4*>(sacc) + (size_t)(4 + wave) * nv;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) { const int c = lane + 64 * i; if (c < nv) { pg[c] = ag[i]; pb[c] = ab[i]; } }
+        for (int i = 0; i < LN_MAXV; ++i) { const int c = lane + 64 * i; if (c < nv) { sg[c] = ag[i]; sb[c] = ab[i]; } }
+        __syncthreads();
+        const float* fg = sacc; const float* fb = sacc + (size_t)4 * D;
+        for (int c = threadIdx.x; c < D; c += 256) {
+            part_dg[(size_t)blockIdx.x * D + c] = (fg[c] + fg[D + c]) + (fg[2 * D + c] + fg[3 * D + c]);
+            part_db[(size_t)blockIdx.x * D + c] = (fb[c] + fb[D + c]) + (fb[2 * D + c] + fb[3 * D + c]);
+        }
     }
-    (void)sred;
 }
 
 // out[c] (+)= sum_r in[r][c]   -- two-stage, fixed order (deterministic).  stage 1: partial[blk][c]
+// block = 64 columns x 4 row-lanes; every thread keeps 8 independent loads in flight.
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ in, int R, int C, int ld, int rows_per_block,
                                                      float* __restrict__ partial) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += in[(size_t)r * ld + c];
-    partial[(size_t)blockIdx.y * C + c] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    if (c < C) {
+        const float* __restrict__ p = in + c;
+        int r = r0 + ry;
+        for (; r + 28 < r1; r += 32) {
+            a0 += p[(size_t)r * ld];        a1 += p[(size_t)(r + 4) * ld];  a2 += p[(size_t)(r + 8) * ld];  a3 += p[(size_t)(r + 12) * ld];
+            a4 += p[(size_t)(r + 16) * ld]; a5 += p[(size_t)(r + 20) * ld]; a6 += p[(size_t)(r + 24) * ld]; a7 += p[(size_t)(r + 28) * ld];
+        }
+        for (; r < r1; r += 4) a0 += p[(size_t)r * ld];
+    }
+    sh[ry][cx] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    __syncthreads();
+    if (ry == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out,
                                                      int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float acc = 0.f;
-    for (int p = 0; p < nparts; ++p) acc += partial[(size_t)p * C + c];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int p = 0;
+    for (; p + 3 < nparts; p += 4) {
+        a0 += partial[(size_t)p * C + c]; a1 += partial[(size_t)(p + 1) * C + c];
+        a2 += partial[(size_t)(p + 2) * C + c]; a3 += partial[(size_t)(p + 3) * C + c];
+    }
+    for (; p < nparts; ++p) a0 += partial[(size_t)p * C + c];
+    const float acc = (a0 + a1) + (a2 + a3);
     out[c] = accumulate ? out[c] + acc : acc;
 }
 
@@ -203,9 +226,10 @@ extern "C" int act_layernorm_fwd_f32(const float* x, const float* pos, const flo
     ACT_LAUNCH_CHECK(); return 0;
 }
 
+static int ln_rows_per_block(int T) { int r = (T + 1023) / 1024; r = (r + 3) / 4 * 4; return r < 16 ? 16 : r; }
 extern "C" size_t act_layernorm_bwd_workspace(int T, int D) {
-    const int rpb = 64; const int nblk = (T + rpb - 1) / rpb;
-    return (size_t)nblk * 4 * D * 2 * sizeof(float);
+    const int rpb = ln_rows_per_block(T); const int nblk = (T + rpb - 1) / rpb;
+    return (size_t)nblk * D * 2 * sizeof(float);
 }
 
 extern "C" int act_layernorm_bwd_f32(const float* dy, const float* xin, const float* gamma, const float* mean, const float* rstd,
@@ -215,38 +239,43 @@ extern "C" int act_layernorm_bwd_f32(const float* dy, const float* xin, const fl
     if (T < 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV) return ACT_E_BADARG;
     if (T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const int rpb = 64; const int nblk = (T + rpb - 1) / rpb;
+    const int rpb = ln_rows_per_block(T); const int nblk = (T + rpb - 1) / rpb;
     const bool params = dgamma && dbeta;
     if (params && (!workspace || workspace_bytes < act_layernorm_bwd_workspace(T, D))) return ACT_E_BADARG;
     ActProfScope ps(KID_LAYERNORM_BWD, s, 0.0, 4.0 * T * (double)D * (3 + (dres ? 1 : 0)));
     float* pg = params ? workspace : nullptr;
-    float* pb = params ? workspace + (size_t)nblk * 4 * D : nullptr;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, s, dy, xin, gamma, mean, rstd, dres, dx, pg, pb, T, D, rpb);
+    float* pb = params ? workspace + (size_t)nblk * D : nullptr;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), params ? (size_t)8 * D * sizeof(float) : 0, s, dy, xin, gamma, mean, rstd, dres, dx, pg, pb, T, D, rpb);
     ACT_LAUNCH_CHECK();
     if (params) {
-        hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, s, pg, nblk * 4, D, dgamma, accumulate_params);
-        hipLaunchKernelGGL(colsum_stage2, dim3((D + 255) / 256), dim3(256), 0, s, pb, nblk * 4, D, dbeta, accumulate_params);
+        hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(64), 0, s, pg, nblk, D, dgamma, accumulate_params);
+        hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(64), 0, s, pb, nblk, D, dbeta, accumulate_params);
         ACT_LAUNCH_CHECK();
     }
     return 0;
 }
 
-extern "C" size_t act_colsum_workspace(int R, int C) {
-    int parts = (R + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
-    return (size_t)parts * C * sizeof(float);
+static int colsum_parts(int R, int C) {
+    const int cb = (C + 63) / 64;
+    int parts = (2048 + cb - 1) / cb;                       // ~2048 workgroups in total
+    const int maxp = (R + 31) / 32; if (parts > maxp) parts = maxp;
+    if (parts > 1024) parts = 1024; if (parts < 1) parts = 1;
+    return parts;
 }
+extern "C" size_t act_colsum_workspace(int R, int C) { return (size_t)colsum_parts(R, C) * C * sizeof(float); }
 
 extern "C" int act_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumulate, float* workspace,
                               size_t workspace_bytes, act_stream_t stream) {
     if (!in || !out || !workspace) return ACT_E_NULLPTR;
     if (R < 0 || C <= 0) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    int parts = (R + 255) / 256; if (parts > 256) parts = 256; if (parts < 1) parts = 1;
+    const int parts = colsum_parts(R, C);
     if (workspace_bytes < (size_t)parts * C * sizeof(float)) return ACT_E_BADARG;
-    const int rpb = (R + parts - 1) / parts > 0 ? (R + parts - 1) / parts : 1;
+    int rpb = (R + parts - 1) / parts; rpb = (rpb + 3) / 4 * 4; if (rpb < 4) rpb = 4;
+    const int nparts = (R + rpb - 1) / rpb > 0 ? (R + rpb - 1) / rpb : 1;
     ActProfScope ps(KID_COLSUM, s, 0.0, 4.0 * R * (double)C);
-    hipLaunchKernelGGL(colsum_stage1, dim3((C + 255) / 256, parts), dim3(256), 0, s, in, R, C, ld, rpb, workspace);
-    hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, workspace, parts, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nparts), dim3(256), 0, s, in, R, C, ld, rpb, workspace);
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(64), 0, s, workspace, nparts, C, out, accumulate);
     ACT_LAUNCH_CHECK(); return 0;
 }
 

@@ -41,7 +41,7 @@ def cpu_baseline(cfg_model, seconds_budget=25.0, B=8):
     """Stage-II step (fwd+bwd+AdamW) of the CPU oracle on the host cores; bounded sample."""
     from oracle import models as OM
     torch.manual_seed(0)
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, int(os.environ.get("ACT_CPU_BASELINE_THREADS", "32")))
     torch.set_num_threads(threads)
     model = OM.ACT_PointDistillation(OM.edict(cfg_model)).train()
     opt = torch.optim.AdamW(OM.param_groups(model, 0.05), lr=1e-3, weight_decay=0.05)
