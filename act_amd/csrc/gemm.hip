@@ -15,10 +15,14 @@
 // works on a compact band of tiles.  The epilogue fuses bias, GELU / ReLU (+ saving the pre-activation),
 // activation-gradient multiply, per-row scale (DropPath gate) and residual add.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define GEMM_BK 16
+#define GEMM_BK_DEFAULT 16
+#ifndef GEMM_MIN_WAVES
+#define GEMM_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (4 workgroups / CU)
+#endif
 
 struct GemmParams {
     const float* A; const float* B; float* C;
@@ -49,12 +53,17 @@ __device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, fl
     return v;
 }
 
-template <int BM, int BN, bool A_K, bool B_K, bool VEC>
-__global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
-    constexpr int BK = GEMM_BK;
-    constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
+// VEC : float4 global loads are legal (alignment, leading dimensions)      FULL: M%BM == N%BN == 0 and every K-range is a
+// multiple of BK, so the loaders carry no bounds checks at all.
+template <int BM, int BN, int BK, bool A_K, bool B_K, bool VEC, bool FULL>
+__global__ __launch_bounds__(256, GEMM_MIN_WAVES) void sgemm_kernel(const GemmParams p) {
+    // LDS row stride: K-major operands are transposed on the store (4 x ds_write_b32 per float4): stride = rows + 2 makes
+    // the 32 lanes of a half-wave hit 32 distinct banks ((8*kq + 2*c + row) mod 32); row-major operands are stored with
+    // ds_write_b128 and need a 16-byte aligned stride (rows + 4).  Operand reads are conflict-free for any stride.
+    constexpr int LDA_S = A_K ? BM + 2 : BM + 4, LDB_S = B_K ? BN + 2 : BN + 4;
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 accumulators per wave
-    constexpr int NA = BM / 64, NB = BN / 64;          // float4 loads per thread per operand per K-tile
+    constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 loads per thread per operand per K-tile
+    constexpr int KQ = BK / 4;                         // float4 per row of a K-major tile
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
 
@@ -90,15 +99,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
             const int v = tid + 256 * i;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (A_K) {                                   // A stored [M][K]
-                const int row = m0 + (v >> 2), kk = k0 + (v & 3) * 4;
-                if (row < p.M) {
+                const int row = m0 + v / KQ, kk = k0 + (v % KQ) * 4;
+                if (FULL) { x = *reinterpret_cast<const float4*>(p.A + (size_t)row * p.lda + kk); }
+                else if (row < p.M) {
                     const float* src = p.A + (size_t)row * p.lda + kk;
                     if (VEC) { if (kk < kend) x = *reinterpret_cast<const float4*>(src); }
                     else { if (kk < kend) x.x = src[0]; if (kk + 1 < kend) x.y = src[1]; if (kk + 2 < kend) x.z = src[2]; if (kk + 3 < kend) x.w = src[3]; }
                 }
             } else {                                     // A stored [K][M]
                 const int kk = k0 + v / (BM / 4), row = m0 + (v % (BM / 4)) * 4;
-                if (kk < kend) {
+                if (FULL) { x = *reinterpret_cast<const float4*>(p.A + (size_t)kk * p.lda + row); }
+                else if (kk < kend) {
                     const float* src = p.A + (size_t)kk * p.lda + row;
                     if (VEC) { if (row < p.M) x = *reinterpret_cast<const float4*>(src); }
                     else { if (row < p.M) x.x = src[0]; if (row + 1 < p.M) x.y = src[1]; if (row + 2 < p.M) x.z = src[2]; if (row + 3 < p.M) x.w = src[3]; }
@@ -113,15 +124,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
             const int v = tid + 256 * i;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
             if (B_K) {                                   // B stored [N][K]
-                const int row = n0 + (v >> 2), kk = k0 + (v & 3) * 4;
-                if (row < p.N) {
+                const int row = n0 + v / KQ, kk = k0 + (v % KQ) * 4;
+                if (FULL) { x = *reinterpret_cast<const float4*>(p.B + (size_t)row * p.ldb + kk); }
+                else if (row < p.N) {
                     const float* src = p.B + (size_t)row * p.ldb + kk;
                     if (VEC) { if (kk < kend) x = *reinterpret_cast<const float4*>(src); }
                     else { if (kk < kend) x.x = src[0]; if (kk + 1 < kend) x.y = src[1]; if (kk + 2 < kend) x.z = src[2]; if (kk + 3 < kend) x.w = src[3]; }
                 }
             } else {                                     // B stored [K][N]
                 const int kk = k0 + v / (BN / 4), row = n0 + (v % (BN / 4)) * 4;
-                if (kk < kend) {
+                if (FULL) { x = *reinterpret_cast<const float4*>(p.B + (size_t)kk * p.ldb + row); }
+                else if (kk < kend) {
                     const float* src = p.B + (size_t)kk * p.ldb + row;
                     if (VEC) { if (row < p.N) x = *reinterpret_cast<const float4*>(src); }
                     else { if (row < p.N) x.x = src[0]; if (row + 1 < p.N) x.y = src[1]; if (row + 2 < p.N) x.z = src[2]; if (row + 3 < p.N) x.w = src[3]; }
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
         for (int i = 0; i < NA; ++i) {
             const int v = tid + 256 * i;
             if (A_K) {
-                float* d = &As[buf][((v & 3) * 4) * LDA_S + (v >> 2)];
+                float* d = &As[buf][((v % KQ) * 4) * LDA_S + v / KQ];
                 d[0] = ra[i].x; d[LDA_S] = ra[i].y; d[2 * LDA_S] = ra[i].z; d[3 * LDA_S] = ra[i].w;
             } else {
                 *reinterpret_cast<float4*>(&As[buf][(v / (BM / 4)) * LDA_S + (v % (BM / 4)) * 4]) = ra[i];
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
         for (int i = 0; i < NB; ++i) {
             const int v = tid + 256 * i;
             if (B_K) {
-                float* d = &Bs[buf][((v & 3) * 4) * LDB_S + (v >> 2)];
+                float* d = &Bs[buf][((v % KQ) * 4) * LDB_S + v / KQ];
                 d[0] = rb[i].x; d[LDB_S] = rb[i].y; d[2 * LDB_S] = rb[i].z; d[3 * LDB_S] = rb[i].w;
             } else {
                 *reinterpret_cast<float4*>(&Bs[buf][(v / (BN / 4)) * LDB_S + (v % (BN / 4)) * 4]) = rb[i];
@@ -162,20 +175,27 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const GemmParams p) {
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) { load_a(kbeg + (t + 1) * BK); load_b(kbeg + (t + 1) * BK); }
-        const float* as = As[buf];
-        const float* bs = Bs[buf];
+        const float* as = As[buf] + khalf * LDA_S + a_off;
+        const float* bs = Bs[buf] + khalf * LDB_S + b_off;
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a[TM], b[TN];
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {                          // fetch the next k-pair while this one is in the matrix pipe
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = as[(kk + khalf) * LDA_S + a_off + i * 32];
+                for (int i = 0; i < TM; ++i) a[nxt][i] = as[(kk + 2) * LDA_S + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = bs[(kk + khalf) * LDB_S + b_off + j * 32];
+                for (int j = 0; j < TN; ++j) b[nxt][j] = bs[(kk + 2) * LDB_S + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < ntiles) store_lds(buf ^ 1);
         __syncthreads();
@@ -221,14 +241,22 @@ __global__ void sgemm_splitk_reduce(const float* __restrict__ partial, int split
     }
 }
 
-template <int BM, int BN>
-static void launch_variant(const GemmParams& p, int ak, int bk, bool vec, dim3 grid, hipStream_t s) {
-#define L(AK, BKK, V) hipLaunchKernelGGL((sgemm_kernel<BM, BN, AK, BKK, V>), grid, dim3(256), 0, s, p)
-    if (ak && bk)       { if (vec) L(true, true, true);   else L(true, true, false); }
-    else if (ak && !bk) { if (vec) L(true, false, true);  else L(true, false, false); }
-    else if (!ak && !bk){ if (vec) L(false, false, true); else L(false, false, false); }
-    else                { if (vec) L(false, true, true);  else L(false, true, false); }
+template <int BM, int BN, int BK>
+static void launch_variant(const GemmParams& p, int ak, int bk, bool vec, bool full, dim3 grid, hipStream_t s) {
+#define L(AK, BKK, V, F) hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, AK, BKK, V, F>), grid, dim3(256), 0, s, p)
+#define LV(AK, BKK) { if (full) L(AK, BKK, true, true); else if (vec) L(AK, BKK, true, false); else L(AK, BKK, false, false); }
+    if (ak && bk)        LV(true, true)
+    else if (ak && !bk)  LV(true, false)
+    else if (!ak && !bk) LV(false, false)
+    else                 LV(false, true)
+#undef LV
 #undef L
+}
+
+static int g_gemm_bk = 0;      // 0 = not read yet; ACT_GEMM_BK={16,32} selects the K-tile depth (tuning knob)
+static int gemm_bk() {
+    if (!g_gemm_bk) { const char* e = getenv("ACT_GEMM_BK"); g_gemm_bk = (e && atoi(e) == 32) ? 32 : GEMM_BK_DEFAULT; }
+    return g_gemm_bk;
 }
 
 extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
@@ -268,16 +296,24 @@ extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, co
         while (splits > 1 && (size_t)splits * M * N * sizeof(float) > workspace_bytes) --splits;
         if (splits < 1) splits = 1;
     }
+    const int BKsel = gemm_bk();
     int kps = K;
-    if (splits > 1) { kps = (K + splits - 1) / splits; kps = (kps + GEMM_BK - 1) / GEMM_BK * GEMM_BK; splits = (K + kps - 1) / kps; }
+    if (splits > 1) { kps = (K + splits - 1) / splits; kps = (kps + 31) / 32 * 32; splits = (K + kps - 1) / kps; }
     p.k_per_split = kps;
     p.partial = splits > 1 ? workspace : nullptr;
     if (K == 0) { p.k_per_split = 0; }
 
     dim3 grid((unsigned)nt, 1, (unsigned)splits);
-    if (BM == 128 && BN == 128) launch_variant<128, 128>(p, a_kmajor, b_kmajor, vec, grid, s);
-    else if (BM == 128)         launch_variant<128, 64>(p, a_kmajor, b_kmajor, vec, grid, s);
-    else                        launch_variant<64, 64>(p, a_kmajor, b_kmajor, vec, grid, s);
+    const bool full = vec && (M % BM == 0) && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
+    if (BKsel == 32) {
+        if (BM == 128 && BN == 128) launch_variant<128, 128, 32>(p, a_kmajor, b_kmajor, vec, full, grid, s);
+        else if (BM == 128)         launch_variant<128, 64, 32>(p, a_kmajor, b_kmajor, vec, full, grid, s);
+        else                        launch_variant<64, 64, 32>(p, a_kmajor, b_kmajor, vec, full, grid, s);
+    } else {
+        if (BM == 128 && BN == 128) launch_variant<128, 128, 16>(p, a_kmajor, b_kmajor, vec, full, grid, s);
+        else if (BM == 128)         launch_variant<128, 64, 16>(p, a_kmajor, b_kmajor, vec, full, grid, s);
+        else                        launch_variant<64, 64, 16>(p, a_kmajor, b_kmajor, vec, full, grid, s);
+    }
     ACT_LAUNCH_CHECK();
     if (splits > 1) {
         const long long total = (long long)M * N;
