@@ -1,0 +1,167 @@
+// dgcnn.hip -- the non-GEMM part of the teacher's DGCNN token mixers and of the dVAE tokenizer (models/dvae.py:26-117,587-588)
+//
+// Edge-conv layer, restructured: conv1x1(cat(x_j - x_i, x_i)) = Wa x_j + (Wb - Wa) x_i, so the GEMM runs once over the
+// B*G points and produces YZ = [Y | Z]; the edge tensor [B, C, G, k] is never materialised:
+//   pre(b,g,j,c) = Y[b, idx[b,j,g], c] + Z[b,g,c]
+//   GroupNorm(4) statistics over (C/4, G, k) per sample  -> edge_gn_stats   (one workgroup per (sample, group))
+//   max_j LeakyReLU(GN(pre)) -> because GN's affine map and LeakyReLU are monotone per channel, this equals
+//   LeakyReLU(GN(max_j pre)) when gamma*rstd >= 0 and LeakyReLU(GN(min_j pre)) otherwise -> edge_gn_apply_max
+// The same two kernels with k = 1 and no gather implement the GroupNorm + LeakyReLU head (layer5).
+// Tokenizer: hard gumbel-softmax + one-hot x codebook == argmax_n(logits + G) followed by a row gather, fused with the
+// head's GroupNorm + LeakyReLU so the [B,G,8192] logits are read exactly once and never rewritten.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------------- GN statistics
+// yz [B*G, ldy] with Y at column offset 0 and Z at column offset zoff (zoff < 0: no Z term); idx int64 [B,k,G] or null
+__global__ __launch_bounds__(256) void edge_gn_stats_kernel(const float* __restrict__ yz, int ldy, int zoff,
+                                                            const int64_t* __restrict__ idx, int G, int k, int C, int groups,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, float eps) {
+    __shared__ float sh[2][4];
+    const int b = blockIdx.x / groups, gi = blockIdx.x % groups;
+    const int cpg = C / groups, c0 = gi * cpg;
+    const long long total = (long long)G * k * cpg;
+    // pivot = first element of the group
+    const int r00 = idx ? (int)idx[(size_t)b * k * G] : 0;
+    const float pv = yz[((size_t)b * G + r00) * ldy + c0] + (zoff >= 0 ? yz[((size_t)b * G) * ldy + zoff + c0] : 0.f);
+    float s = 0.f, q = 0.f;
+    for (long long i = threadIdx.x; i < total; i += 256) {
+        const int c = (int)(i % cpg); const long long t = i / cpg; const int g = (int)(t % G); const int j = (int)(t / G);
+        const int src = idx ? (int)idx[((size_t)b * k + j) * G + g] : g;
+        float v = yz[((size_t)b * G + src) * ldy + c0 + c];
+        if (zoff >= 0) v += yz[((size_t)b * G + g) * ldy + zoff + c0 + c];
+        v -= pv;
+        s += v; q += v * v;
+    }
+    s = wave_sum_f32(s); q = wave_sum_f32(q);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float S = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), Q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        const float dm = S / (float)total;
+        const float var = fmaxf(Q / (float)total - dm * dm, 0.f);
+        mean_out[blockIdx.x] = pv + dm;
+        rstd_out[blockIdx.x] = rsqrtf(var + eps);
+    }
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// out[b*G+g, c] = max_j lrelu(gn(pre))    (ldo = row stride of out, written at column offset ooff)
+__global__ __launch_bounds__(256) void edge_gn_apply_max_kernel(const float* __restrict__ yz, int ldy, int zoff,
+                                                                const int64_t* __restrict__ idx, int G, int k, int C, int groups,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float slope, float* __restrict__ out, int ldo, int ooff,
+                                                                long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long long row = i / C; const int b = (int)(row / G), g = (int)(row % G);
+        const int gi = c / (C / groups);
+        float vmax = -3.0e38f, vmin = 3.0e38f;
+        for (int j = 0; j < k; ++j) {
+            const int src = idx ? (int)idx[((size_t)b * k + j) * G + g] : g;
+            const float v = yz[((size_t)b * G + src) * ldy + c];
+            vmax = fmaxf(vmax, v); vmin = fminf(vmin, v);
+        }
+        const float a = rstd[b * groups + gi] * gamma[c];
+        float v = a >= 0.f ? vmax : vmin;
+        if (zoff >= 0) v += yz[(size_t)row * ldy + zoff + c];
+        out[(size_t)row * ldo + ooff + c] = lrelu((v - mean[b * groups + gi]) * a + beta[c], slope);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- Philox4x32-10 (counter RNG)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
+    const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);     // (0,1)
+    return -__logf(-__logf(u));                                              // -log(Exponential(1))
+}
+
+// one workgroup per token row: index = argmax_c ( lrelu(gn(h[row,c])) + gumbel ), out[row,:] = codebook[index,:]
+// noise != null: use the given gumbel noise (parity tests); else Philox keyed by (seed, row, c/4).
+__global__ __launch_bounds__(256) void gumbel_argmax_gather_kernel(const float* __restrict__ h, int G, int C, int groups,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float slope, const float* __restrict__ noise, uint64_t seed,
+                                                                   float inv_tau, const float* __restrict__ codebook, int D,
+                                                                   int64_t* __restrict__ index_out, float* __restrict__ out,
+                                                                   float* __restrict__ logits_out) {
+    __shared__ float sv[4]; __shared__ int si[4]; __shared__ int swin;
+    const int row = blockIdx.x, b = row / G;
+    const int cpg = C / groups;
+    float best = -3.0e38f; int bi = 0;
+    for (int c4 = threadIdx.x * 4; c4 < C; c4 += 1024) {
+        const float4 x = *reinterpret_cast<const float4*>(h + (size_t)row * C + c4);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        if (!noise) philox4x32_10((uint32_t)(c4 >> 2), (uint32_t)row, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c4 + u, gi = c / cpg;
+            const float v = lrelu((xs[u] - mean[b * groups + gi]) * rstd[b * groups + gi] * gamma[c] + beta[c], slope);
+            if (logits_out) logits_out[(size_t)row * C + c] = v;
+            const float gnoise = noise ? noise[(size_t)row * C + c] : gumbel_from_bits(rnd[u]);
+            const float y = (v + gnoise) * inv_tau;
+            if (y > best) { best = y; bi = c; }         // ascending c inside a thread: first maximum wins
+        }
+    }
+    // block arg-max with lowest-index tie-break (torch.argmax returns the first maximum)
+    const float wmax = wave_max_f32(best, -3.4e38f);
+    int cand = (best == wmax) ? bi : 0x7fffffff;
+    // min over the wave of candidate indices
+    for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off));
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = wmax; si[threadIdx.x >> 6] = cand; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float gv = sv[0]; int gi2 = si[0];
+        for (int w = 1; w < 4; ++w) if (sv[w] > gv || (sv[w] == gv && si[w] < gi2)) { gv = sv[w]; gi2 = si[w]; }
+        swin = gi2;
+        if (index_out) index_out[row] = gi2;
+    }
+    __syncthreads();
+    const int win = swin;
+    for (int d = threadIdx.x; d < D; d += 256) out[(size_t)row * D + d] = codebook[(size_t)win * D + d];
+}
+
+static inline unsigned grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block; if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g;
+}
+
+extern "C" int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C,
+                                         int groups, const float* gamma, const float* beta, float eps, float slope,
+                                         float* stats /* [2][B*groups] */, float* out, int ldo, int ooff, act_stream_t stream) {
+    if (!yz || !gamma || !beta || !stats || !out) return ACT_E_NULLPTR;
+    if (B <= 0 || G <= 0 || k <= 0 || C <= 0 || groups <= 0 || C % groups) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * k + (zoff >= 0 ? 2 : 0) + 1));
+    float* mean = stats; float* rstd = stats + (size_t)B * groups;
+    hipLaunchKernelGGL(edge_gn_stats_kernel, dim3(B * groups), dim3(256), 0, s, yz, ldy, zoff, idx, G, k, C, groups, mean, rstd, eps);
+    const long long total = (long long)B * G * C;
+    hipLaunchKernelGGL(edge_gn_apply_max_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, yz, ldy, zoff, idx, G, k, C, groups, mean, rstd,
+                       gamma, beta, slope, out, ldo, ooff, total);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int C, int groups, const float* gamma, const float* beta,
+                                               float eps, float slope, const float* noise, uint64_t seed, float tau,
+                                               const float* codebook, int D, float* stats, int64_t* index_out, float* out,
+                                               float* logits_out, act_stream_t stream) {
+    if (!h || !gamma || !beta || !codebook || !stats || !out) return ACT_E_NULLPTR;
+    if (B <= 0 || G <= 0 || C <= 0 || (C & 3) || groups <= 0 || C % groups || D <= 0 || tau <= 0.f) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GUMBEL_ARGMAX, s, 0.0, 4.0 * B * G * ((double)C * (2 + (noise ? 1 : 0) + (logits_out ? 1 : 0)) + 2.0 * D));
+    float* mean = stats; float* rstd = stats + (size_t)B * groups;
+    hipLaunchKernelGGL(edge_gn_stats_kernel, dim3(B * groups), dim3(256), 0, s, h, C, -1, nullptr, G, 1, C, groups, mean, rstd, eps);
+    hipLaunchKernelGGL(gumbel_argmax_gather_kernel, dim3(B * G), dim3(256), 0, s, h, G, C, groups, mean, rstd, gamma, beta, slope, noise, seed,
+                       1.0f / tau, codebook, D, index_out, out, logits_out);
+    ACT_LAUNCH_CHECK(); return 0;
+}

@@ -49,7 +49,7 @@ __device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, fl
         default: break;
     }
     if (e.rowscale) v *= e.rowscale[row / e.rows_per_scale];
-    if (e.res) v += e.res[(size_t)row * e.ldr + col];
+    if (e.res) v += e.res[(size_t)(e.res_row_div > 1 ? row / e.res_row_div : row) * e.ldr + col];
     return v;
 }
 

@@ -1,0 +1,235 @@
+// pointnet.hip -- row-major [rows, channels] kernels of the mini-PointNet patch embedding and the FoldingNet decoder
+// (models/dvae.py:185-275): train-mode BatchNorm (batch statistics over all rows) + ReLU forward / backward and the
+// per-group max-pool forward / backward.  All HBM-bound: every kernel streams its operands exactly once with float4
+// accesses; column reductions are two-stage with a fixed summation order (deterministic).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------- column statistics
+// partial[blk][0][c] = sum_r f(r,c), partial[blk][1][c] = sum_r g(r,c) over the block's rows.
+//   MODE 0: f = x,            g = x*x                       (BatchNorm batch statistics)
+//   MODE 1: f = dyh,          g = dyh * xhat                (BatchNorm backward sums), dyh = relu ? dy*(y>0) : dy
+// block = 64 float4-columns?  no: 64 columns x 4 row-lanes like colsum, 4 rows in flight per thread.
+template <int MODE>
+__global__ __launch_bounds__(256) void colstats_stage1(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       int relu, int R, int C, int rows_per_block, float* __restrict__ partial) {
+    __shared__ float sh[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+    if (c < C) {
+        float sc = 0.f, sf = 0.f, mu = 0.f, rs = 0.f, pv = 0.f;
+        if (MODE == 1) { sc = scale[c]; sf = shift[c]; mu = mean[c]; rs = rstd[c]; }
+        else pv = x[c];                                  // pivot (row 0) keeps E[x^2]-E[x]^2 free of cancellation
+        auto term = [&](int r, float& f, float& g) {
+            const float xv = x[(size_t)r * C + c];
+            if (MODE == 0) { const float t = xv - pv; f += t; g += t * t; }
+            else {
+                float d = dy[(size_t)r * C + c];
+                if (relu && !(xv * sc + sf > 0.f)) d = 0.f;
+                f += d; g += d * ((xv - mu) * rs);
+            }
+        };
+        int r = r0 + ry;
+        for (; r + 12 < r1; r += 16) { term(r, f0, g0); term(r + 4, f1, g1); term(r + 8, f2, g2); term(r + 12, f3, g3); }
+        for (; r < r1; r += 4) term(r, f0, g0);
+    }
+    sh[0][ry][cx] = (f0 + f1) + (f2 + f3);
+    sh[1][ry][cx] = (g0 + g1) + (g2 + g3);
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        partial[((size_t)blockIdx.y * 2 + 0) * C + c] = (sh[0][0][cx] + sh[0][1][cx]) + (sh[0][2][cx] + sh[0][3][cx]);
+        partial[((size_t)blockIdx.y * 2 + 1) * C + c] = (sh[1][0][cx] + sh[1][1][cx]) + (sh[1][2][cx] + sh[1][3][cx]);
+    }
+}
+
+// BatchNorm finalize: mean, biased var -> scale = gamma*rstd, shift = beta - mean*scale; running stats (momentum, unbiased var)
+__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nparts, int C, int R, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < nparts; ++p) { s += partial[((size_t)p * 2) * C + c]; q += partial[((size_t)p * 2 + 1) * C + c]; }
+    const float dm = s / (float)R;                      // mean of (x - pivot)
+    const float mean = x[c] + dm;
+    float var = q / (float)R - dm * dm;
+    var = fmaxf(var, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    mean_out[c] = mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = beta[c] - mean * sc;
+    if (running_mean) {
+        const float unb = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+// sums of stage 1 -> out0[c], out1[c]
+__global__ void colstats_stage2(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out0, float* __restrict__ out1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < nparts; ++p) { s += partial[((size_t)p * 2) * C + c]; q += partial[((size_t)p * 2 + 1) * C + c]; }
+    out0[c] = s; out1[c] = q;
+}
+
+// y = relu?(x*scale[c] + shift[c])   (float4)
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int relu, long long total4, int C4,
+                                                         float* __restrict__ y) {
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*>(scale);
+    const float4* __restrict__ h4 = reinterpret_cast<const float4*>(shift);
+    float4* __restrict__ y4 = reinterpret_cast<float4*>(y);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        const float4 v = x4[i], s = s4[c], h = h4[c];
+        float4 o; o.x = v.x * s.x + h.x; o.y = v.y * s.y + h.y; o.z = v.z * s.z + h.z; o.w = v.w * s.w + h.w;
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        y4[i] = o;
+    }
+}
+// dx = scale[c] * (dyh - s1[c]/R - xhat * s2[c]/R),  dyh = relu ? dy*(x*scale+shift>0) : dy      (scale = gamma*rstd)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ s1, const float* __restrict__ s2, int relu,
+                                                           float invR, long long total, int C, float* __restrict__ dx) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float xv = x[i], sc = scale[c];
+        float d = dy[i];
+        if (relu && !(xv * sc + shift[c] > 0.f)) d = 0.f;
+        const float xh = (xv - mean[c]) * rstd[c];
+        dx[i] = sc * (d - s1[c] * invR - xh * s2[c] * invR);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ group max-pool
+// in [G*n, C] -> out [G, C] = max over the n rows of a group; arg [G,C] = first row attaining it (torch.max semantics)
+__global__ __launch_bounds__(256) void group_max_kernel(const float* __restrict__ in, int n, int C, long long total,
+                                                        float* __restrict__ out, int32_t* __restrict__ arg) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long long g = i / C;
+        const float* __restrict__ p = in + (size_t)g * n * C + c;
+        float best = p[0]; int bi = 0;
+        for (int r = 1; r < n; ++r) { const float v = p[(size_t)r * C]; if (v > best) { best = v; bi = r; } }
+        out[i] = best;
+        if (arg) arg[i] = bi;
+    }
+}
+// din[g*n + r, c] (+)= (arg[g,c] == r) ? dout[g,c] : 0
+__global__ __launch_bounds__(256) void group_max_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, int n,
+                                                            int C, long long total, int accumulate, float* __restrict__ din) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long long row = i / C; const long long g = row / n; const int r = (int)(row % n);
+        const float v = arg[g * C + c] == r ? dout[g * C + c] : 0.f;
+        din[i] = accumulate ? din[i] + v : v;
+    }
+}
+// out[g, c] = sum over the n rows of a group   (gradient of a per-group broadcast add)
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* __restrict__ in, int n, int C, long long total, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long long g = i / C;
+        const float* __restrict__ p = in + (size_t)g * n * C + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f; int r = 0;
+        for (; r + 3 < n; r += 4) { a0 += p[(size_t)r * C]; a1 += p[(size_t)(r + 1) * C]; a2 += p[(size_t)(r + 2) * C]; a3 += p[(size_t)(r + 3) * C]; }
+        for (; r < n; ++r) a0 += p[(size_t)r * C];
+        out[i] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+static inline unsigned grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block; if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g;
+}
+static int stats_parts(int R, int C) {
+    const int cb = (C + 63) / 64;
+    int parts = (2048 + cb - 1) / cb;
+    const int maxp = (R + 63) / 64; if (parts > maxp) parts = maxp;
+    if (parts > 1024) parts = 1024; if (parts < 1) parts = 1;
+    return parts;
+}
+extern "C" size_t act_colstats_workspace(int R, int C) { return (size_t)stats_parts(R, C) * 2 * C * sizeof(float); }
+
+// train-mode BatchNorm statistics of x [R,C] (models/dvae.py:189-200 nn.BatchNorm1d over B*G*n samples per channel):
+// writes mean, rstd, scale = gamma*rstd, shift = beta - mean*scale and updates running stats in place (nullable).
+extern "C" int act_bn_stats_f32(const float* x, int R, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                                float* workspace, size_t workspace_bytes, act_stream_t stream) {
+    if (!x || !gamma || !beta || !mean || !rstd || !scale || !shift || !workspace) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0) return ACT_E_BADARG;
+    const int parts = stats_parts(R, C);
+    if (workspace_bytes < (size_t)parts * 2 * C * sizeof(float)) return ACT_E_BADARG;
+    int rpb = (R + parts - 1) / parts; rpb = (rpb + 3) / 4 * 4;
+    const int nparts = (R + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_BN_STATS, s, 0.0, 4.0 * R * (double)C);
+    hipLaunchKernelGGL(colstats_stage1<0>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                       R, C, rpb, workspace);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, x, workspace, nparts, C, R, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean, rstd, scale, shift);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int act_affine_act_f32(const float* x, const float* scale, const float* shift, int relu, int R, int C, float* y,
+                                  act_stream_t stream) {
+    if (!x || !scale || !shift || !y) return ACT_E_NULLPTR;
+    if (R < 0 || C <= 0 || (C & 3)) return ACT_E_BADARG;
+    const long long total4 = (long long)R * C / 4; if (total4 == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_BN_APPLY, s, 0.0, 8.0 * R * (double)C);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(total4, 256)), dim3(256), 0, s, x, scale, shift, relu, total4, C / 4, y);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+// BatchNorm(+ReLU) backward: dy = gradient w.r.t. the (ReLU'd) output; x = BN input; -> dx, dgamma, dbeta
+extern "C" int act_bn_bwd_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean,
+                              const float* rstd, int relu, int R, int C, float* dx, float* dgamma, float* dbeta,
+                              float* workspace, size_t workspace_bytes, act_stream_t stream) {
+    if (!x || !dy || !scale || !shift || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0) return ACT_E_BADARG;
+    const int parts = stats_parts(R, C);
+    if (workspace_bytes < (size_t)parts * 2 * C * sizeof(float)) return ACT_E_BADARG;
+    int rpb = (R + parts - 1) / parts; rpb = (rpb + 3) / 4 * 4;
+    const int nparts = (R + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_BN_BWD, s, 0.0, 20.0 * R * (double)C);
+    hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace);
+    hipLaunchKernelGGL(colstats_stage2, dim3((C + 63) / 64), dim3(64), 0, s, workspace, nparts, C, dbeta, dgamma);
+    const long long total = (long long)R * C;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, dbeta, dgamma, relu,
+                       1.0f / (float)R, total, C, dx);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int act_group_max_f32(const float* in, int G, int n, int C, float* out, int32_t* arg, act_stream_t stream) {
+    if (!in || !out) return ACT_E_NULLPTR;
+    if (G < 0 || n <= 0 || C <= 0) return ACT_E_BADARG;
+    const long long total = (long long)G * C; if (total == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_MAXPOOL, s, 0.0, 4.0 * G * (double)C * (n + 2));
+    hipLaunchKernelGGL(group_max_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, n, C, total, out, arg);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_group_max_bwd_f32(const float* dout, const int32_t* arg, int G, int n, int C, int accumulate, float* din,
+                                     act_stream_t stream) {
+    if (!dout || !arg || !din) return ACT_E_NULLPTR;
+    if (G < 0 || n <= 0 || C <= 0) return ACT_E_BADARG;
+    const long long total = (long long)G * n * C; if (total == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_MAXPOOL_BWD, s, 0.0, 4.0 * G * (double)C * (n * (accumulate ? 2 : 1) + 2));
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, dout, arg, n, C, total, accumulate, din);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_group_sum_f32(const float* in, int G, int n, int C, float* out, act_stream_t stream) {
+    if (!in || !out) return ACT_E_NULLPTR;
+    if (G < 0 || n <= 0 || C <= 0) return ACT_E_BADARG;
+    const long long total = (long long)G * C; if (total == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_ELTWISE, s, 0.0, 4.0 * G * (double)C * (n + 1));
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, n, C, total, out);
+    ACT_LAUNCH_CHECK(); return 0;
+}

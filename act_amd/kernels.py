@@ -16,7 +16,7 @@ EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_GELU_GRAD, EPI_MUL_RELU_MASK = 0, 1, 2, 3,
 
 class GemmEpilogue(ctypes.Structure):
     _fields_ = [("alpha", _f), ("act", _i), ("accumulate", _i), ("rows_per_scale", _i), ("ldr", _i), ("ldaux", _i),
-                ("bias", _vp), ("rowscale", _vp), ("res", _vp), ("aux", _vp)]
+                ("res_row_div", _i), ("bias", _vp), ("rowscale", _vp), ("res", _vp), ("aux", _vp)]
 
 
 _C._declare({
@@ -62,7 +62,7 @@ def _f32c(t, name="tensor"):
 
 # ---- raw wrappers ---------------------------------------------------------------------------------------
 def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, res=None, rowscale=None,
-         rows_per_scale=0, out=None, accumulate=False, alpha=1.0):
+         rows_per_scale=0, out=None, accumulate=False, alpha=1.0, res_row_div=0):
     """C[M,N] = epilogue(op(a) @ op(b)); a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N]."""
     a = _f32c(a, "a"); b = _f32c(b, "b")
     if a_kmajor:
@@ -79,7 +79,7 @@ def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, 
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     e = GemmEpilogue(alpha=alpha, act=act, accumulate=int(accumulate), rows_per_scale=int(rows_per_scale),
                      ldr=(res.stride(0) if res is not None else 0), ldaux=(aux.stride(0) if aux is not None else 0),
-                     bias=ptr(bias), rowscale=ptr(rowscale), res=ptr(res), aux=ptr(aux))
+                     res_row_div=int(res_row_div), bias=ptr(bias), rowscale=ptr(rowscale), res=ptr(res), aux=ptr(aux))
     ws = workspace(a.device)
     check(lib.act_sgemm_f32(int(a_kmajor), int(b_kmajor), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
                             out.stride(0), ctypes.byref(e), ptr(ws), ws.numel() * 4, stream()), "act_sgemm_f32")
@@ -312,3 +312,171 @@ class CosineLossFn(torch.autograd.Function):
 
 def cosine_distill_loss(student, teacher):
     return CosineLossFn.apply(student, teacher).reshape(())
+
+
+# ---- mini-PointNet / FoldingNet row kernels (csrc/pointnet.hip) --------------------------------------------------
+_C._declare({
+    "act_colstats_workspace": [_i, _i],
+    "act_bn_stats_f32": [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "act_affine_act_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "act_bn_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp],
+    "act_group_max_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "act_group_max_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "act_group_sum_f32": [_vp, _i, _i, _i, _vp, _vp],
+})
+_C.lib.act_layernorm_bwd_workspace.restype = _sz
+_C.lib.act_colsum_workspace.restype = _sz
+_C.lib.act_colstats_workspace.restype = _sz
+for _n in ("act_colstats_workspace", "act_bn_stats_f32", "act_affine_act_f32", "act_bn_bwd_f32", "act_group_max_f32",
+           "act_group_max_bwd_f32", "act_group_sum_f32"):
+    _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
+
+
+class BNActFn(torch.autograd.Function):
+    """BatchNorm1d over the rows of x [R,C] (+ optional ReLU).  train: batch statistics (biased variance), running stats
+    updated in place (momentum, unbiased variance) like nn.BatchNorm1d; eval: running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        x = _f32c(x)
+        R, C = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        if training:
+            mean, rstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+            ws = workspace(dev, lib.act_colstats_workspace(R, C))
+            check(lib.act_bn_stats_f32(ptr(x), R, C, ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean),
+                                       ptr(running_var), ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(ws), ws.numel() * 4,
+                                       stream()), "act_bn_stats_f32")
+        else:
+            rstd = torch.rsqrt(running_var + eps)
+            mean = running_mean
+            scale = gamma * rstd
+            shift = beta - running_mean * scale
+        check(lib.act_affine_act_f32(ptr(x), ptr(scale), ptr(shift), int(relu), R, C, ptr(y), stream()), "act_affine_act_f32")
+        ctx.save_for_backward(x, scale, shift, mean, rstd)
+        ctx.training, ctx.relu = training, relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, rstd = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, C = x.shape
+        if not ctx.training:
+            raise NotImplementedError("BatchNorm backward in eval mode is off the training path")
+        dx = torch.empty_like(x)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, lib.act_colstats_workspace(R, C))
+        check(lib.act_bn_bwd_f32(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), int(ctx.relu), R, C, ptr(dx), ptr(dg),
+                                 ptr(db), ptr(ws), ws.numel() * 4, stream()), "act_bn_bwd_f32")
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, training, relu=True):
+    """functional nn.BatchNorm1d (+ReLU) on rows [R,C] with the module's parameters and buffers."""
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu)
+
+
+class GroupMaxFn(torch.autograd.Function):
+    """x [G*n, C] -> max over the n rows of every group, [G, C]   (torch.max(feature, dim=2) of models/dvae.py:211,214)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        x = _f32c(x)
+        R, C = x.shape
+        G = R // n
+        out = torch.empty(G, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(G, C, dtype=torch.int32, device=x.device)
+        check(lib.act_group_max_f32(ptr(x), G, n, C, ptr(out), ptr(arg), stream()), "act_group_max_f32")
+        ctx.save_for_backward(arg)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        G, C = dout.shape
+        din = torch.empty(G * ctx.n, C, dtype=torch.float32, device=dout.device)
+        check(lib.act_group_max_bwd_f32(ptr(dout), ptr(arg), G, ctx.n, C, 0, ptr(din), stream()), "act_group_max_bwd_f32")
+        return din, None
+
+
+def group_max(x, n):
+    return GroupMaxFn.apply(x, n)
+
+
+class LinearGroupAddFn(torch.autograd.Function):
+    """y[r,:] = x[r,:] @ w^T + g[r // n, :]  -- the per-point half of a conv over cat(per-group feature, per-point feature)
+    with the per-group half g added in the GEMM epilogue (models/dvae.py:212-213, :266-271)."""
+
+    @staticmethod
+    def forward(ctx, x, w, g, n):
+        x = _f32c(x); g = _f32c(g)
+        y = gemm(x, w, True, True, res=g, res_row_div=n)
+        ctx.save_for_backward(x, w)
+        ctx.n = n
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _f32c(dy)
+        dx = gemm(dy, w, True, False) if ctx.needs_input_grad[0] else None
+        dw = gemm(dy, x, False, False) if ctx.needs_input_grad[1] else None
+        dg = None
+        if ctx.needs_input_grad[2]:
+            R, C = dy.shape
+            dg = torch.empty(R // ctx.n, C, dtype=torch.float32, device=dy.device)
+            check(lib.act_group_sum_f32(ptr(dy), R // ctx.n, ctx.n, C, ptr(dg), stream()), "act_group_sum_f32")
+        return dx, dw, dg, None
+
+
+def linear_group_add(x, w, g, n):
+    return LinearGroupAddFn.apply(x, w, g, n)
+
+
+# ---- DGCNN / tokenizer glue (csrc/dgcnn.hip) -------------------------------------------------------------------------
+_u64 = ctypes.c_uint64
+_C._declare({
+    "act_edge_gn_lrelu_max_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _vp],
+    "act_gn_gumbel_argmax_gather_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _u64, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+})
+_C.lib.act_layernorm_bwd_workspace.restype = _sz
+_C.lib.act_colsum_workspace.restype = _sz
+_C.lib.act_colstats_workspace.restype = _sz
+for _n in ("act_edge_gn_lrelu_max_f32", "act_gn_gumbel_argmax_gather_f32"):
+    _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
+
+
+def edge_gn_lrelu_max(yz, zoff, idx, B, G, k, C, gn, out=None, ooff=0, slope=0.2):
+    """inference-only tail of a DGCNN layer (see csrc/dgcnn.hip); yz [B*G, ld], -> out[:, ooff:ooff+C]."""
+    yz = _f32c(yz)
+    if out is None:
+        out = torch.empty(B * G, C, dtype=torch.float32, device=yz.device)
+    stats = torch.empty(2 * B * gn.num_groups, dtype=torch.float32, device=yz.device)
+    check(lib.act_edge_gn_lrelu_max_f32(ptr(yz), yz.stride(0), int(zoff), ptr(idx), B, G, k, C, gn.num_groups, ptr(gn.weight),
+                                        ptr(gn.bias), float(gn.eps), float(slope), ptr(stats), ptr(out), out.stride(0), int(ooff),
+                                        stream()), "act_edge_gn_lrelu_max_f32")
+    return out
+
+
+def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, want_logits=False, slope=0.2):
+    """fused layer5 GroupNorm + LeakyReLU + hard gumbel-softmax + codebook lookup -> (codes [B,G,D], index [B,G], logits|None)."""
+    h = _f32c(h)
+    C = h.shape[1]
+    D = codebook.shape[1]
+    dev = h.device
+    stats = torch.empty(2 * B * gn.num_groups, dtype=torch.float32, device=dev)
+    index = torch.empty(B, G, dtype=torch.int64, device=dev)
+    out = torch.empty(B, G, D, dtype=torch.float32, device=dev)
+    logits = torch.empty(B, G, C, dtype=torch.float32, device=dev) if want_logits else None
+    noise = _f32c(noise) if noise is not None else None
+    check(lib.act_gn_gumbel_argmax_gather_f32(ptr(h), B, G, C, gn.num_groups, ptr(gn.weight), ptr(gn.bias), float(gn.eps), float(slope),
+                                              ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF, float(tau), ptr(_f32c(codebook)), D, ptr(stats),
+                                              ptr(index), ptr(out), ptr(logits), stream()), "act_gn_gumbel_argmax_gather_f32")
+    return out, index, logits

@@ -61,29 +61,21 @@ class Encoder(nn.Module):
         self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
                                          nn.Conv1d(512, self.encoder_channel, 1))
 
-    @staticmethod
-    def _bn(x, bn, training):
-        if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, training or not bn.track_running_stats,
-                            bn.momentum, bn.eps)
-
     def forward(self, point_groups):
         bs, g, n, _ = point_groups.shape
         x = point_groups.reshape(bs * g * n, 3)
         c1, bn1, _, c2 = self.first_conv
         c3, bn2, _, c4 = self.second_conv
         h = K.linear(x, _w2d(c1), c1.bias)
-        h = F.relu(self._bn(h, bn1, self.training))
+        h = K.batch_norm_act(h, bn1, self.training, relu=True)
         h = K.linear(h, _w2d(c2), c2.bias)                               # [R,256]
-        fg = h.view(bs * g, n, 256).max(dim=1)[0]                        # [BG,256]
+        fg = K.group_max(h, n)                                           # [BG,256]
         w3 = _w2d(c3)
         gw = K.linear(fg, w3[:, :256], c3.bias)                          # per-group half of the 512->512 conv
-        h = K.linear(h, w3[:, 256:], None).view(bs * g, n, 512) + gw.unsqueeze(1)
-        h = F.relu(self._bn(h.view(bs * g * n, 512), bn2, self.training))
+        h = K.linear_group_add(h, w3[:, 256:], gw, n)                    # + per-point half, broadcast add in the epilogue
+        h = K.batch_norm_act(h, bn2, self.training, relu=True)
         h = K.linear(h, _w2d(c4), c4.bias)
-        out = h.view(bs * g, n, self.encoder_channel).max(dim=1)[0]
-        return out.reshape(bs, g, self.encoder_channel)
+        return K.group_max(h, n).reshape(bs, g, self.encoder_channel)
 
 
 class DGCNN(nn.Module):
@@ -114,33 +106,56 @@ class DGCNN(nn.Module):
         return idx
 
     @staticmethod
-    def _edge_layer(f, idx, layer, B, G):
-        conv, gn, _ = layer
+    def _stacked_weight(conv):
         w = _w2d(conv)
         cin = w.shape[1] // 2
         wa, wb = w[:, :cin], w[:, cin:]
-        yz = K.linear(f, torch.cat((wa, wb - wa), dim=0), None)          # [BG, 2*Cout]
-        cout = w.shape[0]
+        return torch.cat((wa, wb - wa), dim=0)                            # rows: [Wa ; Wb - Wa]
+
+    @staticmethod
+    def _edge_layer(f, idx, layer, B, G, out=None, ooff=0):
+        conv, gn, _ = layer
+        cout = conv.weight.shape[0]
+        yz = K.linear(f, DGCNN._stacked_weight(conv), None)               # [BG, 2*Cout] = [Y | Z]
+        if not torch.is_grad_enabled():                                   # frozen teacher (Stage II): fused HIP tail
+            return K.edge_gn_lrelu_max(yz, cout, idx, B, G, idx.shape[1], cout, gn, out=out, ooff=ooff)
         y = yz[:, :cout].reshape(B, G, cout)
         z = yz[:, cout:].reshape(B, 1, G, cout)
         nb = y[torch.arange(B, device=f.device).view(B, 1, 1), idx]      # [B,k,G,Cout]
         pre = (nb + z).permute(0, 3, 2, 1)                               # [B,Cout,G,k]
         act = F.leaky_relu(F.group_norm(pre, 4, gn.weight, gn.bias, gn.eps), 0.2)
-        return act.max(dim=-1)[0].transpose(1, 2).reshape(B * G, cout)   # rows [BG,Cout]
+        res = act.max(dim=-1)[0].transpose(1, 2).reshape(B * G, cout)    # rows [BG,Cout]
+        if out is not None:
+            out[:, ooff:ooff + cout] = res
+        return res
 
-    def forward(self, f, coor, idx=None):
-        """f [B,G,C], coor [B,G,3] -> [B,G,C']"""
+    def features(self, f, coor, idx=None):
+        """everything up to (not including) layer5's GroupNorm: -> pre-norm head output rows [B*G, C']"""
         B, G, C = f.shape
         if idx is None:
             with torch.no_grad():
                 idx = self.graph_index(coor)
         x = K.linear(f.reshape(B * G, C), _w2d(self.input_trans), self.input_trans.bias)
-        feats = []
+        fused = not torch.is_grad_enabled()
+        cat = torch.empty(B * G, 2304, dtype=torch.float32, device=f.device) if fused else None
+        feats, off = [], 0
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
-            x = self._edge_layer(x, idx, layer, B, G)
+            cout = layer[0].weight.shape[0]
+            x = self._edge_layer(x, idx, layer, B, G, out=cat, ooff=off)
+            if fused:
+                x = cat[:, off:off + cout]                                # written in place: no torch.cat of the 4 outputs
             feats.append(x)
-        conv, gn, _ = self.layer5
-        h = K.linear(torch.cat(feats, dim=1), _w2d(conv), None)          # [BG, C']
+            off += cout
+        h_in = cat if fused else torch.cat(feats, dim=1)
+        return K.linear(h_in, _w2d(self.layer5[0]), None)                 # [BG, C']
+
+    def forward(self, f, coor, idx=None):
+        """f [B,G,C], coor [B,G,3] -> [B,G,C']"""
+        B, G, _ = f.shape
+        h = self.features(f, coor, idx)
+        gn = self.layer5[1]
+        if not torch.is_grad_enabled():
+            return K.edge_gn_lrelu_max(h, -1, None, B, G, 1, h.shape[1], gn).view(B, G, -1)
         h = h.view(B, G, -1).transpose(1, 2)                             # [B,C',G]
         h = F.leaky_relu(F.group_norm(h, 4, gn.weight, gn.bias, gn.eps), 0.2)
         return h.transpose(1, 2)
@@ -180,9 +195,9 @@ class Decoder(nn.Module):
         w1 = _w2d(c1)
         # conv over cat(feature_global, seed, point): the feature_global part is constant per group
         gw = K.linear(fgl, w1[:, :c], c1.bias)                                                  # [BG,512]
-        h = K.linear(torch.cat((seed, rep), dim=1), w1[:, c:], None).view(bs * g, self.num_fine, 512) + gw.unsqueeze(1)
-        h = F.relu(Encoder._bn(h.view(-1, 512), bn1, self.training))
-        h = F.relu(Encoder._bn(K.linear(h, _w2d(c2), c2.bias), bn2, self.training))
+        h = K.linear_group_add(torch.cat((seed, rep), dim=1), w1[:, c:], gw, self.num_fine)
+        h = K.batch_norm_act(h, bn1, self.training, relu=True)
+        h = K.batch_norm_act(K.linear(h, _w2d(c2), c2.bias), bn2, self.training, relu=True)
         fine = K.linear(h, _w2d(c3), c3.bias) + rep
         return coarse.reshape(bs, g, self.num_coarse, 3), fine.reshape(bs, g, self.num_fine, 3)
 
@@ -352,8 +367,18 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
     def forward_tokenizer_features(self, neighborhood, center, return_global=True, draws=None):
         with torch.no_grad():
             idx = DGCNN.graph_index(center)                # the k=4 graph is identical for all 8 edge-conv layers
-        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
-        sampled = self._gumbel_codes(logits, 1.0, True, draws)
+        if not torch.is_grad_enabled():
+            # frozen teacher: head GroupNorm + LeakyReLU + hard gumbel + codebook lookup in one pass over the logits
+            B, G, _ = center.shape
+            h = self.dgcnn_1.features(self.encoder(neighborhood), center, idx)
+            noise = None
+            if draws is not None and (draws.has("gumbel") or draws.record):
+                noise = draws.get("gumbel", lambda: -torch.empty(B, G, h.shape[1], device=h.device).exponential_().log())
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
+            sampled, _, _ = K.gn_gumbel_argmax_gather(h, B, G, self.dgcnn_1.layer5[1], self.codebook, noise=noise, seed=seed)
+        else:
+            logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
+            sampled = self._gumbel_codes(logits, 1.0, True, draws)
         feature = self.visual_embedding(sampled, center, draws)
         if return_global:
             feature = self.dgcnn_2(feature, center, idx)

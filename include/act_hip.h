@@ -73,7 +73,7 @@ int act_chamfer_bwd_f32(const float* xyz1, const float* xyz2, const int32_t* idx
  *   b_kmajor=1: B stored [N][K] (ldb>=K)   b_kmajor=0: B stored [K][N] (ldb>=N)
  * nn.Linear / Conv1d(k=1) forward = (1,1) with B = weight [out,in] (models/act.py:25-69, models/dvae.py:185-215);
  * input gradient = (1,0); weight gradient = (0,0) with K = number of rows (split-K through `workspace`).
- * epilogue order: v = alpha*acc; v += bias[col]; activation; v *= rowscale[row / rows_per_scale]; v += res[row,col];
+ * epilogue order: v = alpha*acc; v += bias[col]; activation; v *= rowscale[row / rows_per_scale]; v += res[row / res_row_div, col];
  * if accumulate: v += C[row,col].   (rowscale = DropPath gate/keep per sample, res = residual stream.)
  *   ACT_EPI_GELU          : if aux != NULL the pre-activation is stored to aux[row,col]; v = gelu_erf(v)
  *   ACT_EPI_MUL_GELU_GRAD : v *= gelu'(aux[row,col])        ACT_EPI_MUL_RELU_MASK: v = aux[row,col] > 0 ? v : 0
@@ -85,6 +85,7 @@ typedef struct {
     int          accumulate;       /* C += result */
     int          rows_per_scale;   /* rows sharing one rowscale entry (tokens per sample) */
     int          ldr, ldaux;       /* leading dimensions of res / aux */
+    int          res_row_div;      /* res row = row / res_row_div (0/1: per row; n: one res row per group of n rows) */
     const float* bias;             /* [N] or NULL */
     const float* rowscale;         /* [ceil(M / rows_per_scale)] or NULL */
     const float* res;              /* [M, ldr] or NULL */
@@ -124,6 +125,42 @@ int act_cosine_loss_fwd_f32(const float* student, const float* teacher, int R, i
                             float* row_loss, float* stats, act_stream_t stream);
 int act_cosine_loss_bwd_f32(const float* student, const float* teacher, const float* stats, const float* grad_loss,
                             int R, int D, float eps, float* grad_student, act_stream_t stream);
+
+/* ---- mini-PointNet / FoldingNet row kernels (models/dvae.py:185-275), rows = points, columns = channels ------ */
+/* train-mode BatchNorm1d statistics over all R rows: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale;
+ * running stats updated in place when non-NULL (momentum, unbiased variance).  workspace: act_colstats_workspace. */
+size_t act_colstats_workspace(int R, int C);
+int act_bn_stats_f32(const float* x, int R, int C, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                     float* workspace, size_t workspace_bytes, act_stream_t stream);
+/* y = relu?(x * scale[c] + shift[c])    (BatchNorm apply, eval or train) */
+int act_affine_act_f32(const float* x, const float* scale, const float* shift, int relu, int R, int C, float* y,
+                       act_stream_t stream);
+/* BatchNorm(+ReLU) backward in train mode: dy w.r.t. the activation output, x = BN input -> dx, dgamma, dbeta */
+int act_bn_bwd_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean,
+                   const float* rstd, int relu, int R, int C, float* dx, float* dgamma, float* dbeta,
+                   float* workspace, size_t workspace_bytes, act_stream_t stream);
+/* torch.max over the n points of each group: in [G*n, C] -> out [G,C], arg int32 [G,C] (first maximum; nullable) */
+int act_group_max_f32(const float* in, int G, int n, int C, float* out, int32_t* arg, act_stream_t stream);
+int act_group_max_bwd_f32(const float* dout, const int32_t* arg, int G, int n, int C, int accumulate, float* din,
+                          act_stream_t stream);
+/* out[g,c] = sum over the n rows of group g (gradient of a per-group broadcast add) */
+int act_group_sum_f32(const float* in, int G, int n, int C, float* out, act_stream_t stream);
+
+/* ---- DGCNN token mixer + dVAE tokenizer glue (models/dvae.py:26-117, 587-588) -------------------------------- */
+/* Edge-conv tail.  yz [B*G, ldy] holds Y = Wa.x at column 0 and (zoff >= 0) Z = (Wb-Wa).x at column zoff; idx int64
+ * [B,k,G] (KNN transpose_mode=False layout; NULL: no gather, k must be 1).  out[b*G+g, ooff + c] =
+ * max_j LeakyReLU(GroupNorm_groups(Y[b, idx[b,j,g], c] + Z[b,g,c])).  stats: scratch [2*B*groups]. */
+int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C,
+                              int groups, const float* gamma, const float* beta, float eps, float slope, float* stats,
+                              float* out, int ldo, int ooff, act_stream_t stream);
+/* Tokenizer head: logits = LeakyReLU(GroupNorm(h [B*G, C])); index = argmax_c((logits + gumbel) / tau);
+ * out [B*G, D] = codebook[index]  (F.gumbel_softmax(hard=True) + einsum with the codebook, models/dvae.py:587-588).
+ * noise [B*G, C] (nullable: Philox4x32-10 keyed by seed); index_out / logits_out nullable. */
+int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int C, int groups, const float* gamma, const float* beta,
+                                    float eps, float slope, const float* noise, uint64_t seed, float tau,
+                                    const float* codebook, int D, float* stats, int64_t* index_out, float* out,
+                                    float* logits_out, act_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -233,3 +233,89 @@ def test_cosine_loss(K):
     sd = s.double().requires_grad_(True)
     (3.0 * (1 - torch.nn.functional.cosine_similarity(sd, t.double(), dim=-1, eps=1e-8)).mean()).backward()
     assert _rel(sg.grad, sd.grad) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------- mini-PointNet / DGCNN glue kernels
+@pytest.mark.parametrize("R,C", [(4096, 128), (32 * 77, 512), (640, 64)])
+def test_batchnorm_relu_fwd_bwd(K, R, C):
+    x = _rnd(f"bn.x{R}", R, C) * 1.5 + 0.7; dy = _rnd(f"bn.dy{R}", R, C)
+    bn_ref = torch.nn.BatchNorm1d(C).double(); bn = torch.nn.BatchNorm1d(C).cuda()
+    with torch.no_grad():
+        w = 1 + 0.2 * _rnd(f"bn.w{C}", C); b = 0.1 * _rnd(f"bn.b{C}", C)
+        bn_ref.weight.copy_(w); bn_ref.bias.copy_(b); bn.weight.copy_(w); bn.bias.copy_(b)
+    xd = x.double().requires_grad_(True)
+    yr = torch.relu(bn_ref(xd)); (yr * dy.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = K.batch_norm_act(xg, bn, True, relu=True); (y * dy.cuda()).sum().backward()
+    assert _rel(y, yr) <= 2e-5 and _rel(xg.grad, xd.grad) <= 5e-5
+    assert _rel(bn.weight.grad, bn_ref.weight.grad) <= 5e-5 and _rel(bn.bias.grad, bn_ref.bias.grad) <= 5e-5
+    assert _rel(bn.running_mean, bn_ref.running_mean) <= 1e-5 and _rel(bn.running_var, bn_ref.running_var) <= 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    bn.eval(); bn_ref.eval()
+    assert _rel(K.batch_norm_act(x.cuda(), bn, False, relu=False), bn_ref(x.double())) <= 2e-5
+
+
+def test_group_max_and_group_add(K):
+    G, n, C = 50, 32, 256
+    x = _rnd("gm.x", G * n, C); dy = _rnd("gm.dy", G, C)
+    x[0:n, 3] = 1.25                                            # exact tie inside a group -> first row wins (torch.max)
+    xd = x.double().requires_grad_(True)
+    ref = xd.view(G, n, C).max(dim=1)[0]; (ref * dy.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    out = K.group_max(xg, n); (out * dy.cuda()).sum().backward()
+    assert _rel(out, ref) == 0 and _rel(xg.grad, xd.grad) <= 1e-6
+    # y = x w^T + g[row // n]
+    w = _rnd("ga.w", 96, C) * 0.1; g = _rnd("ga.g", G, 96); d2 = _rnd("ga.d", G * n, 96)
+    ts = [t.double().requires_grad_(True) for t in (x, w, g)]
+    r2 = (ts[0] @ ts[1].t()).view(G, n, 96) + ts[2].unsqueeze(1); (r2.reshape(G * n, 96) * d2.double()).sum().backward()
+    tg = [t.cuda().requires_grad_(True) for t in (x, w, g)]
+    y2 = K.linear_group_add(tg[0], tg[1], tg[2], n); (y2 * d2.cuda()).sum().backward()
+    assert _rel(y2, r2.reshape(G * n, 96)) <= 2e-5
+    for a, b in zip(tg, ts):
+        assert _rel(a.grad, b.grad) <= 5e-5
+
+
+def test_dgcnn_edge_tail_and_head(K):
+    import torch.nn.functional as F
+    B, G, k, C = 3, 64, 4, 256
+    yz = _rnd("eg.yz", B * G, 2 * C); gn = torch.nn.GroupNorm(4, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(_rnd("eg.w", C)); gn.bias.copy_(0.1 * _rnd("eg.b", C))     # negative gammas exercise the min branch
+    idx = torch.stack([torch.stack([torch.randperm(G, generator=torch.Generator().manual_seed(b * 10 + j)) for j in range(k)]) for b in range(B)])
+    y = yz[:, :C].reshape(B, G, C).double(); z = yz[:, C:].reshape(B, 1, G, C).double()
+    pre = (y[torch.arange(B).view(B, 1, 1), idx] + z).permute(0, 3, 2, 1)
+    ref = F.leaky_relu(F.group_norm(pre, 4, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps), 0.2).max(dim=-1)[0]
+    ref = ref.transpose(1, 2).reshape(B * G, C)
+    buf = torch.zeros(B * G, C + 40, device="cuda")
+    out = K.edge_gn_lrelu_max(yz.cuda(), C, idx.cuda(), B, G, k, C, gn, out=buf, ooff=40)
+    assert _rel(out[:, 40:], ref) <= 2e-5 and (out[:, :40] == 0).all()
+    # head: GroupNorm + LeakyReLU only
+    h = _rnd("eg.h", B * G, C) * 2 + 0.3
+    href = F.leaky_relu(F.group_norm(h.double().view(B, G, C).transpose(1, 2), 4, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps), 0.2)
+    assert _rel(K.edge_gn_lrelu_max(h.cuda(), -1, None, B, G, 1, C, gn), href.transpose(1, 2).reshape(B * G, C)) <= 2e-5
+
+
+def test_gumbel_argmax_codebook_fused(K):
+    import torch.nn.functional as F
+    B, G, C, D = 4, 16, 512, 48
+    h = _rnd("gu.h", B * G, C); cb = _rnd("gu.cb", C, D); gn = torch.nn.GroupNorm(4, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(1 + 0.3 * _rnd("gu.w", C)); gn.bias.copy_(0.1 * _rnd("gu.b", C))
+    torch.manual_seed(5)
+    noise = -torch.empty(B, G, C).exponential_().log()
+    logits = F.leaky_relu(F.group_norm(h.view(B, G, C).transpose(1, 2), 4, gn.weight.cpu(), gn.bias.cpu(), gn.eps), 0.2).transpose(1, 2)
+    ref_idx = (logits + noise).argmax(-1)
+    out, idx, lg = K.gn_gumbel_argmax_gather(h.cuda(), B, G, gn, cb.cuda(), noise=noise.cuda(), want_logits=True)
+    assert _rel(lg, logits) <= 2e-5
+    assert torch.equal(idx.cpu(), ref_idx) and torch.equal(out.cpu(), cb[ref_idx])
+    # device RNG path: deterministic per seed, different across seeds, roughly gumbel-distributed choices
+    o1, i1, _ = K.gn_gumbel_argmax_gather(h.cuda(), B, G, gn, cb.cuda(), seed=123)
+    o2, i2, _ = K.gn_gumbel_argmax_gather(h.cuda(), B, G, gn, cb.cuda(), seed=123)
+    o3, i3, _ = K.gn_gumbel_argmax_gather(h.cuda(), B, G, gn, cb.cuda(), seed=124)
+    assert torch.equal(i1, i2) and not torch.equal(i1, i3)
+    flat = torch.zeros(1, C, device="cuda"); gn1 = torch.nn.GroupNorm(4, C).cuda()
+    counts = torch.zeros(C)
+    big = torch.zeros(4096, C, device="cuda")                      # equal logits -> argmax of pure gumbel noise is uniform
+    _, ib, _ = K.gn_gumbel_argmax_gather(big, 64, 64, gn1, cb.cuda(), seed=7)
+    counts = torch.bincount(ib.flatten().cpu(), minlength=C).float()
+    assert counts.max() <= 30 and (counts > 0).sum() >= 0.95 * C           # mean 8 per bin
