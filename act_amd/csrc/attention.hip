@@ -16,30 +16,45 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int HD, int JT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                       float* __restrict__ lse, int B, int S, int H, float scale) {
+// General operand description: queries come from `q` (Sq rows per cloud), keys/values from up to two row segments
+// (segment 0: S0 rows, e.g. the prompt tokens of the teacher; segment 1: S1 rows).  Packed qkv is the special case
+// S0 = 0, k1 = qkv + H*hd, v1 = qkv + 2*H*hd.  All pointers address head 0; head h adds h*HD.
+struct AttnFwdArgs {
+    const float* q; const float* k0; const float* v0; const float* k1; const float* v1;
+    long long q_bs, kv0_bs, kv1_bs;      // per-cloud strides (floats)
+    int ldq, ld0, ld1;                   // row strides (floats)
+    int B, H, Sq, S0, S1;
+    float scale;
+    float* out; float* lse;              // out [B, Sq, H*HD]; lse [B, H, Sq] or null
+};
+
+template <int HD, int JT, int QT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
     constexpr int LDK = HD + 4;
-    constexpr int PAIRS = (JT == 1) ? 4 : (JT == 2 ? 2 : 1);       // (cloud, head) pairs per workgroup
+    constexpr int PAIRS = (QT == 1) ? 4 : (QT == 2 ? 2 : 1);       // (cloud, head) pairs per workgroup
     constexpr int ROWS = JT * 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];    // [PAIRS][2][ROWS][LDK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long npairs = (long long)B * H;
+    const int H = a.H, Sk = a.S0 + a.S1;
+    const long long npairs = (long long)a.B * H;
     const long long pair0 = (long long)blockIdx.x * PAIRS;
-    const int rs = 3 * H * HD;                                      // qkv row stride (floats)
 
-    // ---- stage K and V of every pair of this workgroup (zero rows beyond S)
+    // ---- stage K and V of every pair of this workgroup (zero rows beyond Sk)
     for (int idx = tid; idx < PAIRS * ROWS * (HD / 4); idx += 256) {
         const int c4 = idx % (HD / 4);
         const int row = (idx / (HD / 4)) % ROWS;
         const int pl = idx / ((HD / 4) * ROWS);
         const long long pr = pair0 + pl;
         float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
-        if (pr < npairs && row < S) {
+        if (pr < npairs && row < Sk) {
             const int b = (int)(pr / H), h = (int)(pr % H);
-            const float* base = qkv + ((size_t)b * S + row) * rs + h * HD + c4 * 4;
-            kx = *reinterpret_cast<const float4*>(base + H * HD);
-            vx = *reinterpret_cast<const float4*>(base + 2 * H * HD);
+            if (row < a.S0) {
+                const size_t o = (size_t)b * a.kv0_bs + (size_t)row * a.ld0 + h * HD + c4 * 4;
+                kx = *reinterpret_cast<const float4*>(a.k0 + o); vx = *reinterpret_cast<const float4*>(a.v0 + o);
+            } else {
+                const size_t o = (size_t)b * a.kv1_bs + (size_t)(row - a.S0) * a.ld1 + h * HD + c4 * 4;
+                kx = *reinterpret_cast<const float4*>(a.k1 + o); vx = *reinterpret_cast<const float4*>(a.v1 + o);
+            }
         }
         float* ks = smem + ((size_t)(pl * 2 + 0) * ROWS + row) * LDK + c4 * 4;
         float* vs = smem + ((size_t)(pl * 2 + 1) * ROWS + row) * LDK + c4 * 4;
@@ -48,23 +63,24 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
     __syncthreads();
 
-    const int pl = wave / JT, qt = wave % JT;
+    const int pl = wave / QT, qt = wave % QT;
     const long long pr = pair0 + pl;
-    if (pl >= PAIRS || pr >= npairs || qt * 32 >= S) return;        // idle wave (no further barriers below)
+    if (pl >= PAIRS || pr >= npairs || qt * 32 >= a.Sq) return;     // idle wave (no further barriers below)
     const int b = (int)(pr / H), h = (int)(pr % H);
     const float* Ks = smem + (size_t)(pl * 2 + 0) * ROWS * LDK;
     const float* Vs = smem + (size_t)(pl * 2 + 1) * ROWS * LDK;
     const int ql = lane & 31, half = lane >> 5;
     const int q = qt * 32 + ql;
+    const float scale = a.scale;
 
     // ---- Q operand: lane (q, half) holds Q[q][half*HD/2 + s], s = 0..HD/2-1
     float qreg[HD / 2];
     {
-        const float* qp = qkv + ((size_t)b * S + min(q, S - 1)) * rs + h * HD + half * (HD / 2);
+        const float* qp = a.q + (size_t)b * a.q_bs + (size_t)min(q, a.Sq - 1) * a.ldq + h * HD + half * (HD / 2);
 #pragma unroll
         for (int s4 = 0; s4 < HD / 8; ++s4) {
             float4 t = *reinterpret_cast<const float4*>(qp + s4 * 4);
-            if (q >= S) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q >= a.Sq) t = make_float4(0.f, 0.f, 0.f, 0.f);
             qreg[s4 * 4 + 0] = t.x; qreg[s4 * 4 + 1] = t.y; qreg[s4 * 4 + 2] = t.z; qreg[s4 * 4 + 3] = t.w;
         }
     }
@@ -77,11 +93,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         const float* kp = Ks + (size_t)(jt * 32 + ql) * LDK + half * (HD / 2);
 #pragma unroll
         for (int s4 = 0; s4 < HD / 8; ++s4) {
-            const float4 a = *reinterpret_cast<const float4*>(kp + s4 * 4);
-            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[s4 * 4 + 0], acc[jt], 0, 0, 0);
-            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[s4 * 4 + 1], acc[jt], 0, 0, 0);
-            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[s4 * 4 + 2], acc[jt], 0, 0, 0);
-            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[s4 * 4 + 3], acc[jt], 0, 0, 0);
+            const float4 kk = *reinterpret_cast<const float4*>(kp + s4 * 4);
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[s4 * 4 + 0], acc[jt], 0, 0, 0);
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[s4 * 4 + 1], acc[jt], 0, 0, 0);
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[s4 * 4 + 2], acc[jt], 0, 0, 0);
+            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[s4 * 4 + 3], acc[jt], 0, 0, 0);
         }
     }
     // ---- softmax over keys (registers + one lane^32 exchange)
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v = key < S ? acc[jt][r] : -3.0e38f;
+            const float v = key < Sk ? acc[jt][r] : -3.0e38f;
             acc[jt][r] = v;
             m = fmaxf(m, v);
         }
@@ -123,8 +139,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
             for (int dt = 0; dt < HD / 32; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], acc[jt][r], o[dt], 0, 0, 0);
         }
-    if (q < S) {
-        float* op = out + ((size_t)b * S + q) * (H * HD) + h * HD;
+    if (q < a.Sq) {
+        float* op = a.out + ((size_t)b * a.Sq + q) * (H * HD) + h * HD;
 #pragma unroll
         for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
                 t.z = o[dt][g * 4 + 2] * inv_l; t.w = o[dt][g * 4 + 3] * inv_l;
                 *reinterpret_cast<float4*>(op + dt * 32 + 8 * g + 4 * half) = t;
             }
-        if (lse && half == 0) lse[((size_t)b * H + h) * S + q] = scale * m + __logf(l);
+        if (a.lse && half == 0) a.lse[((size_t)b * H + h) * a.Sq + q] = scale * m + __logf(l);
     }
 }
 
@@ -291,20 +307,28 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
 }
 
-template <int HD>
-static int launch_attn_fwd(const float* qkv, float* out, float* lse, int B, int S, int H, float scale, hipStream_t s) {
-    const int JT = (S + 31) / 32;
-    const int pairs = JT == 1 ? 4 : (JT == 2 ? 2 : 1);
+template <int HD, int JT, int QT>
+static int launch_attn_fwd3(const AttnFwdArgs& a, hipStream_t s) {
+    constexpr int pairs = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
     const size_t smem = (size_t)pairs * 2 * JT * 32 * (HD + 4) * sizeof(float);
-    const long long np = (long long)B * H;
+    const long long np = (long long)a.B * a.H;
     const unsigned grid = (unsigned)((np + pairs - 1) / pairs);
-#define FWD(J) { auto k = attn_fwd_kernel<HD, J>; \
-        if (smem > 48 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; } \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, qkv, out, lse, B, S, H, scale); }
-    switch (JT) { case 1: FWD(1) break; case 2: FWD(2) break; case 3: FWD(3) break; case 4: FWD(4) break; default: return ACT_E_BADARG; }
-#undef FWD
+    auto k = attn_fwd_kernel<HD, JT, QT>;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, a);
     ACT_LAUNCH_CHECK();
     return 0;
+}
+template <int HD>
+static int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t s) {
+    const int JT = (a.S0 + a.S1 + 31) / 32, QT = (a.Sq + 31) / 32;
+#define C3(J, Q) if (JT == J && QT == Q) return launch_attn_fwd3<HD, J, Q>(a, s)
+    C3(1, 1); C3(2, 1); C3(2, 2); C3(3, 1); C3(3, 2); C3(3, 3); C3(4, 1); C3(4, 2); C3(4, 3); C3(4, 4);
+#undef C3
+    return ACT_E_BADARG;
 }
 
 extern "C" int act_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int S, int H, int head_dim, float scale,
@@ -314,7 +338,30 @@ extern "C" int act_attention_fwd_f32(const float* qkv, float* out, float* lse, i
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_ATTN_FWD, s, 4.0 * B * H * (double)S * S * head_dim, 16.0 * B * S * (double)H * head_dim);
-    return head_dim == 64 ? launch_attn_fwd<64>(qkv, out, lse, B, S, H, scale, s) : launch_attn_fwd<32>(qkv, out, lse, B, S, H, scale, s);
+    const int D = H * head_dim;
+    AttnFwdArgs a;
+    a.q = qkv; a.k0 = nullptr; a.v0 = nullptr; a.k1 = qkv + D; a.v1 = qkv + 2 * D;
+    a.q_bs = (long long)S * 3 * D; a.kv0_bs = 0; a.kv1_bs = a.q_bs; a.ldq = 3 * D; a.ld0 = 0; a.ld1 = 3 * D;
+    a.B = B; a.H = H; a.Sq = S; a.S0 = 0; a.S1 = S; a.scale = scale; a.out = out; a.lse = lse;
+    return head_dim == 64 ? launch_attn_fwd<64>(a, s) : launch_attn_fwd<32>(a, s);
+}
+
+// queries: the Sq rows of qkv1 [B,Sq,3,H,hd]; keys/values: S0 rows of kv0 [B,S0,2,H,hd] followed by the Sq rows of qkv1.
+// (teacher ViT of models/dvae.py:536-576: prompt tokens only ever act as keys/values -- their outputs are replaced by the
+//  next layer's prompts -- so queries, projection and MLP are evaluated for the patch tokens only.)
+extern "C" int act_attention_fwd_prefix_f32(const float* kv0, int S0, const float* qkv1, int Sq, float* out, float* lse, int B,
+                                            int H, int head_dim, float scale, act_stream_t stream) {
+    if (!kv0 || !qkv1 || !out) return ACT_E_NULLPTR;
+    if (B < 0 || Sq <= 0 || S0 < 0 || H <= 0 || S0 + Sq > 128 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_ATTN_FWD, s, 4.0 * B * H * (double)Sq * (S0 + Sq) * head_dim, 4.0 * B * (double)H * head_dim * (4.0 * Sq + 2.0 * S0));
+    const int D = H * head_dim;
+    AttnFwdArgs a;
+    a.q = qkv1; a.k0 = kv0; a.v0 = kv0 + D; a.k1 = qkv1 + D; a.v1 = qkv1 + 2 * D;
+    a.q_bs = (long long)Sq * 3 * D; a.kv0_bs = (long long)S0 * 2 * D; a.kv1_bs = a.q_bs; a.ldq = 3 * D; a.ld0 = 2 * D; a.ld1 = 3 * D;
+    a.B = B; a.H = H; a.Sq = Sq; a.S0 = S0; a.S1 = Sq; a.scale = scale; a.out = out; a.lse = lse;
+    return head_dim == 64 ? launch_attn_fwd<64>(a, s) : launch_attn_fwd<32>(a, s);
 }
 
 extern "C" int act_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,

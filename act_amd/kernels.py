@@ -480,3 +480,35 @@ def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, 
                                               ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF, float(tau), ptr(_f32c(codebook)), D, ptr(stats),
                                               ptr(index), ptr(out), ptr(logits), stream()), "act_gn_gumbel_argmax_gather_f32")
     return out, index, logits
+
+
+_C._declare({"act_attention_fwd_prefix_f32": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]})
+_C.lib.act_layernorm_bwd_workspace.restype = _sz
+_C.lib.act_colsum_workspace.restype = _sz
+_C.lib.act_colstats_workspace.restype = _sz
+_C.SIGNATURES.setdefault("act_attention_fwd_prefix_f32", _C.lib.act_attention_fwd_prefix_f32.argtypes)
+
+
+def attention_fwd_prefix(kv0, S0, qkv1, Sq, B, H, hd):
+    """queries = the Sq rows of qkv1 [B*Sq, 3*H*hd]; keys/values = S0 rows of kv0 [B*S0, 2*H*hd] then the rows of qkv1."""
+    out = torch.empty(B * Sq, H * hd, dtype=torch.float32, device=qkv1.device)
+    check(lib.act_attention_fwd_prefix_f32(ptr(_f32c(kv0)), S0, ptr(_f32c(qkv1)), Sq, ptr(out), None, B, H, hd, float(hd) ** -0.5,
+                                           stream()), "act_attention_fwd_prefix_f32")
+    return out
+
+
+def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps):
+    """Inference-only pre-LN block on G 'patch' tokens per cloud with P extra 'prompt' tokens that act as keys/values only
+    (their outputs are discarded by the caller): x2d [B*G, D] (+ pos2d), prm2d [B*P, D] = prompt + prompt_pos.
+    Exactly the patch-token rows of  blk(cat(prompt, x) + cat(prompt_pos, pos))  of models/dvae.py:549-571."""
+    D = x2d.shape[1]
+    hd = D // heads
+    n1p, _, _, _ = layernorm_fwd(prm2d, None, n1w, n1b, eps, want_stats=False)
+    kvp = gemm(n1p, wqkv[D:], True, True, bias=(bqkv[D:] if bqkv is not None else None))          # K,V of the prompts
+    n1x, xin, _, _ = layernorm_fwd(x2d, pos2d, n1w, n1b, eps, want_stats=False)
+    qkvx = gemm(n1x, wqkv, True, True, bias=bqkv)
+    att = attention_fwd_prefix(kvp, P, qkvx, G, B, heads, hd)
+    x1 = gemm(att, wproj, True, True, bias=bproj, res=xin)
+    n2, _, _, _ = layernorm_fwd(x1, None, n2w, n2b, eps, want_stats=False)
+    a = gemm(n2, w1, True, True, bias=b1, act=EPI_GELU)
+    return gemm(a, w2, True, True, bias=b2, res=x1)

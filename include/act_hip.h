@@ -116,6 +116,10 @@ int act_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumu
  * forward: S <= 128, hd in {32,64}.  backward (recomputes P from lse): S4*(4*(hd+4)+S4+6)*4 bytes of LDS <= 160 KiB. */
 int act_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int S, int H, int head_dim, float scale,
                           act_stream_t stream);
+/* prefix variant: keys/values = S0 rows of kv0 [B,S0,2,H,hd] followed by the Sq rows of qkv1 [B,Sq,3,H,hd]; queries = qkv1.
+ * Used for the prompt-tuned teacher (models/dvae.py:536-576): prompt tokens are keys/values only.  S0 + Sq <= 128. */
+int act_attention_fwd_prefix_f32(const float* kv0, int S0, const float* qkv1, int Sq, float* out, float* lse, int B,
+                                 int H, int head_dim, float scale, act_stream_t stream);
 int act_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                           int B, int S, int H, int head_dim, float scale, act_stream_t stream);
 

@@ -319,3 +319,27 @@ def test_gumbel_argmax_codebook_fused(K):
     _, ib, _ = K.gn_gumbel_argmax_gather(big, 64, 64, gn1, cb.cuda(), seed=7)
     counts = torch.bincount(ib.flatten().cpu(), minlength=C).float()
     assert counts.max() <= 30 and (counts > 0).sum() >= 0.95 * C           # mean 8 per bin
+
+
+def test_attention_prefix_and_teacher_block_prefix(K):
+    """prompt tokens as keys/values only == the patch-token rows of the full block on cat(prompt, x)."""
+    from oracle import layers as L
+    B, P, G, D, H = 3, 64, 64, 128, 2
+    blk = fill_module(L.Block(D, H, qkv_bias=True, eps=1e-6), "pfx.")
+    x = _rnd("pf.x", B, G, D); pos = _rnd("pf.p", B, G, D) * 0.2; prm = _rnd("pf.m", B, P, D) * 0.3; ppos = _rnd("pf.q", 1, P, D) * 0.2
+    full = blk(torch.cat((prm, x), 1) + torch.cat((ppos.expand(B, -1, -1), pos), 1), L.Draws())[:, P:]
+    p = _load_block(blk)
+    names = ["n1w", "n1b", "wqkv", "bqkv", "wproj", "bproj", "n2w", "n2b", "w1", "b1", "w2", "b2"]
+    with torch.no_grad():
+        y = K.block_forward_prefix(x.cuda().reshape(B * G, D), pos.cuda().reshape(B * G, D), (prm + ppos).cuda().reshape(B * P, D),
+                                   B, P, G, *[p[n] for n in names], H, 1e-6)
+    assert _rel(y.reshape(B, G, D), full) <= TOL
+    # raw kernel, odd sizes: S0=20 prompts, Sq=33 queries, hd=64
+    B, S0, Sq, H, hd = 2, 20, 33, 3, 64
+    kv0 = _rnd("pf.kv", B * S0, 2 * H * hd); qkv = _rnd("pf.qkv", B * Sq, 3 * H * hd)
+    out = K.attention_fwd_prefix(kv0.cuda(), S0, qkv.cuda(), Sq, B, H, hd)
+    q, k1, v1 = qkv.double().view(B, Sq, 3, H, hd).permute(2, 0, 3, 1, 4)
+    k0, v0 = kv0.double().view(B, S0, 2, H, hd).permute(2, 0, 3, 1, 4)
+    kk = torch.cat((k0, k1), 2); vv = torch.cat((v0, v1), 2)
+    ref = (torch.softmax(q @ kk.transpose(-2, -1) * hd ** -0.5, -1) @ vv).transpose(1, 2).reshape(B * Sq, H * hd)
+    assert _rel(out, ref) <= 2e-5
