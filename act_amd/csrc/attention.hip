@@ -155,154 +155,204 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------- backward (VALU, LDS resident)
-// thread micro-tile helper: rows {ri + u*RS}, cols {ci + v*CS}
+// One workgroup per (cloud, head).  K and V stay in LDS; queries are processed in chunks of 64 rows (Q, dO, P chunk in
+// LDS); every thread owns fixed 4x4 micro-tiles of dK and dV and accumulates them across chunks in registers.
+// micro-tile convention: rows {ri + u*RS}, cols {ci + v*CS} with RS/CS = extent/4 (bank-conflict-free strides).
+#define ATT_QC 64
+#define ATT_KT 3            // max dK/dV micro-tiles per thread: (S4/4)*(HD/4) <= 256*ATT_KT
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                        const float* __restrict__ dout, const float* __restrict__ lse,
                                                        float* __restrict__ dqkv, int B, int S, int H, float scale) {
     constexpr int LD = HD + 4;
+    constexpr int QC = ATT_QC, RQ = QC / 4, DQ = HD / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int S4 = (S + 3) & ~3;                       // padded sequence (zero rows)
     const int LDP = S4 + 4;
-    float* Qs = smem;                                   // [S4][LD]
-    float* Ks = Qs + (size_t)S4 * LD;
+    const int rk = S4 / 4;                              // key-side micro-tile stride
+    float* Ks = smem;                                   // [S4][LD]
     float* Vs = Ks + (size_t)S4 * LD;
-    float* Os = Vs + (size_t)S4 * LD;                   // dO
-    float* Ps = Os + (size_t)S4 * LD;                   // [S4][LDP]  P then dS
-    float* Dl = Ps + (size_t)S4 * LDP;                  // [S4] D[q], then [S4] lse
-    float* Ll = Dl + S4;
+    float* Qs = Vs + (size_t)S4 * LD;                   // [QC][LD]
+    float* Os = Qs + (size_t)QC * LD;                   // [QC][LD]  dO chunk
+    float* Ps = Os + (size_t)QC * LD;                   // [QC][LDP] P then dS
+    float* Dl = Ps + (size_t)QC * LDP;                  // [QC] D[q]
+    float* Ll = Dl + QC;                                // [QC] lse
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int rs = 3 * H * HD;
-    const int rq = S4 / 4;                              // micro-tile strides
+    const int rs = 3 * H * HD, ro = H * HD;
+    float* dq_base = dqkv + (size_t)b * S * rs + h * HD;
 
-    for (int idx = tid; idx < S4 * (HD / 4); idx += 256) {
-        const int c4 = idx % (HD / 4), row = idx / (HD / 4);
-        float4 qx = make_float4(0.f, 0.f, 0.f, 0.f), kx = qx, vx = qx, ox = qx;
+    for (int idx = tid; idx < S4 * DQ; idx += 256) {
+        const int c4 = idx % DQ, row = idx / DQ;
+        float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
         if (row < S) {
             const float* base = qkv + ((size_t)b * S + row) * rs + h * HD + c4 * 4;
-            qx = *reinterpret_cast<const float4*>(base);
             kx = *reinterpret_cast<const float4*>(base + H * HD);
             vx = *reinterpret_cast<const float4*>(base + 2 * H * HD);
-            ox = *reinterpret_cast<const float4*>(dout + ((size_t)b * S + row) * (H * HD) + h * HD + c4 * 4);
         }
-        *reinterpret_cast<float4*>(Qs + (size_t)row * LD + c4 * 4) = qx;
         *reinterpret_cast<float4*>(Ks + (size_t)row * LD + c4 * 4) = kx;
         *reinterpret_cast<float4*>(Vs + (size_t)row * LD + c4 * 4) = vx;
-        *reinterpret_cast<float4*>(Os + (size_t)row * LD + c4 * 4) = ox;
     }
-    // D[q] = sum_d dO[q][d] * O[q][d]   (one wave per row)
-    for (int row = wave; row < S4; row += 4) {
-        float acc = 0.f;
-        if (row < S)
-            for (int d = lane; d < HD; d += 64)
-                acc += dout[((size_t)b * S + row) * (H * HD) + h * HD + d] * out[((size_t)b * S + row) * (H * HD) + h * HD + d];
-        acc = wave_sum_f32(acc);
-        if (lane == 0) { Dl[row] = acc; Ll[row] = row < S ? lse[((size_t)b * H + h) * S + row] : 0.f; }
-    }
-    __syncthreads();
+    float dk[ATT_KT][4][4], dv[ATT_KT][4][4];
+#pragma unroll
+    for (int t = 0; t < ATT_KT; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { dk[t][u][v] = 0.f; dv[t][u][v] = 0.f; }
+    const int nkt = rk * DQ;                            // dK / dV micro-tiles
 
-    // ---- P[q][k] = exp(scale * q.k - lse[q])
-    for (int mt = tid; mt < rq * rq; mt += 256) {
-        const int ki = mt % rq, qi = mt / rq;
-        float acc[4][4] = {};
-        for (int d = 0; d < HD; d += 4) {
-            float4 a[4], bb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Qs + (size_t)(qi + u * rq) * LD + d);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Ks + (size_t)(ki + v * rq) * LD + d);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int qq = qi + u * rq, kk = ki + v * rq;
-                Ps[(size_t)qq * LDP + kk] = (qq < S && kk < S) ? __expf(scale * acc[u][v] - Ll[qq]) : 0.f;
+    for (int q0 = 0; q0 < S; q0 += QC) {
+        const int qn = min(QC, S - q0);                 // valid rows in this chunk
+        __syncthreads();                                // previous chunk fully consumed (and K/V staged)
+        for (int idx = tid; idx < QC * DQ; idx += 256) {
+            const int c4 = idx % DQ, row = idx / DQ;
+            float4 qx = make_float4(0.f, 0.f, 0.f, 0.f), ox = qx;
+            if (row < qn) {
+                qx = *reinterpret_cast<const float4*>(qkv + ((size_t)b * S + q0 + row) * rs + h * HD + c4 * 4);
+                ox = *reinterpret_cast<const float4*>(dout + ((size_t)b * S + q0 + row) * ro + h * HD + c4 * 4);
             }
-    }
-    __syncthreads();
-    float* dq_base = dqkv + (size_t)b * S * rs + h * HD;
-    // ---- dV[k][d] = sum_q P[q][k] dO[q][d]
-    for (int mt = tid; mt < rq * (HD / 4); mt += 256) {
-        const int di = mt % (HD / 4), ki = mt / (HD / 4);
-        float acc[4][4] = {};
-        for (int qq = 0; qq < S; ++qq) {
-            float p[4], g[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) p[u] = Ps[(size_t)qq * LDP + ki + u * rq];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) g[v] = Os[(size_t)qq * LD + di + v * (HD / 4)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += p[u] * g[v];
+            *reinterpret_cast<float4*>(Qs + (size_t)row * LD + c4 * 4) = qx;
+            *reinterpret_cast<float4*>(Os + (size_t)row * LD + c4 * 4) = ox;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kk = ki + u * rq;
-            if (kk < S)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) dq_base[(size_t)kk * rs + 2 * H * HD + di + v * (HD / 4)] = acc[u][v];
+        for (int row = wave; row < QC; row += 4) {      // D[q] = sum_d dO[q][d] * O[q][d]
+            float acc = 0.f;
+            if (row < qn)
+                for (int d = lane; d < HD; d += 64)
+                    acc += dout[((size_t)b * S + q0 + row) * ro + h * HD + d] * out[((size_t)b * S + q0 + row) * ro + h * HD + d];
+            acc = wave_sum_f32(acc);
+            if (lane == 0) { Dl[row] = acc; Ll[row] = row < qn ? lse[((size_t)b * H + h) * S + q0 + row] : 0.f; }
         }
-    }
-    __syncthreads();
-    // ---- dS = P * (dP - D) * scale, dP[q][k] = sum_d dO[q][d] V[k][d]   (in place over P)
-    for (int mt = tid; mt < rq * rq; mt += 256) {
-        const int ki = mt % rq, qi = mt / rq;
-        float acc[4][4] = {};
-        for (int d = 0; d < HD; d += 4) {
-            float4 a[4], bb[4];
+        __syncthreads();
+        // ---- P[q][k] = exp(scale * q.k - lse[q])
+        for (int mt = tid; mt < RQ * rk; mt += 256) {
+            const int ki = mt % rk, qi = mt / rk;
+            float acc[4][4] = {};
+            for (int d = 0; d < HD; d += 4) {
+                float4 a[4], bb[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Os + (size_t)(qi + u * rq) * LD + d);
+                for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Qs + (size_t)(qi + u * RQ) * LD + d);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Vs + (size_t)(ki + v * rq) * LD + d);
+                for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Ks + (size_t)(ki + v * rk) * LD + d);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int qq = qi + u * rq, kk = ki + v * rq;
-                const size_t o = (size_t)qq * LDP + kk;
-                Ps[o] = Ps[o] * (acc[u][v] - Dl[qq]) * scale;
+                    for (int v = 0; v < 4; ++v)
+                        acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
             }
-    }
-    __syncthreads();
-    // ---- dQ[q][d] = sum_k dS[q][k] K[k][d] ;  dK[k][d] = sum_q dS[q][k] Q[q][d]
-    for (int mt = tid; mt < 2 * rq * (HD / 4); mt += 256) {
-        const bool is_k = mt >= rq * (HD / 4);
-        const int m2 = is_k ? mt - rq * (HD / 4) : mt;
-        const int di = m2 % (HD / 4), ri = m2 / (HD / 4);
-        float acc[4][4] = {};
-        const float* X = is_k ? Qs : Ks;
-        for (int t = 0; t < S; ++t) {
-            float p[4], g[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                p[u] = is_k ? Ps[(size_t)t * LDP + ri + u * rq] : Ps[(size_t)(ri + u * rq) * LDP + t];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) g[v] = X[(size_t)t * LD + di + v * (HD / 4)];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += p[u] * g[v];
+                for (int v = 0; v < 4; ++v) {
+                    const int qq = qi + u * RQ, kk = ki + v * rk;
+                    Ps[(size_t)qq * LDP + kk] = (qq < qn && kk < S) ? __expf(scale * acc[u][v] - Ll[qq]) : 0.f;
+                }
         }
+        __syncthreads();
+        // ---- dV[k][d] += sum_q P[q][k] dO[q][d]
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int rr = ri + u * rq;
-            if (rr < S)
+        for (int t = 0; t < ATT_KT; ++t) {
+            const int mt = tid + 256 * t;
+            if (mt < nkt) {
+                const int di = mt % DQ, ki = mt / DQ;
+                for (int qq = 0; qq < qn; ++qq) {
+                    float pp[4], g[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) dq_base[(size_t)rr * rs + (is_k ? H * HD : 0) + di + v * (HD / 4)] = acc[u][v];
+                    for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)qq * LDP + ki + u * rk];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) g[v] = Os[(size_t)qq * LD + di + v * DQ];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) dv[t][u][v] += pp[u] * g[v];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dS = P * (dP - D) * scale, dP[q][k] = sum_d dO[q][d] V[k][d]   (in place over P)
+        for (int mt = tid; mt < RQ * rk; mt += 256) {
+            const int ki = mt % rk, qi = mt / rk;
+            float acc[4][4] = {};
+            for (int d = 0; d < HD; d += 4) {
+                float4 a[4], bb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Os + (size_t)(qi + u * RQ) * LD + d);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Vs + (size_t)(ki + v * rk) * LD + d);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int qq = qi + u * RQ, kk = ki + v * rk;
+                    const size_t o = (size_t)qq * LDP + kk;
+                    Ps[o] = Ps[o] * (acc[u][v] - Dl[qq]) * scale;
+                }
+        }
+        __syncthreads();
+        // ---- dQ[q][d] = sum_k dS[q][k] K[k][d]   (rows of this chunk are complete: write out)
+        for (int mt = tid; mt < RQ * DQ; mt += 256) {
+            const int di = mt % DQ, qi = mt / DQ;
+            float acc[4][4] = {};
+            for (int kk = 0; kk < S; ++kk) {
+                float pp[4], g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)(qi + u * RQ) * LDP + kk];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) g[v] = Ks[(size_t)kk * LD + di + v * DQ];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] += pp[u] * g[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = qi + u * RQ;
+                if (qq < qn)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) dq_base[(size_t)(q0 + qq) * rs + di + v * DQ] = acc[u][v];
+            }
+        }
+        // ---- dK[k][d] += sum_q dS[q][k] Q[q][d]
+#pragma unroll
+        for (int t = 0; t < ATT_KT; ++t) {
+            const int mt = tid + 256 * t;
+            if (mt < nkt) {
+                const int di = mt % DQ, ki = mt / DQ;
+                for (int qq = 0; qq < qn; ++qq) {
+                    float pp[4], g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)qq * LDP + ki + u * rk];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) g[v] = Qs[(size_t)qq * LD + di + v * DQ];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) dk[t][u][v] += pp[u] * g[v];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < ATT_KT; ++t) {
+        const int mt = tid + 256 * t;
+        if (mt < nkt) {
+            const int di = mt % DQ, ki = mt / DQ;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int kk = ki + u * rk;
+                if (kk < S)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        dq_base[(size_t)kk * rs + H * HD + di + v * DQ] = dk[t][u][v];
+                        dq_base[(size_t)kk * rs + 2 * H * HD + di + v * DQ] = dv[t][u][v];
+                    }
+            }
         }
     }
 }
@@ -370,8 +420,8 @@ extern "C" int act_attention_bwd_f32(const float* qkv, const float* out, const f
     if (B < 0 || S <= 0 || H <= 0 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
     if (B == 0) return 0;
     const int S4 = (S + 3) & ~3;
-    const size_t smem = ((size_t)4 * S4 * (head_dim + 4) + (size_t)S4 * (S4 + 4) + 2 * S4) * sizeof(float);
-    if (smem > 160 * 1024) return ACT_E_BADARG;
+    const size_t smem = ((size_t)2 * S4 * (head_dim + 4) + (size_t)2 * ATT_QC * (head_dim + 4) + (size_t)ATT_QC * (S4 + 4) + 2 * ATT_QC) * sizeof(float);
+    if (smem > 160 * 1024 || (S4 / 4) * (head_dim / 4) > 256 * ATT_KT) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)S * S * head_dim, 28.0 * B * S * (double)H * head_dim);
 #define BWD(HD) { auto k = attn_bwd_kernel<HD>; \

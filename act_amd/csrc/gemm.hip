@@ -280,22 +280,27 @@ extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, co
     const bool vec = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && (lda & 3) == 0 &&
                      (ldb & 3) == 0 && (a_kmajor ? (K & 3) == 0 : (M & 3) == 0) && (b_kmajor ? (K & 3) == 0 : (N & 3) == 0);
 
-    // tile shape: fill the 256 CUs; prefer the big tile when it still gives >= 1 wave of workgroups
-    int BM = 128, BN = 128;
-    auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (tiles(128, 128) < 192) { BM = 64; BN = 64; if (tiles(128, 64) >= 256) { BM = 128; BN = 64; } }
+    // Tile shape + split-K from a small cost model: every workgroup keeps one wave per SIMD busy, so the time of a launch
+    // is ~ ceil(workgroups / 256 CUs) x (work per workgroup) / (efficiency of that tile shape); split-K (deterministic
+    // two-pass) is considered when the tile grid alone cannot fill the chip (weight gradients: K = tokens).
+    struct Cand { int bm, bn; double eff; };
+    const Cand cands[3] = {{128, 128, 1.00}, {128, 64, 0.93}, {64, 64, 0.82}};
+    int BM = 128, BN = 128, splits = 1; double best = 1e300;
+    for (const Cand& c : cands) {
+        const long long nb = (long long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+        int maxs = 1;
+        if (workspace && K >= 1024) { maxs = K / 512; if (maxs > 32) maxs = 32; if (maxs < 1) maxs = 1; }
+        for (int sp = 1; sp <= maxs; sp = (sp < 4 ? sp + 1 : sp * 2)) {
+            if (sp > 1 && (size_t)sp * M * N * sizeof(float) > workspace_bytes) break;
+            const double rounds = (double)((nb * sp + 255) / 256);
+            double cost = rounds * ((double)c.bm * c.bn * ((K + sp - 1) / sp + 32)) / c.eff;
+            if (sp > 1) cost += 2.0 * (double)M * N * sp / 256.0 * 8.0;      // partial write + reduce traffic (rough)
+            if (cost < best) { best = cost; BM = c.bm; BN = c.bn; splits = sp; }
+            if (nb * sp >= 1024) break;
+        }
+    }
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     const long long nt = (long long)p.tiles_m * p.tiles_n;
-
-    // split-K when the tile grid cannot fill the chip and K is long (weight gradients: K = tokens)
-    int splits = 1;
-    if (nt < 256 && K >= 1024 && workspace) {
-        splits = (int)((512 + nt - 1) / nt);
-        const int maxs = K / 256; if (splits > maxs) splits = maxs;
-        if (splits > 64) splits = 64;
-        while (splits > 1 && (size_t)splits * M * N * sizeof(float) > workspace_bytes) --splits;
-        if (splits < 1) splits = 1;
-    }
     const int BKsel = gemm_bk();
     int kps = K;
     if (splits > 1) { kps = (K + splits - 1) / splits; kps = (kps + 31) / 32 * 32; splits = (K + kps - 1) / kps; }

@@ -127,7 +127,8 @@ def test_attention_forward_large_logits(K):
     assert torch.isfinite(out).all() and _rel(out, _attn_ref(qkv, B, S, H, hd)) <= 5e-5
 
 
-@pytest.mark.parametrize("B,S,H,hd", [(3, 14, 6, 64), (2, 64, 6, 64), (4, 33, 2, 64), (2, 16, 2, 32), (2, 1, 1, 64)])
+@pytest.mark.parametrize("B,S,H,hd", [(3, 14, 6, 64), (2, 64, 6, 64), (4, 33, 2, 64), (2, 16, 2, 32), (2, 1, 1, 64), (2, 128, 3, 64),
+                                      (2, 100, 2, 64), (1, 103, 2, 64), (2, 128, 2, 32)])
 def test_attention_backward(K, B, S, H, hd):
     qkv = _rnd(f"ab{B}{S}{H}", B * S, 3 * H * hd); do = _rnd(f"abd{B}{S}{H}", B * S, H * hd)
     qd = qkv.double().requires_grad_(True)
