@@ -28,6 +28,9 @@ struct AttnFwdArgs {
     float* out; float* lse;              // out [B, Sq, H*HD]; lse [B, H, Sq] or null
 };
 
+// JT = 32-key tiles per LDS-resident key chunk (Sk <= 128: one chunk; longer sequences: chunks of 128 keys with an online
+// softmax -- running max m and sum l per query; the rescale of the output accumulators is a per-lane scalar because every
+// accumulator register of a lane belongs to the same query).  QT = 32-query tiles per (cloud, head) handled by a workgroup.
 template <int HD, int JT, int QT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
     constexpr int LDK = HD + 4;
@@ -38,44 +41,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
     const int H = a.H, Sk = a.S0 + a.S1;
     const long long npairs = (long long)a.B * H;
     const long long pair0 = (long long)blockIdx.x * PAIRS;
-
-    // ---- stage K and V of every pair of this workgroup (zero rows beyond Sk)
-    for (int idx = tid; idx < PAIRS * ROWS * (HD / 4); idx += 256) {
-        const int c4 = idx % (HD / 4);
-        const int row = (idx / (HD / 4)) % ROWS;
-        const int pl = idx / ((HD / 4) * ROWS);
-        const long long pr = pair0 + pl;
-        float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
-        if (pr < npairs && row < Sk) {
-            const int b = (int)(pr / H), h = (int)(pr % H);
-            if (row < a.S0) {
-                const size_t o = (size_t)b * a.kv0_bs + (size_t)row * a.ld0 + h * HD + c4 * 4;
-                kx = *reinterpret_cast<const float4*>(a.k0 + o); vx = *reinterpret_cast<const float4*>(a.v0 + o);
-            } else {
-                const size_t o = (size_t)b * a.kv1_bs + (size_t)(row - a.S0) * a.ld1 + h * HD + c4 * 4;
-                kx = *reinterpret_cast<const float4*>(a.k1 + o); vx = *reinterpret_cast<const float4*>(a.v1 + o);
-            }
-        }
-        float* ks = smem + ((size_t)(pl * 2 + 0) * ROWS + row) * LDK + c4 * 4;
-        float* vs = smem + ((size_t)(pl * 2 + 1) * ROWS + row) * LDK + c4 * 4;
-        *reinterpret_cast<float4*>(ks) = kx;
-        *reinterpret_cast<float4*>(vs) = vx;
-    }
-    __syncthreads();
+    const int qblock = blockIdx.y * (QT * 32);                       // first query row of this workgroup
 
     const int pl = wave / QT, qt = wave % QT;
     const long long pr = pair0 + pl;
-    if (pl >= PAIRS || pr >= npairs || qt * 32 >= a.Sq) return;     // idle wave (no further barriers below)
-    const int b = (int)(pr / H), h = (int)(pr % H);
+    const bool active = pl < PAIRS && pr < npairs && qblock + qt * 32 < a.Sq;
+    const int b = active ? (int)(pr / H) : 0, h = active ? (int)(pr % H) : 0;
     const float* Ks = smem + (size_t)(pl * 2 + 0) * ROWS * LDK;
     const float* Vs = smem + (size_t)(pl * 2 + 1) * ROWS * LDK;
     const int ql = lane & 31, half = lane >> 5;
-    const int q = qt * 32 + ql;
+    const int q = qblock + qt * 32 + ql;
     const float scale = a.scale;
 
     // ---- Q operand: lane (q, half) holds Q[q][half*HD/2 + s], s = 0..HD/2-1
     float qreg[HD / 2];
-    {
+    if (active) {
         const float* qp = a.q + (size_t)b * a.q_bs + (size_t)min(q, a.Sq - 1) * a.ldq + h * HD + half * (HD / 2);
 #pragma unroll
         for (int s4 = 0; s4 < HD / 8; ++s4) {
@@ -84,62 +64,99 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
             qreg[s4 * 4 + 0] = t.x; qreg[s4 * 4 + 1] = t.y; qreg[s4 * 4 + 2] = t.z; qreg[s4 * 4 + 3] = t.w;
         }
     }
-    // ---- S^T tiles: acc[jt][r] = score(key = jt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
-    f32x16 acc[JT];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
-        const float* kp = Ks + (size_t)(jt * 32 + ql) * LDK + half * (HD / 2);
-#pragma unroll
-        for (int s4 = 0; s4 < HD / 8; ++s4) {
-            const float4 kk = *reinterpret_cast<const float4*>(kp + s4 * 4);
-            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[s4 * 4 + 0], acc[jt], 0, 0, 0);
-            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[s4 * 4 + 1], acc[jt], 0, 0, 0);
-            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[s4 * 4 + 2], acc[jt], 0, 0, 0);
-            acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[s4 * 4 + 3], acc[jt], 0, 0, 0);
-        }
-    }
-    // ---- softmax over keys (registers + one lane^32 exchange)
-    float m = -3.0e38f;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float v = key < Sk ? acc[jt][r] : -3.0e38f;
-            acc[jt][r] = v;
-            m = fmaxf(m, v);
-        }
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float l = 0.f;
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __expf(scale * (acc[jt][r] - m));      // masked keys: exp(-huge) == 0
-            acc[jt][r] = p;
-            l += p;
-        }
-    l += __shfl_xor(l, 32);
-    const float inv_l = 1.0f / l;
-    // ---- O^T = V^T P^T : o[dt][r] = out(d = dt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
     f32x16 o[HD / 32];
 #pragma unroll
     for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = -3.0e38f, l = 0.f;
+
+    for (int kc = 0; kc < Sk; kc += ROWS) {
+        if (kc > 0) __syncthreads();                                 // previous chunk fully consumed
+        // ---- stage this chunk of K and V for every pair of the workgroup (zero rows beyond Sk)
+        for (int idx = tid; idx < PAIRS * ROWS * (HD / 4); idx += 256) {
+            const int c4 = idx % (HD / 4);
+            const int rl = (idx / (HD / 4)) % ROWS, row = kc + rl;
+            const int p2 = idx / ((HD / 4) * ROWS);
+            const long long pr2 = pair0 + p2;
+            float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
+            if (pr2 < npairs && row < Sk) {
+                const int b2 = (int)(pr2 / H), h2 = (int)(pr2 % H);
+                if (row < a.S0) {
+                    const size_t of = (size_t)b2 * a.kv0_bs + (size_t)row * a.ld0 + h2 * HD + c4 * 4;
+                    kx = *reinterpret_cast<const float4*>(a.k0 + of); vx = *reinterpret_cast<const float4*>(a.v0 + of);
+                } else {
+                    const size_t of = (size_t)b2 * a.kv1_bs + (size_t)(row - a.S0) * a.ld1 + h2 * HD + c4 * 4;
+                    kx = *reinterpret_cast<const float4*>(a.k1 + of); vx = *reinterpret_cast<const float4*>(a.v1 + of);
+                }
+            }
+            *reinterpret_cast<float4*>(smem + ((size_t)(p2 * 2 + 0) * ROWS + rl) * LDK + c4 * 4) = kx;
+            *reinterpret_cast<float4*>(smem + ((size_t)(p2 * 2 + 1) * ROWS + rl) * LDK + c4 * 4) = vx;
+        }
+        __syncthreads();
+        if (!active) continue;                                       // idle waves only help staging
+        // ---- S^T tiles: acc[jt][r] = score(key = kc + jt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
+        f32x16 acc[JT];
 #pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
+        for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // this half-wave's k index for step r
-            const float* vp = Vs + (size_t)key * LDK + ql;
+            for (int r = 0; r < 16; ++r) acc[jt][r] = 0.f;
+            const float* kp = Ks + (size_t)(jt * 32 + ql) * LDK + half * (HD / 2);
+#pragma unroll
+            for (int s4 = 0; s4 < HD / 8; ++s4) {
+                const float4 kk = *reinterpret_cast<const float4*>(kp + s4 * 4);
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[s4 * 4 + 0], acc[jt], 0, 0, 0);
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[s4 * 4 + 1], acc[jt], 0, 0, 0);
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[s4 * 4 + 2], acc[jt], 0, 0, 0);
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[s4 * 4 + 3], acc[jt], 0, 0, 0);
+            }
+        }
+        // ---- online softmax over keys (registers + one lane^32 exchange)
+        float mc = -3.0e38f;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kc + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v = key < Sk ? acc[jt][r] : -3.0e38f;
+                acc[jt][r] = v;
+                mc = fmaxf(mc, v);
+            }
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float mn = fmaxf(m, mc);
+        const float alpha = __expf(scale * (m - mn));                // 0 on the first chunk (m = -huge)
+        m = mn;
+        float lc = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(scale * (acc[jt][r] - m));    // masked keys: exp(-huge) == 0
+                acc[jt][r] = p;
+                lc += p;
+            }
+        lc += __shfl_xor(lc, 32);
+        l = l * alpha + lc;
+        if (kc > 0) {
 #pragma unroll
             for (int dt = 0; dt < HD / 32; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], acc[jt][r], o[dt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
-    if (q < a.Sq) {
+        // ---- O^T += V^T P^T : o[dt][r] = out(d = dt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // this half-wave's k index for step r
+                const float* vp = Vs + (size_t)key * LDK + ql;
+#pragma unroll
+                for (int dt = 0; dt < HD / 32; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], acc[jt][r], o[dt], 0, 0, 0);
+            }
+    }
+    if (active && q < a.Sq) {
+        const float inv_l = 1.0f / l;
         float* op = a.out + ((size_t)b * a.Sq + q) * (H * HD) + h * HD;
 #pragma unroll
         for (int dt = 0; dt < HD / 32; ++dt)
@@ -155,24 +172,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
 }
 
 // -------------------------------------------------------------------------------- backward (VALU, LDS resident)
-// One workgroup per (cloud, head).  K and V stay in LDS; queries are processed in chunks of 64 rows (Q, dO, P chunk in
-// LDS); every thread owns fixed 4x4 micro-tiles of dK and dV and accumulates them across chunks in registers.
+// One workgroup per (cloud, head).  Keys/values are processed in LDS-resident chunks of up to 128 rows (one chunk when
+// S <= 128); inside a key chunk the queries stream through in chunks of 64 rows (Q, dO and the P/dS tile in LDS).  Every
+// thread owns fixed 4x4 micro-tiles of dK and dV of the current key chunk and accumulates them in registers; dQ is
+// accumulated across key chunks in global memory by the thread that owns the micro-tile (no atomics: deterministic).
 // micro-tile convention: rows {ri + u*RS}, cols {ci + v*CS} with RS/CS = extent/4 (bank-conflict-free strides).
 #define ATT_QC 64
-#define ATT_KT 3            // max dK/dV micro-tiles per thread: (S4/4)*(HD/4) <= 256*ATT_KT
+#define ATT_KC 128
+#define ATT_KT 2            // dK/dV micro-tiles per thread: (KC/4)*(HD/4) <= 256*ATT_KT
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                        const float* __restrict__ dout, const float* __restrict__ lse,
-                                                       float* __restrict__ dqkv, int B, int S, int H, float scale) {
+                                                       float* __restrict__ dqkv, int B, int S, int H, float scale, int KR) {
     constexpr int LD = HD + 4;
     constexpr int QC = ATT_QC, RQ = QC / 4, DQ = HD / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int S4 = (S + 3) & ~3;                       // padded sequence (zero rows)
-    const int LDP = S4 + 4;
-    const int rk = S4 / 4;                              // key-side micro-tile stride
-    float* Ks = smem;                                   // [S4][LD]
-    float* Vs = Ks + (size_t)S4 * LD;
-    float* Qs = Vs + (size_t)S4 * LD;                   // [QC][LD]
+    const int LDP = KR + 4;                             // KR = key rows per chunk (multiple of 4, <= ATT_KC)
+    const int rk = KR / 4;                              // key-side micro-tile stride
+    float* Ks = smem;                                   // [KR][LD]
+    float* Vs = Ks + (size_t)KR * LD;
+    float* Qs = Vs + (size_t)KR * LD;                   // [QC][LD]
     float* Os = Qs + (size_t)QC * LD;                   // [QC][LD]  dO chunk
     float* Ps = Os + (size_t)QC * LD;                   // [QC][LDP] P then dS
     float* Dl = Ps + (size_t)QC * LDP;                  // [QC] D[q]
@@ -181,177 +200,184 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int rs = 3 * H * HD, ro = H * HD;
     float* dq_base = dqkv + (size_t)b * S * rs + h * HD;
+    const int nkt = rk * DQ;                            // dK / dV micro-tiles of a key chunk
 
-    for (int idx = tid; idx < S4 * DQ; idx += 256) {
-        const int c4 = idx % DQ, row = idx / DQ;
-        float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
-        if (row < S) {
-            const float* base = qkv + ((size_t)b * S + row) * rs + h * HD + c4 * 4;
-            kx = *reinterpret_cast<const float4*>(base + H * HD);
-            vx = *reinterpret_cast<const float4*>(base + 2 * H * HD);
-        }
-        *reinterpret_cast<float4*>(Ks + (size_t)row * LD + c4 * 4) = kx;
-        *reinterpret_cast<float4*>(Vs + (size_t)row * LD + c4 * 4) = vx;
-    }
-    float dk[ATT_KT][4][4], dv[ATT_KT][4][4];
-#pragma unroll
-    for (int t = 0; t < ATT_KT; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) { dk[t][u][v] = 0.f; dv[t][u][v] = 0.f; }
-    const int nkt = rk * DQ;                            // dK / dV micro-tiles
-
-    for (int q0 = 0; q0 < S; q0 += QC) {
-        const int qn = min(QC, S - q0);                 // valid rows in this chunk
-        __syncthreads();                                // previous chunk fully consumed (and K/V staged)
-        for (int idx = tid; idx < QC * DQ; idx += 256) {
+    for (int k0 = 0; k0 < S; k0 += KR) {
+        const int kn = min(KR, S - k0);                 // valid key rows in this chunk
+        __syncthreads();
+        for (int idx = tid; idx < KR * DQ; idx += 256) {
             const int c4 = idx % DQ, row = idx / DQ;
-            float4 qx = make_float4(0.f, 0.f, 0.f, 0.f), ox = qx;
-            if (row < qn) {
-                qx = *reinterpret_cast<const float4*>(qkv + ((size_t)b * S + q0 + row) * rs + h * HD + c4 * 4);
-                ox = *reinterpret_cast<const float4*>(dout + ((size_t)b * S + q0 + row) * ro + h * HD + c4 * 4);
+            float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
+            if (row < kn) {
+                const float* base = qkv + ((size_t)b * S + k0 + row) * rs + h * HD + c4 * 4;
+                kx = *reinterpret_cast<const float4*>(base + H * HD);
+                vx = *reinterpret_cast<const float4*>(base + 2 * H * HD);
             }
-            *reinterpret_cast<float4*>(Qs + (size_t)row * LD + c4 * 4) = qx;
-            *reinterpret_cast<float4*>(Os + (size_t)row * LD + c4 * 4) = ox;
+            *reinterpret_cast<float4*>(Ks + (size_t)row * LD + c4 * 4) = kx;
+            *reinterpret_cast<float4*>(Vs + (size_t)row * LD + c4 * 4) = vx;
         }
-        for (int row = wave; row < QC; row += 4) {      // D[q] = sum_d dO[q][d] * O[q][d]
-            float acc = 0.f;
-            if (row < qn)
-                for (int d = lane; d < HD; d += 64)
-                    acc += dout[((size_t)b * S + q0 + row) * ro + h * HD + d] * out[((size_t)b * S + q0 + row) * ro + h * HD + d];
-            acc = wave_sum_f32(acc);
-            if (lane == 0) { Dl[row] = acc; Ll[row] = row < qn ? lse[((size_t)b * H + h) * S + q0 + row] : 0.f; }
-        }
-        __syncthreads();
-        // ---- P[q][k] = exp(scale * q.k - lse[q])
-        for (int mt = tid; mt < RQ * rk; mt += 256) {
-            const int ki = mt % rk, qi = mt / rk;
-            float acc[4][4] = {};
-            for (int d = 0; d < HD; d += 4) {
-                float4 a[4], bb[4];
+        float dk[ATT_KT][4][4], dv[ATT_KT][4][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Qs + (size_t)(qi + u * RQ) * LD + d);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Ks + (size_t)(ki + v * rk) * LD + d);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
-            }
+        for (int t = 0; t < ATT_KT; ++t)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int qq = qi + u * RQ, kk = ki + v * rk;
-                    Ps[(size_t)qq * LDP + kk] = (qq < qn && kk < S) ? __expf(scale * acc[u][v] - Ll[qq]) : 0.f;
+                for (int v = 0; v < 4; ++v) { dk[t][u][v] = 0.f; dv[t][u][v] = 0.f; }
+
+        for (int q0 = 0; q0 < S; q0 += QC) {
+            const int qn = min(QC, S - q0);             // valid rows in this query chunk
+            __syncthreads();                            // previous chunk fully consumed (and K/V staged)
+            for (int idx = tid; idx < QC * DQ; idx += 256) {
+                const int c4 = idx % DQ, row = idx / DQ;
+                float4 qx = make_float4(0.f, 0.f, 0.f, 0.f), ox = qx;
+                if (row < qn) {
+                    qx = *reinterpret_cast<const float4*>(qkv + ((size_t)b * S + q0 + row) * rs + h * HD + c4 * 4);
+                    ox = *reinterpret_cast<const float4*>(dout + ((size_t)b * S + q0 + row) * ro + h * HD + c4 * 4);
                 }
-        }
-        __syncthreads();
-        // ---- dV[k][d] += sum_q P[q][k] dO[q][d]
+                *reinterpret_cast<float4*>(Qs + (size_t)row * LD + c4 * 4) = qx;
+                *reinterpret_cast<float4*>(Os + (size_t)row * LD + c4 * 4) = ox;
+            }
+            for (int row = wave; row < QC; row += 4) {  // D[q] = sum_d dO[q][d] * O[q][d]
+                float acc = 0.f;
+                if (row < qn)
+                    for (int d = lane; d < HD; d += 64)
+                        acc += dout[((size_t)b * S + q0 + row) * ro + h * HD + d] * out[((size_t)b * S + q0 + row) * ro + h * HD + d];
+                acc = wave_sum_f32(acc);
+                if (lane == 0) { Dl[row] = acc; Ll[row] = row < qn ? lse[((size_t)b * H + h) * S + q0 + row] : 0.f; }
+            }
+            __syncthreads();
+            // ---- P[q][k] = exp(scale * q.k - lse[q])
+            for (int mt = tid; mt < RQ * rk; mt += 256) {
+                const int ki = mt % rk, qi = mt / rk;
+                float acc[4][4] = {};
+                for (int d = 0; d < HD; d += 4) {
+                    float4 a[4], bb[4];
 #pragma unroll
-        for (int t = 0; t < ATT_KT; ++t) {
-            const int mt = tid + 256 * t;
-            if (mt < nkt) {
-                const int di = mt % DQ, ki = mt / DQ;
-                for (int qq = 0; qq < qn; ++qq) {
-                    float pp[4], g[4];
+                    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Qs + (size_t)(qi + u * RQ) * LD + d);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)qq * LDP + ki + u * rk];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) g[v] = Os[(size_t)qq * LD + di + v * DQ];
+                    for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Ks + (size_t)(ki + v * rk) * LD + d);
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) dv[t][u][v] += pp[u] * g[v];
+                        for (int v = 0; v < 4; ++v)
+                            acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
                 }
-            }
-        }
-        __syncthreads();
-        // ---- dS = P * (dP - D) * scale, dP[q][k] = sum_d dO[q][d] V[k][d]   (in place over P)
-        for (int mt = tid; mt < RQ * rk; mt += 256) {
-            const int ki = mt % rk, qi = mt / rk;
-            float acc[4][4] = {};
-            for (int d = 0; d < HD; d += 4) {
-                float4 a[4], bb[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Os + (size_t)(qi + u * RQ) * LD + d);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Vs + (size_t)(ki + v * rk) * LD + d);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int qq = qi + u * RQ, kk = ki + v * rk;
-                    const size_t o = (size_t)qq * LDP + kk;
-                    Ps[o] = Ps[o] * (acc[u][v] - Dl[qq]) * scale;
-                }
-        }
-        __syncthreads();
-        // ---- dQ[q][d] = sum_k dS[q][k] K[k][d]   (rows of this chunk are complete: write out)
-        for (int mt = tid; mt < RQ * DQ; mt += 256) {
-            const int di = mt % DQ, qi = mt / DQ;
-            float acc[4][4] = {};
-            for (int kk = 0; kk < S; ++kk) {
-                float pp[4], g[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)(qi + u * RQ) * LDP + kk];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) g[v] = Ks[(size_t)kk * LD + di + v * DQ];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] += pp[u] * g[v];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int qq = qi + u * RQ;
-                if (qq < qn)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) dq_base[(size_t)(q0 + qq) * rs + di + v * DQ] = acc[u][v];
-            }
-        }
-        // ---- dK[k][d] += sum_q dS[q][k] Q[q][d]
-#pragma unroll
-        for (int t = 0; t < ATT_KT; ++t) {
-            const int mt = tid + 256 * t;
-            if (mt < nkt) {
-                const int di = mt % DQ, ki = mt / DQ;
-                for (int qq = 0; qq < qn; ++qq) {
-                    float pp[4], g[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)qq * LDP + ki + u * rk];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) g[v] = Qs[(size_t)qq * LD + di + v * DQ];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) dk[t][u][v] += pp[u] * g[v];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < ATT_KT; ++t) {
-        const int mt = tid + 256 * t;
-        if (mt < nkt) {
-            const int di = mt % DQ, ki = mt / DQ;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int kk = ki + u * rk;
-                if (kk < S)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        dq_base[(size_t)kk * rs + H * HD + di + v * DQ] = dk[t][u][v];
-                        dq_base[(size_t)kk * rs + 2 * H * HD + di + v * DQ] = dv[t][u][v];
+                        const int qq = qi + u * RQ, kk = ki + v * rk;
+                        Ps[(size_t)qq * LDP + kk] = (qq < qn && kk < kn) ? __expf(scale * acc[u][v] - Ll[qq]) : 0.f;
                     }
+            }
+            __syncthreads();
+            // ---- dV[k][d] += sum_q P[q][k] dO[q][d]
+#pragma unroll
+            for (int t = 0; t < ATT_KT; ++t) {
+                const int mt = tid + 256 * t;
+                if (mt < nkt) {
+                    const int di = mt % DQ, ki = mt / DQ;
+                    for (int qq = 0; qq < qn; ++qq) {
+                        float pp[4], g[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)qq * LDP + ki + u * rk];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) g[v] = Os[(size_t)qq * LD + di + v * DQ];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) dv[t][u][v] += pp[u] * g[v];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- dS = P * (dP - D) * scale, dP[q][k] = sum_d dO[q][d] V[k][d]   (in place over P)
+            for (int mt = tid; mt < RQ * rk; mt += 256) {
+                const int ki = mt % rk, qi = mt / rk;
+                float acc[4][4] = {};
+                for (int d = 0; d < HD; d += 4) {
+                    float4 a[4], bb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(Os + (size_t)(qi + u * RQ) * LD + d);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) bb[v] = *reinterpret_cast<const float4*>(Vs + (size_t)(ki + v * rk) * LD + d);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            acc[u][v] += a[u].x * bb[v].x + a[u].y * bb[v].y + a[u].z * bb[v].z + a[u].w * bb[v].w;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int qq = qi + u * RQ, kk = ki + v * rk;
+                        const size_t o = (size_t)qq * LDP + kk;
+                        Ps[o] = Ps[o] * (acc[u][v] - Dl[qq]) * scale;
+                    }
+            }
+            __syncthreads();
+            // ---- dQ[q][d] (+)= sum_k dS[q][k] K[k][d]
+            for (int mt = tid; mt < RQ * DQ; mt += 256) {
+                const int di = mt % DQ, qi = mt / DQ;
+                float acc[4][4] = {};
+                for (int kk = 0; kk < kn; ++kk) {
+                    float pp[4], g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)(qi + u * RQ) * LDP + kk];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) g[v] = Ks[(size_t)kk * LD + di + v * DQ];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[u][v] += pp[u] * g[v];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int qq = qi + u * RQ;
+                    if (qq < qn)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            float* dst = dq_base + (size_t)(q0 + qq) * rs + di + v * DQ;
+                            *dst = k0 == 0 ? acc[u][v] : *dst + acc[u][v];
+                        }
+                }
+            }
+            // ---- dK[k][d] += sum_q dS[q][k] Q[q][d]
+#pragma unroll
+            for (int t = 0; t < ATT_KT; ++t) {
+                const int mt = tid + 256 * t;
+                if (mt < nkt) {
+                    const int di = mt % DQ, ki = mt / DQ;
+                    for (int qq = 0; qq < qn; ++qq) {
+                        float pp[4], g[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) pp[u] = Ps[(size_t)qq * LDP + ki + u * rk];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) g[v] = Qs[(size_t)qq * LD + di + v * DQ];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) dk[t][u][v] += pp[u] * g[v];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < ATT_KT; ++t) {
+            const int mt = tid + 256 * t;
+            if (mt < nkt) {
+                const int di = mt % DQ, ki = mt / DQ;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kk = ki + u * rk;
+                    if (kk < kn)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            dq_base[(size_t)(k0 + kk) * rs + H * HD + di + v * DQ] = dk[t][u][v];
+                            dq_base[(size_t)(k0 + kk) * rs + 2 * H * HD + di + v * DQ] = dv[t][u][v];
+                        }
+                }
             }
         }
     }
@@ -362,19 +388,21 @@ static int launch_attn_fwd3(const AttnFwdArgs& a, hipStream_t s) {
     constexpr int pairs = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
     const size_t smem = (size_t)pairs * 2 * JT * 32 * (HD + 4) * sizeof(float);
     const long long np = (long long)a.B * a.H;
-    const unsigned grid = (unsigned)((np + pairs - 1) / pairs);
+    const unsigned gx = (unsigned)((np + pairs - 1) / pairs), gy = (unsigned)((a.Sq + QT * 32 - 1) / (QT * 32));
     auto k = attn_fwd_kernel<HD, JT, QT>;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(k, dim3(gx, gy), dim3(256), smem, s, a);
     ACT_LAUNCH_CHECK();
     return 0;
 }
 template <int HD>
 static int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t s) {
-    const int JT = (a.S0 + a.S1 + 31) / 32, QT = (a.Sq + 31) / 32;
+    const int Sk = a.S0 + a.S1;
+    const int JT = Sk > 128 ? 4 : (Sk + 31) / 32;                    // key tiles per LDS chunk
+    const int QT = a.Sq > 128 ? 4 : (a.Sq + 31) / 32;                // query tiles per workgroup
 #define C3(J, Q) if (JT == J && QT == Q) return launch_attn_fwd3<HD, J, Q>(a, s)
     C3(1, 1); C3(2, 1); C3(2, 2); C3(3, 1); C3(3, 2); C3(3, 3); C3(4, 1); C3(4, 2); C3(4, 3); C3(4, 4);
 #undef C3
@@ -384,7 +412,7 @@ static int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t s) {
 extern "C" int act_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int S, int H, int head_dim, float scale,
                                      act_stream_t stream) {
     if (!qkv || !out) return ACT_E_NULLPTR;
-    if (B < 0 || S <= 0 || H <= 0 || S > 128 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
+    if (B < 0 || S <= 0 || H <= 0 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_ATTN_FWD, s, 4.0 * B * H * (double)S * S * head_dim, 16.0 * B * S * (double)H * head_dim);
@@ -402,7 +430,7 @@ extern "C" int act_attention_fwd_f32(const float* qkv, float* out, float* lse, i
 extern "C" int act_attention_fwd_prefix_f32(const float* kv0, int S0, const float* qkv1, int Sq, float* out, float* lse, int B,
                                             int H, int head_dim, float scale, act_stream_t stream) {
     if (!kv0 || !qkv1 || !out) return ACT_E_NULLPTR;
-    if (B < 0 || Sq <= 0 || S0 < 0 || H <= 0 || S0 + Sq > 128 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
+    if (B < 0 || Sq <= 0 || S0 < 0 || H <= 0 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_ATTN_FWD, s, 4.0 * B * H * (double)Sq * (S0 + Sq) * head_dim, 4.0 * B * (double)H * head_dim * (4.0 * Sq + 2.0 * S0));
@@ -420,13 +448,13 @@ extern "C" int act_attention_bwd_f32(const float* qkv, const float* out, const f
     if (B < 0 || S <= 0 || H <= 0 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
     if (B == 0) return 0;
     const int S4 = (S + 3) & ~3;
-    const size_t smem = ((size_t)2 * S4 * (head_dim + 4) + (size_t)2 * ATT_QC * (head_dim + 4) + (size_t)ATT_QC * (S4 + 4) + 2 * ATT_QC) * sizeof(float);
-    if (smem > 160 * 1024 || (S4 / 4) * (head_dim / 4) > 256 * ATT_KT) return ACT_E_BADARG;
+    const int KR = S4 < ATT_KC ? S4 : ATT_KC;
+    const size_t smem = ((size_t)2 * KR * (head_dim + 4) + (size_t)2 * ATT_QC * (head_dim + 4) + (size_t)ATT_QC * (KR + 4) + 2 * ATT_QC) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)S * S * head_dim, 28.0 * B * S * (double)H * head_dim);
 #define BWD(HD) { auto k = attn_bwd_kernel<HD>; \
         if (smem > 48 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; } \
-        hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(256), smem, s, qkv, out, dout, lse, dqkv, B, S, H, scale); }
+        hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(256), smem, s, qkv, out, dout, lse, dqkv, B, S, H, scale, KR); }
     if (head_dim == 64) BWD(64) else BWD(32)
 #undef BWD
     ACT_LAUNCH_CHECK();

@@ -113,11 +113,11 @@ int act_colsum_f32(const float* in, int R, int C, int ld, float* out, int accumu
 
 /* Fused multi-head self-attention (models/act.py:57-69): qkv [B,S,3,H,hd] packed as the qkv Linear writes it,
  * out [B,S,H*hd] as the proj Linear reads it, lse [B,H,S] (nullable) = log-sum-exp of the scaled scores.
- * forward: S <= 128, hd in {32,64}.  backward (recomputes P from lse; K/V LDS-resident, 64-query chunks): S <= ~150 at hd=64. */
+ * forward: any S (keys streamed through LDS in chunks of 128 with an online softmax), hd in {32,64}.  backward (recomputes P from lse; 128-key x 64-query LDS chunks): any S. */
 int act_attention_fwd_f32(const float* qkv, float* out, float* lse, int B, int S, int H, int head_dim, float scale,
                           act_stream_t stream);
 /* prefix variant: keys/values = S0 rows of kv0 [B,S0,2,H,hd] followed by the Sq rows of qkv1 [B,Sq,3,H,hd]; queries = qkv1.
- * Used for the prompt-tuned teacher (models/dvae.py:536-576): prompt tokens are keys/values only.  S0 + Sq <= 128. */
+ * Used for the prompt-tuned teacher (models/dvae.py:536-576): prompt tokens are keys/values only. */
 int act_attention_fwd_prefix_f32(const float* kv0, int S0, const float* qkv1, int Sq, float* out, float* lse, int B,
                                  int H, int head_dim, float scale, act_stream_t stream);
 int act_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,

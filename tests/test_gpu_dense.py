@@ -110,7 +110,7 @@ def _attn_ref(qkv, B, S, H, hd):
 
 
 @pytest.mark.parametrize("B,S,H,hd", [(3, 14, 6, 64), (2, 64, 6, 64), (2, 128, 12, 64), (5, 33, 2, 64), (2, 100, 3, 64), (9, 1, 2, 64),
-                                      (2, 16, 2, 32), (3, 128, 2, 32), (128, 14, 6, 64)])
+                                      (2, 16, 2, 32), (3, 128, 2, 32), (128, 14, 6, 64), (1, 512, 3, 64), (2, 576, 2, 64), (2, 129, 2, 64), (1, 300, 2, 32)])
 def test_attention_forward(K, B, S, H, hd):
     qkv = _rnd(f"at{B}{S}{H}", B * S, 3 * H * hd)
     out, lse = K.attention_fwd(qkv.cuda(), B, S, H, hd)
@@ -128,7 +128,7 @@ def test_attention_forward_large_logits(K):
 
 
 @pytest.mark.parametrize("B,S,H,hd", [(3, 14, 6, 64), (2, 64, 6, 64), (4, 33, 2, 64), (2, 16, 2, 32), (2, 1, 1, 64), (2, 128, 3, 64),
-                                      (2, 100, 2, 64), (1, 103, 2, 64), (2, 128, 2, 32)])
+                                      (2, 100, 2, 64), (1, 103, 2, 64), (2, 128, 2, 32), (1, 512, 2, 64), (2, 300, 1, 64), (1, 129, 2, 32)])
 def test_attention_backward(K, B, S, H, hd):
     qkv = _rnd(f"ab{B}{S}{H}", B * S, 3 * H * hd); do = _rnd(f"abd{B}{S}{H}", B * S, H * hd)
     qd = qkv.double().requires_grad_(True)

@@ -173,3 +173,35 @@ def test_no_host_sync_in_training_step(dev):
         model(pts).backward()
     finally:
         torch.cuda.set_sync_debug_mode("default")
+
+
+def test_stress_geometry_vs_oracle(dev):
+    """BASELINE configs[4] geometry (N=8192, 512 groups x 64 neighbours, 24-layer d=768 student, 104 / 512 / 576-token
+    sequences) at B=1 against the CPU oracle: exercises the multi-wave FPS, 128-points-per-lane kNN, chunked (online-softmax)
+    attention forward and the key/query-chunked attention backward."""
+    import copy
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import cfg_from_yaml_file
+    from act_amd.utils.draws import Draws
+    cfg = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml").model
+    cfg.dvae_config.ckpt = "none"
+    cfg.transformer_config.embed_dim = 768; cfg.transformer_config.encoder_dims = 768; cfg.transformer_config.depth = 24
+    cfg.transformer_config.num_heads = 12; cfg.transformer_config.decoder_num_heads = 12
+    for k in ("encoder_dims", "tokens_dims", "decoder_dims"):
+        cfg.dvae_config[k] = 768
+    cfg.dvae_config.num_group = 512; cfg.dvae_config.group_size = 64
+    torch.manual_seed(3)
+    oracle = OM.ACT_PointDistillation(OM.edict(cfg)).train()
+    model = build_model_from_cfg(cfg)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model.to(dev).train()
+    pts = torch.from_numpy(clouds(8, 1, 8192))
+    rec = OL.Draws(record=True)
+    lo = oracle(pts, rec); lo.backward()
+    lg = model(pts.to(dev), draws=Draws(rec.table, device=dev)); lg.backward()
+    assert abs(lg.item() - lo.item()) <= TOL, (lg.item(), lo.item())
+    od = dict(oracle.named_parameters())
+    for n in ["ACT_encoder.blocks.blocks.23.mlp.fc1.weight", "ACT_encoder.encoder.second_conv.0.weight", "mask_token",
+              "ACT_decoder.blocks.1.attn.qkv.weight", "ACT_encoder.pos_embed.0.weight"]:
+        assert _rel(dict(model.named_parameters())[n].grad, od[n].grad) <= 3e-4, n
