@@ -169,6 +169,15 @@ def main():
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": ach / PEAK_HBM_GBS, "traffic": None,
                                "avg_launch_us": 1e3 * dv["ms"] / dv["launches"], "launches_per_step": dv["launches"] / nprof}
+        # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (profiles/)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom)
+            if pm:
+                out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE (calibrated), profiles/r01_pmc_traffic.json"
+                out["roofline"]["algorithmic_bytes_per_launch"] = dv["bytes"] / dv["launches"]
+        except Exception:
+            pass
         out["kernels"] = kernels
         out["hip_kernel_ms_per_step"] = tot_ms / nprof
         # ---- FPS + kNN "Group" throughput (BASELINE metric part 2), hipEvents on the current stream ------------------
