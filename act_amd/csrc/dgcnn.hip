@@ -13,9 +13,11 @@
 
 // ------------------------------------------------------------------------------------------------------- GN statistics
 // yz [B*G, ldy] with Y at column offset 0 and Z at column offset zoff (zoff < 0: no Z term); idx int64 [B,k,G] or null
+#define GN_SPLIT 8
+// stage 1: grid (B*groups, GN_SPLIT); partial sums of (v - pivot), (v - pivot)^2 -> part[(bg*GN_SPLIT + sp)*2 + {0,1}]
 __global__ __launch_bounds__(256) void edge_gn_stats_kernel(const float* __restrict__ yz, int ldy, int zoff,
                                                             const int64_t* __restrict__ idx, int G, int k, int C, int groups,
-                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out, float eps) {
+                                                            float* __restrict__ part) {
     __shared__ float sh[2][4];
     const int b = blockIdx.x / groups, gi = blockIdx.x % groups;
     const int cpg = C / groups, c0 = gi * cpg;
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(256) void edge_gn_stats_kernel(const float* __restr
     const int r00 = idx ? (int)idx[(size_t)b * k * G] : 0;
     const float pv = yz[((size_t)b * G + r00) * ldy + c0] + (zoff >= 0 ? yz[((size_t)b * G) * ldy + zoff + c0] : 0.f);
     float s = 0.f, q = 0.f;
-    for (long long i = threadIdx.x; i < total; i += 256) {
+    for (long long i = (long long)blockIdx.y * 256 + threadIdx.x; i < total; i += 256 * GN_SPLIT) {
         const int c = (int)(i % cpg); const long long t = i / cpg; const int g = (int)(t % G); const int j = (int)(t / G);
         const int src = idx ? (int)idx[((size_t)b * k + j) * G + g] : g;
         float v = yz[((size_t)b * G + src) * ldy + c0 + c];
@@ -36,12 +38,26 @@ __global__ __launch_bounds__(256) void edge_gn_stats_kernel(const float* __restr
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float S = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), Q = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
-        const float dm = S / (float)total;
-        const float var = fmaxf(Q / (float)total - dm * dm, 0.f);
-        mean_out[blockIdx.x] = pv + dm;
-        rstd_out[blockIdx.x] = rsqrtf(var + eps);
+        part[((size_t)blockIdx.x * GN_SPLIT + blockIdx.y) * 2 + 0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[((size_t)blockIdx.x * GN_SPLIT + blockIdx.y) * 2 + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     }
+}
+// stage 2: one thread per (sample, group): fold the partials (fixed order) -> mean, rstd
+__global__ void edge_gn_finalize_kernel(const float* __restrict__ yz, int ldy, int zoff, const int64_t* __restrict__ idx, int G, int k,
+                                        int C, int groups, int nbg, const float* __restrict__ part, float eps,
+                                        float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    const int bg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bg >= nbg) return;
+    const int b = bg / groups, gi = bg % groups, cpg = C / groups, c0 = gi * cpg;
+    const int r00 = idx ? (int)idx[(size_t)b * k * G] : 0;
+    const float pv = yz[((size_t)b * G + r00) * ldy + c0] + (zoff >= 0 ? yz[((size_t)b * G) * ldy + zoff + c0] : 0.f);
+    float S = 0.f, Q = 0.f;
+    for (int sp = 0; sp < GN_SPLIT; ++sp) { S += part[((size_t)bg * GN_SPLIT + sp) * 2]; Q += part[((size_t)bg * GN_SPLIT + sp) * 2 + 1]; }
+    const float total = (float)G * (float)k * (float)cpg;
+    const float dm = S / total;
+    const float var = fmaxf(Q / total - dm * dm, 0.f);
+    mean_out[bg] = pv + dm;
+    rstd_out[bg] = rsqrtf(var + eps);
 }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
@@ -138,13 +154,16 @@ static inline unsigned grid_for(long long total, int block) {
 
 extern "C" int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C,
                                          int groups, const float* gamma, const float* beta, float eps, float slope,
-                                         float* stats /* [2][B*groups] */, float* out, int ldo, int ooff, act_stream_t stream) {
+                                         float* stats /* [18][B*groups] */, float* out, int ldo, int ooff, act_stream_t stream) {
     if (!yz || !gamma || !beta || !stats || !out) return ACT_E_NULLPTR;
     if (B <= 0 || G <= 0 || k <= 0 || C <= 0 || groups <= 0 || C % groups) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * k + (zoff >= 0 ? 2 : 0) + 1));
     float* mean = stats; float* rstd = stats + (size_t)B * groups;
-    hipLaunchKernelGGL(edge_gn_stats_kernel, dim3(B * groups), dim3(256), 0, s, yz, ldy, zoff, idx, G, k, C, groups, mean, rstd, eps);
+    float* part = stats + (size_t)2 * B * groups;
+    hipLaunchKernelGGL(edge_gn_stats_kernel, dim3(B * groups, GN_SPLIT), dim3(256), 0, s, yz, ldy, zoff, idx, G, k, C, groups, part);
+    hipLaunchKernelGGL(edge_gn_finalize_kernel, dim3((B * groups + 63) / 64), dim3(64), 0, s, yz, ldy, zoff, idx, G, k, C, groups, B * groups,
+                       part, eps, mean, rstd);
     const long long total = (long long)B * G * C;
     hipLaunchKernelGGL(edge_gn_apply_max_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, yz, ldy, zoff, idx, G, k, C, groups, mean, rstd,
                        gamma, beta, slope, out, ldo, ooff, total);
@@ -160,7 +179,10 @@ extern "C" int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_GUMBEL_ARGMAX, s, 0.0, 4.0 * B * G * ((double)C * (2 + (noise ? 1 : 0) + (logits_out ? 1 : 0)) + 2.0 * D));
     float* mean = stats; float* rstd = stats + (size_t)B * groups;
-    hipLaunchKernelGGL(edge_gn_stats_kernel, dim3(B * groups), dim3(256), 0, s, h, C, -1, nullptr, G, 1, C, groups, mean, rstd, eps);
+    float* part = stats + (size_t)2 * B * groups;
+    hipLaunchKernelGGL(edge_gn_stats_kernel, dim3(B * groups, GN_SPLIT), dim3(256), 0, s, h, C, -1, nullptr, G, 1, C, groups, part);
+    hipLaunchKernelGGL(edge_gn_finalize_kernel, dim3((B * groups + 63) / 64), dim3(64), 0, s, h, C, -1, nullptr, G, 1, C, groups, B * groups,
+                       part, eps, mean, rstd);
     hipLaunchKernelGGL(gumbel_argmax_gather_kernel, dim3(B * G), dim3(256), 0, s, h, G, C, groups, mean, rstd, gamma, beta, slope, noise, seed,
                        1.0f / tau, codebook, D, index_out, out, logits_out);
     ACT_LAUNCH_CHECK(); return 0;

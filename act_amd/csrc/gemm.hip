@@ -55,8 +55,11 @@ __device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, fl
 
 // VEC : float4 global loads are legal (alignment, leading dimensions)      FULL: M%BM == N%BN == 0 and every K-range is a
 // multiple of BK, so the loaders carry no bounds checks at all.
-template <int BM, int BN, int BK, bool A_K, bool B_K, bool VEC, bool FULL>
-__global__ __launch_bounds__(256, GEMM_MIN_WAVES) void sgemm_kernel(const GemmParams p) {
+// PIPE: software-pipelined main loop for low-occupancy launches -- three LDS stages, the LDS store of tile t+1 and the
+// workgroup barrier sit in the MIDDLE of tile t's MFMA stream, and the first operand fragments of tile t+1 are fetched under
+// the last MFMAs of tile t, so a wave never waits on LDS latency or on the barrier with an empty matrix pipe.
+template <int BM, int BN, int BK, bool A_K, bool B_K, bool VEC, bool FULL, bool PIPE>
+__global__ __launch_bounds__(256, PIPE ? 3 : GEMM_MIN_WAVES) void sgemm_kernel(const GemmParams p) {
     // LDS row stride: K-major operands are transposed on the store (4 x ds_write_b32 per float4): stride = rows + 2 makes
     // the 32 lanes of a half-wave hit 32 distinct banks ((8*kq + 2*c + row) mod 32); row-major operands are stored with
     // ds_write_b128 and need a 16-byte aligned stride (rows + 4).  Operand reads are conflict-free for any stride.
@@ -64,8 +67,9 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void sgemm_kernel(const GemmPa
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 accumulators per wave
     constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 loads per thread per operand per K-tile
     constexpr int KQ = BK / 4;                         // float4 per row of a K-major tile
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA_S];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB_S];
+    constexpr int NSTAGE = PIPE ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float As[NSTAGE][BK * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[NSTAGE][BK * LDB_S];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -166,39 +170,89 @@ __global__ __launch_bounds__(256, GEMM_MIN_WAVES) void sgemm_kernel(const GemmPa
         }
     };
 
-    if (ntiles > 0) {
-        load_a(kbeg); load_b(kbeg);
-        store_lds(0);
-        __syncthreads();
-    }
     const int a_off = wm * (BM / 2) + (lane & 31), b_off = wn * (BN / 2) + (lane & 31), khalf = lane >> 5;
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) { load_a(kbeg + (t + 1) * BK); load_b(kbeg + (t + 1) * BK); }
-        const float* as = As[buf] + khalf * LDA_S + a_off;
-        const float* bs = Bs[buf] + khalf * LDB_S + b_off;
-        float a[2][TM], b[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-            if (kk + 2 < BK) {                          // fetch the next k-pair while this one is in the matrix pipe
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[nxt][i] = as[(kk + 2) * LDA_S + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[nxt][j] = bs[(kk + 2) * LDB_S + j * 32];
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+    if constexpr (!PIPE) {
+        if (ntiles > 0) {
+            load_a(kbeg); load_b(kbeg);
+            store_lds(0);
+            __syncthreads();
         }
-        if (t + 1 < ntiles) store_lds(buf ^ 1);
-        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < ntiles) { load_a(kbeg + (t + 1) * BK); load_b(kbeg + (t + 1) * BK); }
+            const float* as = As[buf] + khalf * LDA_S + a_off;
+            const float* bs = Bs[buf] + khalf * LDB_S + b_off;
+            float a[2][TM], b[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = as[i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[0][j] = bs[j * 32];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+                if (kk + 2 < BK) {                      // fetch the next k-pair while this one is in the matrix pipe
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = as[(kk + 2) * LDA_S + i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = bs[(kk + 2) * LDB_S + j * 32];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            }
+            if (t + 1 < ntiles) store_lds(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        float a[2][TM], b[2][TN];
+        if (ntiles > 0) {
+            load_a(kbeg); load_b(kbeg);
+            store_lds(0);
+            if (ntiles > 1) { load_a(kbeg + BK); load_b(kbeg + BK); }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = As[0][khalf * LDA_S + a_off + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[0][j] = Bs[0][khalf * LDB_S + b_off + j * 32];
+        }
+        int cb = 0;                                     // LDS stage of tile t
+        for (int t = 0; t < ntiles; ++t) {
+            const int nb = cb == 2 ? 0 : cb + 1;
+            const float* as = As[cb] + khalf * LDA_S + a_off;
+            const float* bs = Bs[cb] + khalf * LDB_S + b_off;
+            const float* an = As[nb] + khalf * LDA_S + a_off;
+            const float* bn = Bs[nb] + khalf * LDB_S + b_off;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+                if (kk == BK / 2) {                     // mid-tile: publish tile t+1, start fetching tile t+2, rendezvous
+                    if (t + 1 < ntiles) store_lds(nb);
+                    if (t + 2 < ntiles) { load_a(kbeg + (t + 2) * BK); load_b(kbeg + (t + 2) * BK); }
+                    __syncthreads();
+                }
+                if (kk + 2 < BK) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = as[(kk + 2) * LDA_S + i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = bs[(kk + 2) * LDB_S + j * 32];
+                } else if (t + 1 < ntiles) {            // first fragments of the next tile, under this tile's last MFMAs
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = an[i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = bn[j * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cb = nb;
+        }
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -242,9 +296,10 @@ __global__ void sgemm_splitk_reduce(const float* __restrict__ partial, int split
 }
 
 template <int BM, int BN, int BK>
-static void launch_variant(const GemmParams& p, int ak, int bk, bool vec, bool full, dim3 grid, hipStream_t s) {
-#define L(AK, BKK, V, F) hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, AK, BKK, V, F>), grid, dim3(256), 0, s, p)
-#define LV(AK, BKK) { if (full) L(AK, BKK, true, true); else if (vec) L(AK, BKK, true, false); else L(AK, BKK, false, false); }
+static void launch_variant(const GemmParams& p, int ak, int bk, bool vec, bool full, bool pipe, dim3 grid, hipStream_t s) {
+#define L(AK, BKK, V, F, P) hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, AK, BKK, V, F, P>), grid, dim3(256), 0, s, p)
+#define LV(AK, BKK) { if (full && pipe) L(AK, BKK, true, true, true); else if (full) L(AK, BKK, true, true, false); \
+                      else if (vec) L(AK, BKK, true, false, false); else L(AK, BKK, false, false, false); }
     if (ak && bk)        LV(true, true)
     else if (ak && !bk)  LV(true, false)
     else if (!ak && !bk) LV(false, false)
@@ -259,9 +314,9 @@ static int gemm_bk() {
     return g_gemm_bk;
 }
 
-extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                             float* C, int ldc, const act_gemm_epilogue_t* epi_in, float* workspace, size_t workspace_bytes,
-                             act_stream_t stream) {
+extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                float* C, int ldc, const act_gemm_epilogue_t* epi_in, float* workspace, size_t workspace_bytes,
+                                int tile, int force_splits, act_stream_t stream) {
     if (!A || !B || !C) return ACT_E_NULLPTR;
     if (M < 0 || N < 0 || K < 0) return ACT_E_BADARG;
     if (M == 0 || N == 0) return 0;
@@ -299,6 +354,13 @@ extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, co
             if (nb * sp >= 1024) break;
         }
     }
+    const bool pipe = tile >= 4 && tile <= 6;           // tiles 4..6 = software-pipelined main loop of tiles 1..3
+    if (pipe) tile -= 3;
+    if (tile >= 1 && tile <= 3) {                       // explicit configuration (autotuner)
+        BM = cands[tile - 1].bm; BN = cands[tile - 1].bn;
+        splits = force_splits >= 1 ? force_splits : 1;
+        if (splits > 1 && (!workspace || (size_t)splits * M * N * sizeof(float) > workspace_bytes)) return ACT_E_BADARG;
+    }
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     const long long nt = (long long)p.tiles_m * p.tiles_n;
     const int BKsel = gemm_bk();
@@ -311,13 +373,13 @@ extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, co
     dim3 grid((unsigned)nt, 1, (unsigned)splits);
     const bool full = vec && (M % BM == 0) && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
     if (BKsel == 32) {
-        if (BM == 128 && BN == 128) launch_variant<128, 128, 32>(p, a_kmajor, b_kmajor, vec, full, grid, s);
-        else if (BM == 128)         launch_variant<128, 64, 32>(p, a_kmajor, b_kmajor, vec, full, grid, s);
-        else                        launch_variant<64, 64, 32>(p, a_kmajor, b_kmajor, vec, full, grid, s);
+        if (BM == 128 && BN == 128) launch_variant<128, 128, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
+        else if (BM == 128)         launch_variant<128, 64, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
+        else                        launch_variant<64, 64, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
     } else {
-        if (BM == 128 && BN == 128) launch_variant<128, 128, 16>(p, a_kmajor, b_kmajor, vec, full, grid, s);
-        else if (BM == 128)         launch_variant<128, 64, 16>(p, a_kmajor, b_kmajor, vec, full, grid, s);
-        else                        launch_variant<64, 64, 16>(p, a_kmajor, b_kmajor, vec, full, grid, s);
+        if (BM == 128 && BN == 128) launch_variant<128, 128, 16>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
+        else if (BM == 128)         launch_variant<128, 64, 16>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
+        else                        launch_variant<64, 64, 16>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
     }
     ACT_LAUNCH_CHECK();
     if (splits > 1) {
@@ -327,4 +389,10 @@ extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, co
         ACT_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                             float* C, int ldc, const act_gemm_epilogue_t* epi_in, float* workspace, size_t workspace_bytes,
+                             act_stream_t stream) {
+    return act_sgemm_ex_f32(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epi_in, workspace, workspace_bytes, 0, 0, stream);
 }

@@ -151,19 +151,44 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ i
     __syncthreads();
     if (ry == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
 }
+__global__ __launch_bounds__(256) void colsum_stage2_pair(const float* __restrict__ partial0, const float* __restrict__ partial1,
+                                                          int nparts, int C, float* __restrict__ out0, float* __restrict__ out1,
+                                                          int accumulate) {
+    __shared__ float sh[4][64];
+    const float* __restrict__ partial = blockIdx.y ? partial1 : partial0;
+    float* __restrict__ out = blockIdx.y ? out1 : out0;
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int p = ry;
+        for (; p + 4 < nparts; p += 8) { a0 += partial[(size_t)p * C + c]; a1 += partial[(size_t)(p + 4) * C + c]; }
+        for (; p < nparts; p += 4) a0 += partial[(size_t)p * C + c];
+    }
+    sh[ry][cx] = a0 + a1;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        const float acc = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+        out[c] = accumulate ? out[c] + acc : acc;
+    }
+}
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out,
                                                      int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int p = 0;
-    for (; p + 3 < nparts; p += 4) {
-        a0 += partial[(size_t)p * C + c]; a1 += partial[(size_t)(p + 1) * C + c];
-        a2 += partial[(size_t)(p + 2) * C + c]; a3 += partial[(size_t)(p + 3) * C + c];
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int p = ry;
+        for (; p + 4 < nparts; p += 8) { a0 += partial[(size_t)p * C + c]; a1 += partial[(size_t)(p + 4) * C + c]; }
+        for (; p < nparts; p += 4) a0 += partial[(size_t)p * C + c];
     }
-    for (; p < nparts; ++p) a0 += partial[(size_t)p * C + c];
-    const float acc = (a0 + a1) + (a2 + a3);
-    out[c] = accumulate ? out[c] + acc : acc;
+    sh[ry][cx] = a0 + a1;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        const float acc = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
+        out[c] = accumulate ? out[c] + acc : acc;
+    }
 }
 
 // cosine distillation loss: rows [R,D] ; loss = mean_r (1 - cos(s_r, t_r)), cos with torch's eps semantics
@@ -248,8 +273,7 @@ extern "C" int act_layernorm_bwd_f32(const float* dy, const float* xin, const fl
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), params ? (size_t)8 * D * sizeof(float) : 0, s, dy, xin, gamma, mean, rstd, dres, dx, pg, pb, T, D, rpb);
     ACT_LAUNCH_CHECK();
     if (params) {
-        hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(64), 0, s, pg, nblk, D, dgamma, accumulate_params);
-        hipLaunchKernelGGL(colsum_stage2, dim3((D + 63) / 64), dim3(64), 0, s, pb, nblk, D, dbeta, accumulate_params);
+        hipLaunchKernelGGL(colsum_stage2_pair, dim3((D + 63) / 64, 2), dim3(256), 0, s, pg, pb, nblk, D, dgamma, dbeta, accumulate_params);
         ACT_LAUNCH_CHECK();
     }
     return 0;
@@ -275,7 +299,7 @@ extern "C" int act_colsum_f32(const float* in, int R, int C, int ld, float* out,
     const int nparts = (R + rpb - 1) / rpb > 0 ? (R + rpb - 1) / rpb : 1;
     ActProfScope ps(KID_COLSUM, s, 0.0, 4.0 * R * (double)C);
     hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nparts), dim3(256), 0, s, in, R, C, ld, rpb, workspace);
-    hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(64), 0, s, workspace, nparts, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nparts, C, out, accumulate);
     ACT_LAUNCH_CHECK(); return 0;
 }
 

@@ -4,6 +4,7 @@ Nothing here computes on the host: every function allocates outputs with torch (
 allocator) and launches kernels of libact_hip.so on the current HIP stream.
 """
 import ctypes
+import os
 
 import torch
 
@@ -21,6 +22,7 @@ class GemmEpilogue(ctypes.Structure):
 
 _C._declare({
     "act_sgemm_f32": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, ctypes.POINTER(GemmEpilogue), _vp, _sz, _vp],
+    "act_sgemm_ex_f32": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, ctypes.POINTER(GemmEpilogue), _vp, _sz, _i, _i, _vp],
     "act_layernorm_fwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "act_layernorm_bwd_workspace": [_i, _i],
     "act_layernorm_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _vp],
@@ -33,7 +35,7 @@ _C._declare({
 })
 _C.lib.act_layernorm_bwd_workspace.restype = _sz
 _C.lib.act_colsum_workspace.restype = _sz
-for _n in ("act_sgemm_f32", "act_layernorm_fwd_f32", "act_layernorm_bwd_workspace", "act_layernorm_bwd_f32",
+for _n in ("act_sgemm_f32", "act_sgemm_ex_f32", "act_layernorm_fwd_f32", "act_layernorm_bwd_workspace", "act_layernorm_bwd_f32",
            "act_colsum_workspace", "act_colsum_f32", "act_attention_fwd_f32", "act_attention_bwd_f32",
            "act_cosine_loss_fwd_f32", "act_cosine_loss_bwd_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
@@ -62,7 +64,7 @@ def _f32c(t, name="tensor"):
 
 # ---- raw wrappers ---------------------------------------------------------------------------------------
 def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, res=None, rowscale=None,
-         rows_per_scale=0, out=None, accumulate=False, alpha=1.0, res_row_div=0):
+         rows_per_scale=0, out=None, accumulate=False, alpha=1.0, res_row_div=0, cfg=None):
     """C[M,N] = epilogue(op(a) @ op(b)); a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N]."""
     a = _f32c(a, "a"); b = _f32c(b, "b")
     if a_kmajor:
@@ -81,9 +83,58 @@ def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, 
                      ldr=(res.stride(0) if res is not None else 0), ldaux=(aux.stride(0) if aux is not None else 0),
                      res_row_div=int(res_row_div), bias=ptr(bias), rowscale=ptr(rowscale), res=ptr(res), aux=ptr(aux))
     ws = workspace(a.device)
-    check(lib.act_sgemm_f32(int(a_kmajor), int(b_kmajor), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
-                            out.stride(0), ctypes.byref(e), ptr(ws), ws.numel() * 4, stream()), "act_sgemm_f32")
+    tile, splits = cfg if cfg is not None else _gemm_config(a, b, a_kmajor, b_kmajor, M, N, K, ws)
+    check(lib.act_sgemm_ex_f32(int(a_kmajor), int(b_kmajor), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
+                               out.stride(0), ctypes.byref(e), ptr(ws), ws.numel() * 4, tile, splits, stream()), "act_sgemm_f32")
     return out
+
+
+# ---- GEMM autotuner: the step has ~40 distinct (layout, M, N, K) shapes; each is timed once (tile shape x split-K) on first
+# use -- i.e. during the warm-up steps -- and the winner is cached, so steady-state steps never synchronise.
+_GEMM_CACHE = {}
+AUTOTUNE = os.environ.get("ACT_GEMM_AUTOTUNE", "1") != "0"
+
+
+def _gemm_config(a, b, ak, bk, M, N, K, ws):
+    if not AUTOTUNE or M * N * K < (1 << 24):
+        return 0, 0                                            # tiny products: built-in cost model
+    key = (int(ak), int(bk), M, N, K, a.device.index)
+    cfg = _GEMM_CACHE.get(key)
+    if cfg is not None:
+        return cfg
+    if torch.cuda.is_current_stream_capturing():
+        return 0, 0
+    cands = []
+    for tile, (bm, bn) in ((1, (128, 128)), (2, (128, 64)), (3, (64, 64))):
+        nb = -(-M // bm) * -(-N // bn)
+        if nb > 16384 and tile > 1:
+            continue
+        sp_list = [1]
+        if K >= 1024 and nb < 2048:
+            sp_list += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nb * s <= 8192]
+        cands += [(tile, s) for s in sp_list]
+        if M % bm == 0 and N % bn == 0 and K % 32 == 0:
+            cands += [(tile + 3, s) for s in sp_list if s <= 4 and (K // s) % 32 == 0]       # software-pipelined main loop
+    scratch = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    e = GemmEpilogue(alpha=1.0)
+    best, best_t = (0, 0), float("inf")
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for tile, sp in cands:
+        def run():
+            return lib.act_sgemm_ex_f32(int(ak), int(bk), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(scratch), N,
+                                        ctypes.byref(e), ptr(ws), ws.numel() * 4, tile, sp, stream())
+        if run() != 0:
+            continue
+        ev[0].record()
+        for _ in range(3):
+            run()
+        ev[1].record()
+        ev[1].synchronize()
+        t = ev[0].elapsed_time(ev[1])
+        if t < best_t:
+            best, best_t = (tile, sp), t
+    _GEMM_CACHE[key] = best
+    return best
 
 
 def layernorm_fwd(x, pos, gamma, beta, eps, want_xin=True, want_stats=True):
@@ -458,7 +509,7 @@ def edge_gn_lrelu_max(yz, zoff, idx, B, G, k, C, gn, out=None, ooff=0, slope=0.2
     yz = _f32c(yz)
     if out is None:
         out = torch.empty(B * G, C, dtype=torch.float32, device=yz.device)
-    stats = torch.empty(2 * B * gn.num_groups, dtype=torch.float32, device=yz.device)
+    stats = torch.empty(18 * B * gn.num_groups, dtype=torch.float32, device=yz.device)
     check(lib.act_edge_gn_lrelu_max_f32(ptr(yz), yz.stride(0), int(zoff), ptr(idx), B, G, k, C, gn.num_groups, ptr(gn.weight),
                                         ptr(gn.bias), float(gn.eps), float(slope), ptr(stats), ptr(out), out.stride(0), int(ooff),
                                         stream()), "act_edge_gn_lrelu_max_f32")
@@ -471,7 +522,7 @@ def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, 
     C = h.shape[1]
     D = codebook.shape[1]
     dev = h.device
-    stats = torch.empty(2 * B * gn.num_groups, dtype=torch.float32, device=dev)
+    stats = torch.empty(18 * B * gn.num_groups, dtype=torch.float32, device=dev)
     index = torch.empty(B, G, dtype=torch.int64, device=dev)
     out = torch.empty(B, G, D, dtype=torch.float32, device=dev)
     logits = torch.empty(B, G, C, dtype=torch.float32, device=dev) if want_logits else None

@@ -94,6 +94,12 @@ typedef struct {
 int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                   float* C, int ldc, const act_gemm_epilogue_t* epilogue, float* workspace, size_t workspace_bytes,
                   act_stream_t stream);
+/* same, with an explicit launch configuration: tile 1 = 128x128, 2 = 128x64, 3 = 64x64 workgroup tile, 4..6 = the same tiles with the
+ * software-pipelined (3-stage LDS, mid-tile barrier) main loop (0: built-in cost model), splits >= 1 = split-K factor.  Used by the host-side autotuner (act_amd/kernels.py), results are identical up to
+ * the fp32 summation order of split-K. */
+int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                     float* C, int ldc, const act_gemm_epilogue_t* epilogue, float* workspace, size_t workspace_bytes,
+                     int tile, int splits, act_stream_t stream);
 
 /* ---- row-wise fused kernels of a Transformer block ------------------------------------------- */
 /* xin = x + pos (pos nullable); y = LayerNorm(xin) * gamma + beta  (models/act.py:87-90 with the
@@ -154,7 +160,7 @@ int act_group_sum_f32(const float* in, int G, int n, int C, float* out, act_stre
 /* ---- DGCNN token mixer + dVAE tokenizer glue (models/dvae.py:26-117, 587-588) -------------------------------- */
 /* Edge-conv tail.  yz [B*G, ldy] holds Y = Wa.x at column 0 and (zoff >= 0) Z = (Wb-Wa).x at column zoff; idx int64
  * [B,k,G] (KNN transpose_mode=False layout; NULL: no gather, k must be 1).  out[b*G+g, ooff + c] =
- * max_j LeakyReLU(GroupNorm_groups(Y[b, idx[b,j,g], c] + Z[b,g,c])).  stats: scratch [2*B*groups]. */
+ * max_j LeakyReLU(GroupNorm_groups(Y[b, idx[b,j,g], c] + Z[b,g,c])).  stats: scratch [18*B*groups]. */
 int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C,
                               int groups, const float* gamma, const float* beta, float eps, float slope, float* stats,
                               float* out, int ldo, int ooff, act_stream_t stream);

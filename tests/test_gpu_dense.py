@@ -344,3 +344,21 @@ def test_attention_prefix_and_teacher_block_prefix(K):
     kk = torch.cat((k0, k1), 2); vv = torch.cat((v0, v1), 2)
     ref = (torch.softmax(q @ kk.transpose(-2, -1) * hd ** -0.5, -1) @ vv).transpose(1, 2).reshape(B * Sq, H * hd)
     assert _rel(out, ref) <= 2e-5
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_gemm_explicit_configs_and_pipelined_loop(K, tile):
+    """every tile shape, with and without the software-pipelined main loop, with and without split-K, all layouts."""
+    M, N, Kd = 512, 384, 1024
+    a = _rnd("cf.a", M, Kd); b = _rnd("cf.b", N, Kd)
+    ref = a.double() @ b.double().t()
+    for ak, bk in [(True, True), (True, False), (False, False)]:
+        A = a.cuda() if ak else a.t().contiguous().cuda()
+        Bm = b.cuda() if bk else b.t().contiguous().cuda()
+        for sp in (1, 2, 4):
+            c = K.gemm(A, Bm, ak, bk, cfg=(tile, sp))
+            assert _rel(c, ref) <= 2e-5, (tile, ak, bk, sp)
+    # K with a single / odd number of tiles exercises the pipeline prologue and drain
+    for Kd2 in (32, 64, 96, 160):
+        a2 = _rnd(f"cf.a{Kd2}", 256, Kd2); b2 = _rnd(f"cf.b{Kd2}", 128, Kd2)
+        assert _rel(K.gemm(a2.cuda(), b2.cuda(), cfg=(tile, 1)), a2.double() @ b2.double().t()) <= 2e-5
