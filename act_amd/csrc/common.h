@@ -68,4 +68,18 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
     v += dpp_mov_f<0x143, 0xc>(0.f, v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// integer max over the wave (no float canonicalisation ops in the dependent chain); ident must be <= every value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov_i(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_max_i32(int v, int ident) {
+    v = max(v, dpp_mov_i<0x111, 0xf>(ident, v));
+    v = max(v, dpp_mov_i<0x112, 0xf>(ident, v));
+    v = max(v, dpp_mov_i<0x114, 0xf>(ident, v));
+    v = max(v, dpp_mov_i<0x118, 0xf>(ident, v));
+    v = max(v, dpp_mov_i<0x142, 0xa>(ident, v));
+    v = max(v, dpp_mov_i<0x143, 0xc>(ident, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ int first_lane(unsigned long long ballot) { return __ffsll((long long)ballot) - 1; }

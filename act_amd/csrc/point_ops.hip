@@ -13,13 +13,16 @@
 //  * Distances use __fsub_rn/__fmul_rn/__fadd_rn: (dx*dx + dy*dy) + dz*dz, bit-identical to the
 //    CPU oracle, so indices are bit-exact.
 #include "common.h"
+#include <stdlib.h>
 
 // =============================================== FPS ==============================================
-template <int WAVES, int PPL>
+// LDS_CLOUD is a template parameter on purpose: a runtime LDS-or-global choice compiles to FLAT loads, whose latency sits on
+// the critical path of every one of the G-1 dependent iterations.
+template <int WAVES, int PPL, bool LDS_CLOUD>
 __global__ __launch_bounds__(WAVES * 64) void fps_kernel(const float* __restrict__ xyz, int N, int G,
                                                          int32_t* __restrict__ idx_out,
-                                                         float* __restrict__ centers_out, int skip_near_origin,
-                                                         int lds_cloud) {
+                                                         float* __restrict__ centers_out, int skip_near_origin) {
+    constexpr bool lds_cloud = LDS_CLOUD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // layout: [2][WAVES] best value, [2][WAVES] best index, then (optional) the cloud xyz
     float* s_val = smem;
@@ -51,33 +54,37 @@ __global__ __launch_bounds__(WAVES * 64) void fps_kernel(const float* __restrict
     }
     if (WAVES > 1 || lds_cloud) __syncthreads();
 
+    // the selected indices are collected in LDS and written once at the end: a global store inside the loop would put a
+    // vmcnt(0) wait in front of every workgroup barrier and serialise each iteration with a memory round trip
+    int* s_sel = reinterpret_cast<int*>(smem + 4 * WAVES) + (lds_cloud ? N * 3 : 0);
+    int* s_vali = reinterpret_cast<int*>(s_val);
     int old = 0;
     float cx = p[0], cy = p[1], cz = p[2];
-    if (tid == 0) {
-        idx_out[(size_t)b * G] = 0;
-        if (centers_out) { float* c = centers_out + (size_t)b * G * 3; c[0] = cx; c[1] = cy; c[2] = cz; }
-    }
+    if (tid == 0) s_sel[0] = 0;
 
     for (int it = 1; it < G; ++it) {
-        float best = -2.0f; int bj = 0;
+        // distances are >= 0 (dead / padding: -1): their bit patterns compare like signed integers, so the wave reduction
+        // runs on integers and carries no float canonicalisation ops in its dependent chain
+        int best = (int)0x80000000; int bj = 0;
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
             const float d = sqdist3(px[j], py[j], pz[j], cx, cy, cz);
             const float t = fminf(td[j], d);
             td[j] = t;
-            if (t > best) { best = t; bj = j; }       // strict '>' : lowest j wins inside the lane
+            const int ti = __float_as_int(t);
+            if (ti > best) { best = ti; bj = j; }      // strict '>' : lowest j wins inside the lane
         }
-        const float wmax = wave_max_f32(best, -3.0f);
+        const int wmax = wave_max_i32(best, (int)0x80000000);
         const int wl = first_lane(__ballot(best == wmax));     // lowest lane == lowest index (contiguous chunks)
         int widx = __builtin_amdgcn_readlane(base + bj, wl);
         if (WAVES > 1) {
             const int par = it & 1;
-            if (lane == 0) { s_val[par * WAVES + wave] = wmax; s_idx[par * WAVES + wave] = widx; }
+            if (lane == 0) { s_vali[par * WAVES + wave] = wmax; s_idx[par * WAVES + wave] = widx; }
             __syncthreads();
-            float gv = s_val[par * WAVES]; int gi = s_idx[par * WAVES];
+            int gv = s_vali[par * WAVES]; int gi = s_idx[par * WAVES];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) {
-                const float v = s_val[par * WAVES + w];
+                const int v = s_vali[par * WAVES + w];
                 if (v > gv) { gv = v; gi = s_idx[par * WAVES + w]; }
             }
             widx = gi;
@@ -85,9 +92,15 @@ __global__ __launch_bounds__(WAVES * 64) void fps_kernel(const float* __restrict
         old = widx;
         if (lds_cloud) { cx = s_xyz[old * 3 + 0]; cy = s_xyz[old * 3 + 1]; cz = s_xyz[old * 3 + 2]; }
         else           { cx = p[old * 3 + 0];     cy = p[old * 3 + 1];     cz = p[old * 3 + 2]; }
-        if (tid == 0) {
-            idx_out[(size_t)b * G + it] = old;
-            if (centers_out) { float* c = centers_out + ((size_t)b * G + it) * 3; c[0] = cx; c[1] = cy; c[2] = cz; }
+        if (tid == 0) s_sel[it] = old;
+    }
+    __syncthreads();
+    for (int g = tid; g < G; g += WAVES * 64) {
+        const int k = s_sel[g];
+        idx_out[(size_t)b * G + g] = k;
+        if (centers_out) {
+            float* c = centers_out + ((size_t)b * G + g) * 3;
+            c[0] = p[k * 3 + 0]; c[1] = p[k * 3 + 1]; c[2] = p[k * 3 + 2];
         }
     }
 }
@@ -138,13 +151,14 @@ template <int WAVES, int PPL>
 static int launch_fps(const float* xyz, int B, int N, int G, int32_t* idx, float* centers, int skip, hipStream_t s) {
     const size_t cloud_bytes = (size_t)N * 3 * sizeof(float);
     const int lds_cloud = cloud_bytes <= 128 * 1024 ? 1 : 0;
-    const size_t smem = 4 * WAVES * sizeof(float) + (lds_cloud ? cloud_bytes : 0);
-    auto k = fps_kernel<WAVES, PPL>;
+    const size_t smem = 4 * WAVES * sizeof(float) + (lds_cloud ? cloud_bytes : 0) + (size_t)G * sizeof(int);
+    if (smem > 160 * 1024) return ACT_E_BADARG;
+    auto k = lds_cloud ? fps_kernel<WAVES, PPL, true> : fps_kernel<WAVES, PPL, false>;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k, dim3(B), dim3(WAVES * 64), smem, s, xyz, N, G, idx, centers, skip, lds_cloud);
+    hipLaunchKernelGGL(k, dim3(B), dim3(WAVES * 64), smem, s, xyz, N, G, idx, centers, skip);
     ACT_LAUNCH_CHECK();
     return 0;
 }
@@ -159,6 +173,9 @@ extern "C" int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_o
     hipStream_t s = (hipStream_t)stream;
     // algorithmic bytes: read xyz once, write idx (+ centers)  [SURVEY 8d]
     ActProfScope ps(KID_FPS, s, 0.0, (double)B * (12.0 * N + 4.0 * G + (centers_out ? 12.0 * G : 0.0)));
+    { const char* e = getenv("ACT_FPS_CFG");          // tuning knob for N <= 1024: 1 = one wave x 16 points/lane, 2 = two waves x 8
+      if (e && N <= 1024 && N > 256) { if (atoi(e) == 1) return launch_fps<1, 16>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+                                       if (atoi(e) == 2) return launch_fps<2, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s); } }
     if (N <= 256)   return launch_fps<1, 4>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
     if (N <= 1024)  return launch_fps<4, 4>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
     if (N <= 2048)  return launch_fps<4, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
