@@ -14,44 +14,9 @@
 // staging, double-buffered LDS, one barrier per K-tile).  Workgroup ids are remapped so each XCD (own L2)
 // works on a compact band of tiles.  The epilogue fuses bias, GELU / ReLU (+ saving the pre-activation),
 // activation-gradient multiply, per-row scale (DropPath gate) and residual add.
-#include "common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define GEMM_BK_DEFAULT 16
-#ifndef GEMM_MIN_WAVES
-#define GEMM_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (4 workgroups / CU)
-#endif
-
-struct GemmParams {
-    const float* A; const float* B; float* C;
-    int M, N, K, lda, ldb, ldc;
-    int k_per_split;                 // K range per blockIdx.z (== K when no split)
-    float* partial;                  // split-K workspace [splits][M][N] (C untouched) or null
-    act_gemm_epilogue_t epi;
-    int tiles_m, tiles_n;
-};
-
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-}
-
-__device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, float v, int row, int col) {
-    v *= e.alpha;
-    if (e.bias) v += e.bias[col];
-    switch (e.act) {
-        case ACT_EPI_GELU:      if (e.aux) e.aux[(size_t)row * e.ldaux + col] = v; v = gelu_f(v); break;
-        case ACT_EPI_RELU:      v = fmaxf(v, 0.f); break;
-        case ACT_EPI_MUL_GELU_GRAD: v *= gelu_grad_f(e.aux[(size_t)row * e.ldaux + col]); break;
-        case ACT_EPI_MUL_RELU_MASK: v = e.aux[(size_t)row * e.ldaux + col] > 0.f ? v : 0.f; break;
-        default: break;
-    }
-    if (e.rowscale) v *= e.rowscale[row / e.rows_per_scale];
-    if (e.res) v += e.res[(size_t)(e.res_row_div > 1 ? row / e.res_row_div : row) * e.ldr + col];
-    return v;
-}
 
 // VEC : float4 global loads are legal (alignment, leading dimensions)      FULL: M%BM == N%BN == 0 and every K-range is a
 // multiple of BK, so the loaders carry no bounds checks at all.
@@ -354,6 +319,8 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
             if (nb * sp >= 1024) break;
         }
     }
+    const bool mi16 = tile >= 7 && tile <= 9;           // tiles 7..9 = tiles 1..3 on v_mfma_f32_16x16x4_f32 (gemm16.hip)
+    if (mi16) tile -= 6;
     const bool pipe = tile >= 4 && tile <= 6;           // tiles 4..6 = software-pipelined main loop of tiles 1..3
     if (pipe) tile -= 3;
     if (tile >= 1 && tile <= 3) {                       // explicit configuration (autotuner)
@@ -372,7 +339,10 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
 
     dim3 grid((unsigned)nt, 1, (unsigned)splits);
     const bool full = vec && (M % BM == 0) && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
-    if (BKsel == 32) {
+    if (mi16) {
+        if (!full) return ACT_E_BADARG;
+        launch_sgemm16(p, BM == 128 ? (BN == 128 ? 0 : 1) : 2, a_kmajor, b_kmajor, grid, s);
+    } else if (BKsel == 32) {
         if (BM == 128 && BN == 128) launch_variant<128, 128, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
         else if (BM == 128)         launch_variant<128, 64, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
         else                        launch_variant<64, 64, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);

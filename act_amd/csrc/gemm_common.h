@@ -1,0 +1,49 @@
+// gemm_common.h -- parameter block and fused epilogue shared by the fp32 MFMA GEMM kernels (gemm.hip, gemm16.hip)
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GEMM_BK_DEFAULT 16
+#ifndef GEMM_MIN_WAVES
+#define GEMM_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (4 workgroups / CU)
+#endif
+
+struct GemmParams {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc;
+    int k_per_split;                 // K range per blockIdx.z (== K when no split)
+    float* partial;                  // split-K workspace [splits][M][N] (C untouched) or null
+    act_gemm_epilogue_t epi;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, float v, int row, int col) {
+    v *= e.alpha;
+    if (e.bias) v += e.bias[col];
+    switch (e.act) {
+        case ACT_EPI_GELU:      if (e.aux) e.aux[(size_t)row * e.ldaux + col] = v; v = gelu_f(v); break;
+        case ACT_EPI_RELU:      v = fmaxf(v, 0.f); break;
+        case ACT_EPI_MUL_GELU_GRAD: v *= gelu_grad_f(e.aux[(size_t)row * e.ldaux + col]); break;
+        case ACT_EPI_MUL_RELU_MASK: v = e.aux[(size_t)row * e.ldaux + col] > 0.f ? v : 0.f; break;
+        default: break;
+    }
+    if (e.rowscale) v *= e.rowscale[row / e.rows_per_scale];
+    if (e.res) v += e.res[(size_t)(e.res_row_div > 1 ? row / e.res_row_div : row) * e.ldr + col];
+    return v;
+}
+
+
+// XCD-aware remap: workgroup b is dispatched to XCD b%8; give each XCD a contiguous band of tiles (own L2)
+__device__ __forceinline__ int xcd_remap(int wg, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// launcher of the 16x16x4-MFMA kernels (gemm16.hip); tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  FULL shapes only.
+void launch_sgemm16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);

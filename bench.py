@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="clouds per GPU (configs[1]: 128)")
+    ap.add_argument("--stage", type=int, default=2, choices=(1, 2),
+                    help="2: Stage-II distillation step (BASELINE metric, default); 1: Stage-I autoencoder step (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true")
     args = ap.parse_args()
@@ -92,8 +94,11 @@ def main():
     for n in ("ACT", "Transformer"):
         get_logger(n).setLevel(logging.ERROR)
 
-    config = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml")
-    config.model.dvae_config.ckpt = "none"
+    if args.stage == 2:
+        config = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml")
+        config.model.dvae_config.ckpt = "none"
+    else:
+        config = cfg_from_yaml_file("cfgs/autoencoder/act_dvae_with_pretrained_transformer.yaml")
     torch.manual_seed(0)                                # identical initial weights on every rank
     model = build_model_from_cfg(config.model)
     freeze_unused_heads(model)
@@ -106,7 +111,13 @@ def main():
     B, N = args.batch, 1024
     pool = [synthetic_clouds(B, N, 1234 + rank * 100 + i, device) for i in range(4)]
 
+    if args.stage == 1:
+        from act_amd.tools.runner_autoencoder import train_step as train_step_ae
+
     def step(i):
+        if args.stage == 1:
+            l1, l2, _ = train_step_ae(wrapped, optimizer, pool[i % len(pool)], config, 20000 + i)
+            return l1 + l2
         return train_step(wrapped, optimizer, pool[i % len(pool)].clone(), config)
 
     def barrier():
@@ -129,12 +140,15 @@ def main():
     loss_val = float(loss.item())
 
     out = {
-        "metric": "stage2_pretrain_point_clouds_per_sec", "value": B * world * args.steps / elapsed, "unit": "clouds/s",
+        "metric": "stage2_pretrain_point_clouds_per_sec" if args.stage == 2 else "stage1_autoencoder_point_clouds_per_sec", "value": B * world * args.steps / elapsed, "unit": "clouds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: ACT Stage-II pretrain step (pretrain_act_distill.yaml geometry): "
-                               "B=128 clouds/GPU x 1024 pts, 64 groups x 32 nbrs, 12L d=384 student + 2L decoder, "
-                               "frozen 12L ViT-B teacher (random init), aug+fwd+bwd+AdamW",
+        "config": {"workload": ("configs[1]: ACT Stage-II pretrain step (pretrain_act_distill.yaml geometry): "
+                                "B=128 clouds/GPU x 1024 pts, 64 groups x 32 nbrs, 12L d=384 student + 2L decoder, "
+                                "frozen 12L ViT-B teacher (random init), aug+fwd+bwd+AdamW") if args.stage == 2 else
+                               ("configs[2]: ACT Stage-I autoencoder step (act_dvae_with_pretrained_transformer.yaml geometry): "
+                                "B=%d clouds/GPU x 1024 pts, tokenizer + prompt-tuned frozen ViT-B + FoldingNet, "
+                                "Chamfer-L1 + KL losses, fwd+bwd+AdamW" % B),
                    "clouds_per_gpu": B, "points_per_cloud": N, "parallelism": f"dp{world}", "final_loss": loss_val},
     }
 
@@ -182,7 +196,7 @@ def main():
         out["hip_kernel_ms_per_step"] = tot_ms / nprof
         # ---- FPS + kNN "Group" throughput (BASELINE metric part 2), hipEvents on the current stream ------------------
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        grp = model.group_divider
+        grp = model.group_divider if hasattr(model, "group_divider") else None
         for _ in range(3):
             grp(pool[0])
         reps = 20
@@ -195,7 +209,7 @@ def main():
         out["group_fps_knn"] = {"Mpts_per_s": B * N / (gms * 1e-3) / 1e6, "ms": gms,
                                 "alg_GBs": (fps_b + knn_b) / (gms * 1e-3) / 1e9, "frac_hbm": (fps_b + knn_b) / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.stage == 2:
         try:
             out["cpu_baseline"] = cpu_baseline(config.model)
         except Exception as e:                           # the baseline is a report, never a reason to lose the bench line

@@ -346,7 +346,7 @@ def test_attention_prefix_and_teacher_block_prefix(K):
     assert _rel(out, ref) <= 2e-5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_explicit_configs_and_pipelined_loop(K, tile):
     """every tile shape, with and without the software-pipelined main loop, with and without split-K, all layouts."""
     M, N, Kd = 512, 384, 1024

@@ -205,3 +205,33 @@ def test_stress_geometry_vs_oracle(dev):
     for n in ["ACT_encoder.blocks.blocks.23.mlp.fc1.weight", "ACT_encoder.encoder.second_conv.0.weight", "mask_token",
               "ACT_decoder.blocks.1.attn.qkv.weight", "ACT_encoder.pos_embed.0.weight"]:
         assert _rel(dict(model.named_parameters())[n].grad, od[n].grad) <= 3e-4, n
+
+
+def test_forward_eval_cls_feature_vs_oracle(dev):
+    """model(pts, noaug=True) -> cls feature [B, cls_dim] (models/act.py:1197-1201), no masking, no grad."""
+    from oracle import models as OM, layers as OL
+    torch.manual_seed(4)
+    oracle = fill_module(OM.ACT_PointDistillation(OM.edict(TINY_STAGE2)), "ev.").eval()
+    model = _tiny(dev, "ev.").eval()
+    pts = torch.from_numpy(clouds(9, 3, TINY_N))
+    fo = oracle(pts, OL.Draws(), noaug=True)
+    fg = model(pts.to(dev), noaug=True)
+    assert tuple(fg.shape) == (3, 32) and not fg.requires_grad
+    assert _rel(fg, fo) <= TOL
+
+
+def test_state_dict_keys_match_reference_listing(dev):
+    """key groups of SURVEY 8(b): a reference checkpoint ({'base_model': sd}) must load strictly."""
+    model = _tiny(dev)
+    keys = set(model.state_dict())
+    for k in ["mask_token", "ACT_encoder.cls_token", "ACT_encoder.cls_pos", "ACT_encoder.encoder.first_conv.0.weight",
+              "ACT_encoder.encoder.first_conv.1.running_mean", "ACT_encoder.encoder.second_conv.3.bias", "ACT_encoder.pos_embed.2.weight",
+              "ACT_encoder.blocks.blocks.1.norm1.weight", "ACT_encoder.blocks.blocks.1.attn.qkv.weight", "ACT_encoder.blocks.blocks.1.attn.proj.bias",
+              "ACT_encoder.blocks.blocks.1.mlp.fc2.weight", "ACT_encoder.norm.bias", "ACT_encoder.lm_head.weight", "ACT_encoder.cls_head.2.bias",
+              "dvae_tokenizer.codebook", "dvae_tokenizer.visual_prompt_token", "dvae_tokenizer.deep_prompt_pos", "dvae_tokenizer.encoder.first_conv.0.weight",
+              "dvae_tokenizer.dgcnn_1.layer5.0.weight", "dvae_tokenizer.dgcnn_2.input_trans.bias", "dvae_tokenizer.decoder.final_conv.6.weight",
+              "dvae_tokenizer.visual_embed.0.0.attn.qkv.bias", "dvae_tokenizer.visual_embed.1.weight", "dvae_tokenizer.proj_pre.weight",
+              "dvae_tokenizer.visual_pos_embed.0.weight", "dvae_tokenizer.proj_post.bias", "proj_head.weight", "decoder_pos_embed.2.bias",
+              "ACT_decoder.blocks.0.attn.qkv.weight", "ACT_decoder.norm.weight"]:
+        assert k in keys, k
+    assert not any("qkv.bias" in k for k in keys if k.startswith("ACT_encoder.") or k.startswith("ACT_decoder."))   # qkv_bias=False
