@@ -46,7 +46,7 @@ def freeze_unused_heads(model):
 def wrap_ddp(base_model, args):
     device_ids = [args.local_rank % torch.cuda.device_count()] if torch.cuda.is_available() and args.use_gpu else None
     return nn.parallel.DistributedDataParallel(base_model, device_ids=device_ids, broadcast_buffers=False,
-                                               gradient_as_bucket_view=True, bucket_cap_mb=64)
+                                               gradient_as_bucket_view=True, bucket_cap_mb=25)
 
 
 class _Single(nn.Module):

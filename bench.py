@@ -79,9 +79,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP kernels are the product path; there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_ddp = os.environ.get("ACT_BENCH_FORCE_DDP") == "1"       # exercise the DDP/RCCL path on a single GPU (testing)
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")        # RCCL over xGMI
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)        # RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import act_amd._C as C
@@ -104,7 +106,7 @@ def main():
     freeze_unused_heads(model)
     model.to(device).train()
     ns = argparse.Namespace(local_rank=local_rank, use_gpu=True)
-    wrapped = wrap_ddp(model, ns) if world > 1 else _Single(model)
+    wrapped = wrap_ddp(model, ns) if (world > 1 or force_ddp) else _Single(model)
     optimizer, _ = builder.build_opti_sche(wrapped, config)
     torch.manual_seed(1234 + rank)                      # per-rank draws (main.py:67 seed + local_rank)
 
@@ -215,9 +217,16 @@ def main():
         except Exception as e:                           # the baseline is a report, never a reason to lose the bench line
             out["cpu_baseline"] = {"value": None, "unit": "clouds/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
 
+    if world > 1 or force_ddp:
+        dist.barrier()
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        try:                                             # RCCL prints its version banner through C stdio: flush it first
+            import ctypes                                # so that the JSON line is the last thing on stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+    if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 
