@@ -20,6 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+    os.environ["NCCL_DEBUG"] = "WARN"               # keep RCCL's version banner off stdout (one JSON line contract)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
