@@ -319,6 +319,8 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
             if (nb * sp >= 1024) break;
         }
     }
+    const bool nt16 = tile >= 10 && tile <= 12;         // tiles 10..12 = tiles 1..3, NT-only b128-fragment kernel (gemm16.hip)
+    if (nt16) { if (!(a_kmajor && b_kmajor)) return ACT_E_BADARG; tile -= 9; }
     const bool mi16 = tile >= 7 && tile <= 9;           // tiles 7..9 = tiles 1..3 on v_mfma_f32_16x16x4_f32 (gemm16.hip)
     if (mi16) tile -= 6;
     const bool pipe = tile >= 4 && tile <= 6;           // tiles 4..6 = software-pipelined main loop of tiles 1..3
@@ -339,7 +341,10 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
 
     dim3 grid((unsigned)nt, 1, (unsigned)splits);
     const bool full = vec && (M % BM == 0) && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
-    if (mi16) {
+    if (nt16) {
+        if (!full) return ACT_E_BADARG;
+        launch_sgemm_nt16(p, BM == 128 ? (BN == 128 ? 0 : 1) : 2, grid, s);
+    } else if (mi16) {
         if (!full) return ACT_E_BADARG;
         launch_sgemm16(p, BM == 128 ? (BN == 128 ? 0 : 1) : 2, a_kmajor, b_kmajor, grid, s);
     } else if (BKsel == 32) {

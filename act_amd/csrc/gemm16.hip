@@ -133,12 +133,134 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// NT specialisation (both operands K-contiguous in memory: every forward Linear / Conv1d(k=1)): the LDS image keeps the
+// global layout, [row][16 k] with NO padding, so global float4 -> ds_write_b128 needs no transpose, and one ds_read_b128
+// per operand row-block feeds FOUR MFMA k-steps: lane (m = lane&15, g = lane>>4) reads k = 4g..4g+3 of its row and MFMA
+// step s consumes element s of both operands (the reduction order over k is a permutation, identical for A and B).
+// Bank conflicts of the b128 reads (serviced in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) are removed
+// by XOR-swizzling the 16-byte chunk index with H[(row>>2)&3], H = {0,3,2,1}.  The main loop then contains no VALU address
+// arithmetic at all (row-block strides are ds_read immediates) and 4x fewer LDS instructions than the [k][row] kernels.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) {
+    constexpr int BK = 16;
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int tile_m = wg / p.tiles_n, tile_n = wg % p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int ntiles = (kend - kbeg) / BK;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // global -> register staging: thread v owns the float4 (row = v>>2 (+64 per extra load), chunk = v&3) of each operand tile;
+    // rows 64 apart share the swizzle, so the extra loads are plain immediates on one pointer / one LDS offset per operand
+    const int srow = tid >> 2, sch = tid & 3;
+    const float* ga = p.A + (size_t)(m0 + srow) * p.lda + kbeg + sch * 4;
+    const float* gb = p.B + (size_t)(n0 + srow) * p.ldb + kbeg + sch * 4;
+    const int s_off = srow * 16 + 4 * (sch ^ ((4 - ((srow >> 2) & 3)) & 3));
+    const size_t stride_a = (size_t)64 * p.lda, stride_b = (size_t)64 * p.ldb;
+    // staging registers as named scalars (NA, NB <= 2): arrays indexed inside the helper lambdas are not promoted to
+    // registers by hipcc here and would round-trip through scratch memory in the main loop
+    float4 ra0, ra1, rb0, rb1;
+    ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_g = [&](int t) {
+        ra0 = *reinterpret_cast<const float4*>(ga + t * BK);
+        if constexpr (NA > 1) ra1 = *reinterpret_cast<const float4*>(ga + stride_a + t * BK);
+        rb0 = *reinterpret_cast<const float4*>(gb + t * BK);
+        if constexpr (NB > 1) rb1 = *reinterpret_cast<const float4*>(gb + stride_b + t * BK);
+    };
+    auto store_lds = [&](int buf) {
+        *reinterpret_cast<float4*>(&As[buf][s_off]) = ra0;
+        if constexpr (NA > 1) *reinterpret_cast<float4*>(&As[buf][s_off + 1024]) = ra1;
+        *reinterpret_cast<float4*>(&Bs[buf][s_off]) = rb0;
+        if constexpr (NB > 1) *reinterpret_cast<float4*>(&Bs[buf][s_off + 1024]) = rb1;
+    };
+
+    if (ntiles > 0) {
+        load_g(0);
+        store_lds(0);
+        __syncthreads();
+    }
+    const int kl = lane >> 4, ml = lane & 15;
+    const int hsw = (4 - ((ml >> 2) & 3)) & 3;                        // row-block bases are multiples of 16: H depends on ml only
+    const int a_off = (wm * (BM / 2) + ml) * 16 + 4 * (kl ^ hsw);
+    const int b_off = (wn * (BN / 2) + ml) * 16 + 4 * (kl ^ hsw);
+    auto compute = [&](int buf) {
+        float4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[buf][a_off + i * 256]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_off + j * 256]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) {              // steady state: fetch tile t+1 while computing tile t
+        load_g(t + 1);
+        compute(t & 1);
+        store_lds((t & 1) ^ 1);
+        __syncthreads();
+    }
+    if (ntiles > 0) compute((ntiles - 1) & 1);
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 16 + ml;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 16 + kl * 4 + r;
+                float v = acc[i][j][r];
+                if (p.partial) {
+                    p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v = epilogue_apply(p.epi, v, row, col);
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.epi.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
 template <int BM, int BN>
 static void launch16(const GemmParams& p, int ak, int bk, dim3 grid, hipStream_t s) {
     if (ak && bk)        hipLaunchKernelGGL((sgemm16_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, p);
     else if (ak && !bk)  hipLaunchKernelGGL((sgemm16_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, p);
     else if (!ak && !bk) hipLaunchKernelGGL((sgemm16_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, p);
     else                 hipLaunchKernelGGL((sgemm16_kernel<BM, BN, false, true>), grid, dim3(256), 0, s, p);
+}
+
+void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s) {
+    if (tile == 0)      hipLaunchKernelGGL((sgemm_nt16_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    else if (tile == 1) hipLaunchKernelGGL((sgemm_nt16_kernel<128, 64>), grid, dim3(256), 0, s, p);
+    else                hipLaunchKernelGGL((sgemm_nt16_kernel<64, 64>), grid, dim3(256), 0, s, p);
 }
 
 void launch_sgemm16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s) {

@@ -47,3 +47,5 @@ __device__ __forceinline__ int xcd_remap(int wg, int nwg) {
 
 // launcher of the 16x16x4-MFMA kernels (gemm16.hip); tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  FULL shapes only.
 void launch_sgemm16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
+// NT-only kernels with K-contiguous swizzled LDS image and ds_read_b128 operand fetch (gemm16.hip)
+void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s);

@@ -116,6 +116,8 @@ def _gemm_config(a, b, ak, bk, M, N, K, ws):
         if M % bm == 0 and N % bn == 0 and K % 32 == 0:
             cands += [(tile + 3, s) for s in sp_list if s <= 4 and (K // s) % 32 == 0]       # software-pipelined main loop
             cands += [(tile + 6, s) for s in sp_list if (K // s) % 32 == 0]                  # v_mfma_f32_16x16x4_f32 main loop
+            if ak and bk:
+                cands += [(tile + 9, s) for s in sp_list if (K // s) % 32 == 0]              # NT: K-contiguous LDS image, b128 fragments
     scratch = torch.empty(M, N, dtype=torch.float32, device=a.device)
     e = GemmEpilogue(alpha=1.0)
     best, best_t = (0, 0), float("inf")

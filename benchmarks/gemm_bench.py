@@ -44,7 +44,7 @@ def main():
         ours = min(timeit(lambda: K.gemm(a, b, bool(ak), bool(bk), out=out), reps) for _ in range(3))
         cfgs = {}
         if os.environ.get("GEMM_BENCH_CFGS"):
-            for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+            for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
                 try:
                     tt = min(timeit(lambda: K.gemm(a, b, bool(ak), bool(bk), out=out, cfg=(tile, 1)), reps) for _ in range(2))
                     cfgs[tile] = round(flops / tt / 1e9, 1)
@@ -54,7 +54,7 @@ def main():
         ref = min(timeit(lambda: torch.mm(A2, B2, out=out), reps) for _ in range(3))
         res[tag] = dict(M=M, N=N, K=Kd, ours_us=1e3 * ours, ours_tf=flops / ours / 1e9, torch_us=1e3 * ref, torch_tf=flops / ref / 1e9)
         if cfgs:
-            print(f"    {tag:10s} per-config TF (1:128x128 2:128x64 3:64x64 4-6: pipelined, 7-9: 16x16x4 MFMA): {cfgs}   picked {K._GEMM_CACHE.get((ak, bk, M, N, Kd, 0))}", flush=True)
+            print(f"    {tag:10s} per-config TF (1:128x128 2:128x64 3:64x64 4-6: pipelined, 7-9: 16x16x4 MFMA, 10-12: NT b128): {cfgs}   picked {K._GEMM_CACHE.get((ak, bk, M, N, Kd, 0))}", flush=True)
         print(f"{tag:10s} {M:7d}x{N:5d}x{Kd:6d} ak={ak} bk={bk}  ours {1e3*ours:9.1f} us {flops/ours/1e9:7.1f} TF | torch.mm {1e3*ref:9.1f} us {flops/ref/1e9:7.1f} TF", flush=True)
     print(json.dumps(res))
 

@@ -346,13 +346,15 @@ def test_attention_prefix_and_teacher_block_prefix(K):
     assert _rel(out, ref) <= 2e-5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_gemm_explicit_configs_and_pipelined_loop(K, tile):
     """every tile shape, with and without the software-pipelined main loop, with and without split-K, all layouts."""
     M, N, Kd = 512, 384, 1024
     a = _rnd("cf.a", M, Kd); b = _rnd("cf.b", N, Kd)
     ref = a.double() @ b.double().t()
     for ak, bk in [(True, True), (True, False), (False, False)]:
+        if tile >= 10 and not (ak and bk):
+            continue                                       # tiles 10..12 are NT-only
         A = a.cuda() if ak else a.t().contiguous().cuda()
         Bm = b.cuda() if bk else b.t().contiguous().cuda()
         for sp in (1, 2, 4):
