@@ -112,6 +112,8 @@ def _gemm_config(a, b, ak, bk, M, N, K, ws):
         sp_list = [1]
         if K >= 1024 and nb < 2048:
             sp_list += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nb * s <= 8192]
+        # prune hopeless configurations (a long serial K loop on a handful of workgroups takes tens of ms per trial)
+        sp_list = [s for s in sp_list if not (K // s > 8192 and nb * s < 256) or s == sp_list[-1]]
         cands += [(tile, s) for s in sp_list]
         if M % bm == 0 and N % bn == 0 and K % 32 == 0:
             cands += [(tile + 3, s) for s in sp_list if s <= 4 and (K // s) % 32 == 0]       # software-pipelined main loop
