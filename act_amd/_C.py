@@ -40,6 +40,7 @@ SIGNATURES = {
     "act_gather_points_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "act_gather_points_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "act_scale_translate_f32": [_vp, _vp, _vp, _i, _i, _vp],
+    "act_rotate_points_f32": [_vp, _vp, _i, _i, _vp],
     "act_chamfer_fwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "act_chamfer_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
 }

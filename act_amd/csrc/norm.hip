@@ -303,6 +303,63 @@ extern "C" int act_colsum_f32(const float* in, int R, int C, int ld, float* out,
     ACT_LAUNCH_CHECK(); return 0;
 }
 
+// softmax cross-entropy (nn.CrossEntropyLoss, mean): one wave per row
+__global__ __launch_bounds__(256) void xent_fwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ lab, int R, int C,
+                                                       float* __restrict__ row_buf) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* zr = z + (size_t)row * C;
+    float m = -INFINITY; int am = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) { const float v = zr[c]; if (v > m) { m = v; am = c; } }
+    const float mx = wave_max_f32(m, -INFINITY);
+    int cand = (m == mx) ? am : 0x7fffffff;                         // lowest index attaining the max (torch argmax)
+    cand = -wave_max_i32(-cand, -0x7fffffff);
+    float se = 0.f;
+    for (int c = lane; c < C; c += 64) se += expf(zr[c] - mx);
+    se = wave_sum_f32(se);
+    if (lane == 0) {
+        const float lse = mx + logf(se);
+        const int64_t l = lab[row];
+        row_buf[row] = lse;
+        row_buf[R + row] = lse - zr[l];
+        row_buf[2 * R + row] = (cand == (int)l) ? 1.0f : 0.0f;
+    }
+}
+__global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__ z, const int64_t* __restrict__ lab,
+                                                       const float* __restrict__ row_buf, const float* __restrict__ gout,
+                                                       int R, int C, float inv_rows, float* __restrict__ dz) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)R * C) return;
+    const int row = (int)(i / C), c = (int)(i % C);
+    const float p = expf(z[i] - row_buf[row]);
+    dz[i] = gout[0] * inv_rows * (p - ((int64_t)c == lab[row] ? 1.0f : 0.0f));
+}
+
+extern "C" int act_softmax_xent_fwd_f32(const float* logits, const int64_t* labels, int R, int C, float* loss_out,
+                                        float* row_buf, float* acc_out, act_stream_t stream) {
+    if (!logits || !labels || !loss_out || !row_buf) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_COSINE_FWD, s, 0.0, 4.0 * R * (double)C);
+    hipLaunchKernelGGL(xent_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, s, logits, labels, R, C, row_buf);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, row_buf + R, R, loss_out);
+    if (acc_out) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, row_buf + 2 * (size_t)R, R, acc_out);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" int act_softmax_xent_bwd_f32(const float* logits, const int64_t* labels, const float* row_buf, const float* grad_loss,
+                                        int R, int C, float* grad_logits, act_stream_t stream) {
+    if (!logits || !labels || !row_buf || !grad_loss || !grad_logits) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_COSINE_BWD, s, 0.0, 8.0 * R * (double)C);
+    const long long total = (long long)R * C;
+    hipLaunchKernelGGL(xent_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, logits, labels, row_buf, grad_loss,
+                       R, C, 1.0f / (float)R, grad_logits);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
 extern "C" int act_cosine_loss_fwd_f32(const float* student, const float* teacher, int R, int D, float eps, float* loss_out,
                                        float* row_loss, float* stats, act_stream_t stream) {
     if (!student || !teacher || !loss_out || !row_loss || !stats) return ACT_E_NULLPTR;

@@ -378,3 +378,22 @@ extern "C" int act_scale_translate_f32(float* pc, const float* scale, const floa
     hipLaunchKernelGGL(scale_translate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, pc, scale, shift, N, total);
     ACT_LAUNCH_CHECK(); return 0;
 }
+
+// PointcloudRotate: p' = p @ R[b]  (out_j = sum_k p_k R[k][j]); one thread per point
+__global__ void rotate_points_kernel(float* __restrict__ pc, const float* __restrict__ rot, int N, long long npts) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npts; i += (long long)gridDim.x * blockDim.x) {
+        const float* r = rot + (i / N) * 9;
+        const float x = pc[3 * i], y = pc[3 * i + 1], z = pc[3 * i + 2];
+        pc[3 * i]     = x * r[0] + y * r[3] + z * r[6];
+        pc[3 * i + 1] = x * r[1] + y * r[4] + z * r[7];
+        pc[3 * i + 2] = x * r[2] + y * r[5] + z * r[8];
+    }
+}
+extern "C" int act_rotate_points_f32(float* pc, const float* rot, int B, int N, act_stream_t stream) {
+    if (!pc || !rot) return ACT_E_NULLPTR;
+    const long long npts = (long long)B * N; if (npts == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_AUGMENT, s, 0.0, 24.0 * npts);
+    hipLaunchKernelGGL(rotate_points_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, s, pc, rot, N, npts);
+    ACT_LAUNCH_CHECK(); return 0;
+}

@@ -34,3 +34,33 @@ class ShapeNet(data.Dataset):
 
     def __len__(self):
         return self.num
+
+
+@DATASETS.register_module()
+class ModelNet(data.Dataset):
+    """Synthetic stand-in for ModelNet40 (reference: datasets/ModelNetDataset.py:142-149): yields
+    ``('ModelNet', 'sample', (points[N_POINTS,3] float32, label int))``.  Class c is an anisotropic gaussian whose axis
+    scales and orientation are a fixed function of c, so a classifier can actually learn the labels."""
+
+    def __init__(self, config):
+        self.npoints = config.N_POINTS
+        self.num_category = config.NUM_CATEGORY
+        self.subset = config.subset
+        self.num = int(config.get("NUM_SAMPLES", 512))
+        if not config.get("SYNTHETIC", False):
+            raise NotImplementedError("ModelNet40 files are not shipped; use cfgs/dataset_configs/SyntheticModelNet40.yaml")
+        self.seed = 4321 + (0 if self.subset == "train" else 1)
+
+    def __getitem__(self, index):
+        g = np.random.RandomState((self.seed * 1000003 + index) & 0x7FFFFFFF)
+        label = int(g.randint(self.num_category))
+        c = np.random.RandomState(977 + label)
+        scales = 0.25 + 1.5 * c.rand(3)
+        ang = 2 * np.pi * c.rand()
+        rot = np.array([[np.cos(ang), -np.sin(ang), 0.0], [np.sin(ang), np.cos(ang), 0.0], [0.0, 0.0, 1.0]])
+        pts = (g.standard_normal((self.npoints, 3)) * scales) @ rot.T
+        pts = pc_norm(pts).astype(np.float32)
+        return 'ModelNet', 'sample', (torch.from_numpy(pts), label)
+
+    def __len__(self):
+        return self.num

@@ -32,12 +32,14 @@ _C._declare({
     "act_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "act_cosine_loss_fwd_f32": [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
     "act_cosine_loss_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp],
+    "act_softmax_xent_fwd_f32": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "act_softmax_xent_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
 })
 _C.lib.act_layernorm_bwd_workspace.restype = _sz
 _C.lib.act_colsum_workspace.restype = _sz
 for _n in ("act_sgemm_f32", "act_sgemm_ex_f32", "act_layernorm_fwd_f32", "act_layernorm_bwd_workspace", "act_layernorm_bwd_f32",
            "act_colsum_workspace", "act_colsum_f32", "act_attention_fwd_f32", "act_attention_bwd_f32",
-           "act_cosine_loss_fwd_f32", "act_cosine_loss_bwd_f32"):
+           "act_cosine_loss_fwd_f32", "act_cosine_loss_bwd_f32", "act_softmax_xent_fwd_f32", "act_softmax_xent_bwd_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
 
 lib, ptr, stream, check = _C.lib, _C.ptr, _C.stream, _C.check
@@ -368,6 +370,39 @@ class CosineLossFn(torch.autograd.Function):
 
 def cosine_distill_loss(student, teacher):
     return CosineLossFn.apply(student, teacher).reshape(())
+
+
+class SoftmaxXentFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean) + top-1 accuracy fraction of the same logits (models/act.py:823-830)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        z = _f32c(logits)
+        R, C = z.shape
+        lab = labels.to(torch.int64).contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=z.device)
+        acc = torch.empty(1, dtype=torch.float32, device=z.device)                 # fraction of correct rows
+        buf = torch.empty(3, R, dtype=torch.float32, device=z.device)
+        check(lib.act_softmax_xent_fwd_f32(ptr(z), ptr(lab), R, C, ptr(loss), ptr(buf), ptr(acc), stream()),
+              "act_softmax_xent_fwd_f32")
+        ctx.save_for_backward(z, lab, buf)
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g, _gacc):
+        z, lab, buf = ctx.saved_tensors
+        R, C = z.shape
+        dz = torch.empty_like(z)
+        check(lib.act_softmax_xent_bwd_f32(ptr(z), ptr(lab), ptr(buf), ptr(_f32c(g).reshape(-1)), R, C, ptr(dz), stream()),
+              "act_softmax_xent_bwd_f32")
+        return dz, None
+
+
+def softmax_xent(logits, labels):
+    """-> (mean cross-entropy loss, fraction of rows with arg-max == label), both 0-d tensors on the device."""
+    loss, acc = SoftmaxXentFn.apply(logits, labels)
+    return loss.reshape(()), acc.reshape(())
 
 
 # ---- mini-PointNet / FoldingNet row kernels (csrc/pointnet.hip) --------------------------------------------------

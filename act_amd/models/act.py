@@ -210,6 +210,146 @@ class VisableOnlyMaskTransformer(nn.Module):
 
 
 @MODELS.register_module()
+class PointTransformer(nn.Module):
+    """Finetune / inference classifier on the pretrained student (models/act.py:727-910): Group -> mini-PointNet tokens ->
+    [cls; 64 tokens] through the encoder blocks -> LN -> cat(cls, max over tokens) -> linear or mlp-3 head.  Same config keys,
+    state_dict keys, ``transfer_type`` freezing rules, ``get_loss_acc`` and ``load_model_from_ckpt`` as the reference; every
+    layer runs on the HIP kernels (eval-mode BatchNorm = one affine launch from the running statistics)."""
+
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.config = config
+        self.embed_dim = config.embed_dim
+        self.depth = config.depth
+        self.drop_path_rate = config.drop_path_rate
+        self.cls_dim = config.cls_dim
+        self.num_heads = config.num_heads
+        self.group_size = config.group_size
+        self.num_group = config.num_group
+        self.encoder_dims = config.encoder_dims
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.reduce_dim = nn.Linear(self.encoder_dims, self.embed_dim) if self.encoder_dims != self.embed_dim else nn.Identity()
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(embed_dim=self.embed_dim, depth=self.depth, drop_path_rate=dpr, num_heads=self.num_heads)
+        self.norm = nn.LayerNorm(self.embed_dim)
+        if config.transfer_type == 'linear':
+            self.cls_head_finetune = nn.Sequential(nn.Linear(self.embed_dim * 2, self.cls_dim))
+        else:                                                             # mlp-3 head (the original head)
+            self.cls_head_finetune = nn.Sequential(
+                nn.Linear(self.embed_dim * 2, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+                nn.Linear(256, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+                nn.Linear(256, self.cls_dim))
+        self.build_loss_func()
+        self.setup_side()
+        trunc_normal_(self.cls_token, std=.02)
+        trunc_normal_(self.cls_pos, std=.02)
+        t = config.transfer_type
+        if t != 'full':                                                   # parameter-efficient transfer: freeze by name
+            for name, param in self.named_parameters():
+                if t in ('mlp-3', 'linear'):
+                    keep = 'cls' in name
+                elif t == 'side':
+                    keep = 'side' in name or 'cls' in name
+                elif t == 'bit-fit':
+                    keep = 'bias' in name or 'cls' in name
+                else:
+                    keep = True
+                if not keep:
+                    param.requires_grad = False
+
+    def setup_side(self):
+        if self.config.transfer_type != "side":
+            self.side = None
+        else:
+            self.side_alpha = nn.Parameter(torch.Tensor([0.0]))
+            self.side = Encoder(encoder_channel=self.embed_dim)
+            self.side_projection = nn.Linear(self.embed_dim, self.embed_dim, bias=False)
+
+    def build_loss_func(self):
+        self.loss_ce = nn.CrossEntropyLoss()          # kept for interface parity; get_loss_acc runs the HIP kernel
+
+    def get_loss_acc(self, ret, gt):
+        """-> (mean cross-entropy, top-1 accuracy in percent), both on the device, no host sync."""
+        loss, acc = K.softmax_xent(ret, gt)
+        return loss, acc * 100
+
+    def load_model_from_ckpt(self, bert_ckpt_path, custom_loading=False):
+        if bert_ckpt_path is None:
+            print_log('Training from scratch!!!', logger='Transformer')
+            self.apply(self._init_weights)
+            return
+        ckpt = torch.load(bert_ckpt_path, map_location='cpu')
+        if custom_loading:
+            base_ckpt = {k.replace("module.point_encoder.", ""): v for k, v in ckpt['state_dict'].items()}
+            base_ckpt = {k.replace("encoder", "blocks"): v for k, v in base_ckpt.items()}
+            base_ckpt = {k.replace("patch_embed", "encoder"): v for k, v in base_ckpt.items()}
+        else:
+            base_ckpt = {k.replace("module.", ""): v for k, v in ckpt['base_model'].items()}
+        for k in list(base_ckpt.keys()):
+            if k.startswith('ACT_encoder'):
+                base_ckpt[k[len('ACT_encoder.'):]] = base_ckpt[k]
+                del base_ckpt[k]
+            elif k.startswith('base_model'):
+                base_ckpt[k[len('base_model.'):]] = base_ckpt[k]
+                del base_ckpt[k]
+        incompatible = self.load_state_dict(base_ckpt, strict=False)
+        if incompatible.missing_keys:
+            print_log(f'missing_keys: {incompatible.missing_keys}', logger='Transformer')
+        if incompatible.unexpected_keys:
+            print_log(f'unexpected_keys: {incompatible.unexpected_keys}', logger='Transformer')
+        print_log(f'[Transformer] Successful Loading the ckpt from {bert_ckpt_path}', logger='Transformer')
+
+    def _init_weights(self, m):
+        if isinstance(m, (nn.Linear, nn.Conv1d)):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _head(self, f, draws):
+        h = self.cls_head_finetune
+        if len(h) == 1:
+            return K.linear(f, h[0].weight, h[0].bias)
+        x = f
+        for i in (0, 4):
+            x = K.batch_norm_act(K.linear(x, h[i].weight, h[i].bias), h[i + 1], self.training, relu=True)
+            drop = h[i + 3]
+            if self.training and drop.p > 0:
+                key = "head.drop1" if i == 0 else "head.drop2"
+                mk = lambda: (torch.rand_like(x) >= drop.p).to(x.dtype)
+                keep = draws.get(key, mk) if draws is not None else mk()
+                x = x * (keep.to(x.device) / (1.0 - drop.p))
+        return K.linear(x, h[8].weight, h[8].bias)
+
+    def forward(self, pts, draws=None):
+        neighborhood, center = self.group_divider(pts)
+        tokens = self.encoder(neighborhood)                                                 # B G C
+        if not isinstance(self.reduce_dim, nn.Identity):
+            tokens = K.linear(tokens, self.reduce_dim.weight, self.reduce_dim.bias)
+        B, G, C = tokens.shape
+        if self.side is not None:
+            side = K.linear(self.side(neighborhood), self.side_projection.weight, None)
+        pe = self.pos_embed
+        pos = K.mlp(center, pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias)
+        x = torch.cat((self.cls_token.expand(B, -1, -1), tokens), dim=1)
+        pos = torch.cat((self.cls_pos.expand(B, -1, -1), pos), dim=1)
+        x = self.blocks(x, pos, draws)
+        x = K.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        patch = x[:, 1:]
+        if self.side is not None:
+            a = torch.sigmoid(self.side_alpha)
+            patch = a * patch + (1 - a) * side
+        pooled = K.group_max(patch.reshape(B * G, C), G)                                    # max over the G tokens of a cloud
+        return self._head(torch.cat((x[:, 0], pooled), dim=-1), draws)
+
+
+@MODELS.register_module()
 class ACT_PointDistillation(nn.Module):
     """ACT Stage II: student encoder on visible patches + mask-token decoder regress the frozen teacher's
     features with a cosine loss (models/act.py:1099-1258)."""

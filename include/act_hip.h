@@ -57,6 +57,10 @@ int act_gather_points_bwd_f32(const float* grad_out, const int32_t* idx, int B, 
  * pc[b,n,:] = pc[b,n,:] * scale[b,:] + shift[b,:]   (mul then add, no FMA). */
 int act_scale_translate_f32(float* pc, const float* scale, const float* shift, int B, int N, act_stream_t stream);
 
+/* PointcloudRotate (datasets/data_transforms.py:6-18), in place: pc[b,n,:] = pc[b,n,:] @ R[b] with R[b] row-major [3,3]
+ * (the reference builds R = [[c,0,s],[0,1,0],[-s,0,c]] per sample on the host; any per-sample 3x3 is accepted here). */
+int act_rotate_points_f32(float* pc, const float* rot, int B, int N, act_stream_t stream);
+
 /* ---- Chamfer distance (extensions/chamfer_dist: chamfer_cuda.cpp:12-39, chamfer.cu:15-229) --- */
 /* forward: xyz1 [B,n,3], xyz2 [B,m,3] -> dist1 [B,n], dist2 [B,m] (squared), idx1 int32 [B,n], idx2 int32 [B,m] */
 int act_chamfer_fwd_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
@@ -136,6 +140,16 @@ int act_cosine_loss_fwd_f32(const float* student, const float* teacher, int R, i
                             float* row_loss, float* stats, act_stream_t stream);
 int act_cosine_loss_bwd_f32(const float* student, const float* teacher, const float* stats, const float* grad_loss,
                             int R, int D, float eps, float* grad_student, act_stream_t stream);
+
+/* Classification loss of the finetune path (models/act.py:823-830: nn.CrossEntropyLoss(), mean over rows):
+ * logits [R,C], labels int64 [R] -> loss_out[0] = mean_r (logsumexp(logits_r) - logits_r[label_r]); row_buf [3,R] =
+ * {logsumexp (kept for backward), row loss, arg-max==label flag}; acc_out (nullable) [1] = fraction of rows whose arg-max
+ * (lowest index on ties) equals the label.
+ * backward: grad_logits = grad_loss * (softmax(logits) - onehot(label)) / R. */
+int act_softmax_xent_fwd_f32(const float* logits, const int64_t* labels, int R, int C, float* loss_out, float* row_buf,
+                             float* acc_out, act_stream_t stream);
+int act_softmax_xent_bwd_f32(const float* logits, const int64_t* labels, const float* row_buf, const float* grad_loss,
+                             int R, int C, float* grad_logits, act_stream_t stream);
 
 /* ---- mini-PointNet / FoldingNet row kernels (models/dvae.py:185-275), rows = points, columns = channels ------ */
 /* train-mode BatchNorm1d statistics over all R rows: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale;

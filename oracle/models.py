@@ -7,6 +7,7 @@ Reference files restated (file:line in /root/reference):
   ACTPromptedDiscreteVAEwithVIT       models/dvae.py:360-615
   ACT_PointDistillation               models/act.py:1099-1258
   ChamferDistanceL1/L2                extensions/chamfer_dist/__init__.py:13-84
+  PointTransformer (finetune / inference) models/act.py:727-910
 """
 import math
 import numpy as np
@@ -282,6 +283,93 @@ class ACT_PointDistillation(nn.Module):
         student = self.proj_head(self.ACT_decoder(x_full, pos_full, num_mask, draws))
         teacher = teacher[mask].reshape(B, -1, student.shape[-1])
         return cosine_distill_loss(student, teacher)
+
+
+class PointTransformer(nn.Module):
+    """Finetune / inference classifier (models/act.py:727-910): Group -> mini-PointNet tokens -> [cls; tokens] through the
+    encoder blocks -> LN -> cat(cls, max over tokens) -> head.  Dropout masks of the mlp-3 head come from ``draws``
+    (keys ``head.drop1`` / ``head.drop2``: keep masks, scaled by 1/(1-p))."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embed_dim, self.depth, self.cls_dim = config.embed_dim, config.depth, config.cls_dim
+        self.num_heads, self.encoder_dims = config.num_heads, config.encoder_dims
+        self.group_divider = Group(config.num_group, config.group_size)
+        self.encoder = Encoder(self.encoder_dims)
+        self.reduce_dim = nn.Linear(self.encoder_dims, self.embed_dim) if self.encoder_dims != self.embed_dim \
+            else nn.Identity()
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, config.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(self.embed_dim, self.depth, self.num_heads, dpr, tag="enc")
+        self.norm = nn.LayerNorm(self.embed_dim)
+        if config.transfer_type == 'linear':
+            self.cls_head_finetune = nn.Sequential(nn.Linear(self.embed_dim * 2, self.cls_dim))
+        else:
+            self.cls_head_finetune = nn.Sequential(
+                nn.Linear(self.embed_dim * 2, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+                nn.Linear(256, 256), nn.BatchNorm1d(256), nn.ReLU(inplace=True), nn.Dropout(0.5),
+                nn.Linear(256, self.cls_dim))
+        if config.transfer_type == 'side':
+            self.side_alpha = nn.Parameter(torch.Tensor([0.0]))
+            self.side = Encoder(self.embed_dim)
+            self.side_projection = nn.Linear(self.embed_dim, self.embed_dim, bias=False)
+        else:
+            self.side = None
+        trunc_normal_(self.cls_token); trunc_normal_(self.cls_pos)
+        t = config.transfer_type                       # parameter-efficient transfer: freeze by name (models/act.py:797-808)
+        if t != 'full':
+            for name, p in self.named_parameters():
+                if t in ('mlp-3', 'linear'):
+                    keep = 'cls' in name
+                elif t == 'side':
+                    keep = 'side' in name or 'cls' in name
+                elif t == 'bit-fit':
+                    keep = 'bias' in name or 'cls' in name
+                else:
+                    keep = True
+                if not keep:
+                    p.requires_grad = False
+
+    def _head(self, f, draws):
+        h = self.cls_head_finetune
+        if len(h) == 1:
+            return h[0](f)
+        x = f
+        for i, m in enumerate(h):
+            if isinstance(m, nn.Dropout):
+                if self.training and m.p > 0:
+                    key = "head.drop1" if i == 3 else "head.drop2"
+                    keep = draws.get(key, lambda: (torch.rand_like(x) >= m.p).to(x.dtype))
+                    x = x * keep / (1.0 - m.p)
+            else:
+                x = m(x)
+        return x
+
+    def forward(self, pts, draws=None):
+        draws = draws if draws is not None else Draws()
+        neighborhood, center = self.group_divider(pts)
+        tok = self.reduce_dim(self.encoder(neighborhood))
+        B = tok.shape[0]
+        if self.side is not None:
+            side = self.side_projection(self.side(neighborhood))
+        x = torch.cat((self.cls_token.expand(B, -1, -1), tok), dim=1)
+        pos = torch.cat((self.cls_pos.expand(B, -1, -1), self.pos_embed(center)), dim=1)
+        x = self.norm(self.blocks(x, pos, draws))
+        if self.side is not None:
+            a = torch.sigmoid(self.side_alpha)
+            side = a * x[:, 1:] + (1 - a) * side
+            f = torch.cat([x[:, 0], side.max(1)[0]], dim=-1)
+        else:
+            f = torch.cat([x[:, 0], x[:, 1:].max(1)[0]], dim=-1)
+        return self._head(f, draws)
+
+    def get_loss_acc(self, ret, gt):
+        loss = F.cross_entropy(ret, gt.long())
+        acc = (ret.argmax(-1) == gt).sum() / float(gt.size(0))
+        return loss, acc * 100
 
 
 def param_groups(model, weight_decay):

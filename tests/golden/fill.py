@@ -65,3 +65,7 @@ TINY_STAGE2 = dict(
                      visual_embed_depth=2, visual_embed_heads=2),
 )
 TINY_B, TINY_N = 2, 128
+
+TINY_FINETUNE = dict(NAME="PointTransformer", embed_dim=64, depth=2, drop_path_rate=0.0, cls_dim=10, num_heads=2,
+                     group_size=8, num_group=16, encoder_dims=32, transfer_type="full")
+TINY_FT_LABELS = [3, 1, 4, 1]

@@ -189,3 +189,34 @@ def test_cosine_loss_and_augment():
     g = golden("g9_augment")
     out = OP.scale_translate_ref(clouds(9, 2, 128), g["scale"], g["shift"])
     _close(out, g["out"], 1e-6)
+
+
+@pytest.mark.parametrize("ttype", ["full", "linear", "side"])
+def test_g10_point_transformer_finetune(ttype):
+    """oracle PointTransformer == the reference's (models/act.py:727-910) on the tiny finetune config."""
+    from tests.golden.fill import TINY_FINETUNE, TINY_FT_LABELS
+    g = golden("g10_finetune")
+    model = fill_module(M.PointTransformer(M.edict(dict(TINY_FINETUNE, transfer_type=ttype))), f"g10.{ttype}.")
+    if ttype == "side":
+        with torch.no_grad():
+            model.side_alpha.fill_(0.3)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    pts = torch.from_numpy(clouds(10, 4, 128))
+    label = torch.tensor(TINY_FT_LABELS)
+    model.train()
+    logits = model(pts)
+    loss, acc = model.get_loss_acc(logits, label)
+    np.testing.assert_allclose(logits.detach().numpy(), g[f"{ttype}_logits_train"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(loss.item(), g[f"{ttype}_loss"], rtol=1e-5)
+    assert float(acc) == float(g[f"{ttype}_acc"])
+    if ttype != "linear":
+        names = [str(n) for n in g[f"{ttype}_trainable"]]
+        assert sorted(names) == sorted(n for n, p in model.named_parameters() if p.requires_grad)
+        loss.backward()
+        norms = np.array([dict(model.named_parameters())[n].grad.norm().item() for n in names])
+        np.testing.assert_allclose(norms, g[f"{ttype}_grad_norms"], rtol=2e-3, atol=1e-7)
+    model.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(model(pts).numpy(), g[f"{ttype}_logits_eval"], atol=2e-5, rtol=1e-4)
