@@ -383,6 +383,220 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Attention backward on the matrix cores (fp32-input v_mfma_f32_32x32x2).  One workgroup (4 waves) per (cloud, head); keys come
+// from two sources (S0 "prefix" rows of kv0, then the Sq rows of qkv1), so the same kernel serves plain self-attention (S0 = 0)
+// and the prompt-prefix attention of the prompt-tuned Transformer (models/dvae.py:536-576).  Per (64-key, 64-query) tile pair:
+//   S = Q K^T -> P = exp(scale S - lse) ; dP = dO V^T ; dS = P (dP - D) scale            (wave = one 32x32 quadrant, in regs)
+//   dV += P^T dO ; dK += dS^T Q   (accumulated in registers over the query tiles, one [32 keys x 32 dims] quadrant per wave)
+//   dQ (+)= dS K                  (accumulated over key tiles through global memory: the workgroup owns its dQ rows)
+// Operands of the two head-dimension reductions (S, dP) never touch LDS: the MFMA k-index is free to be any permutation as
+// long as A and B agree, so lane half 0 reduces d in [0,HD/2) and half 1 d in [HD/2,HD) and each lane keeps HD/2 CONTIGUOUS
+// floats of its Q / dO / K / V row in registers (float4 global loads, K/V fragments live across the query loop).
+// The three row reductions take their B operand from row-major LDS tiles Q, dO, K [64][HD] (two consecutive rows land in
+// opposite bank halves through an XOR-32 column swizzle) and their A operand from one P/dS tile [64][65].
+// Invalid rows are zero-filled and masked out of P; quadrants and reduction ranges made of padding only are skipped.
+struct AttnBwdArgs {
+    const float* kv0; const float* qkv1; const float* out; const float* dout; const float* lse;
+    float* dkv0; float* dqkv1;
+    int B, S0, Sq, H; float scale;
+};
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int HD, int OCC>
+__global__ __launch_bounds__(256, OCC) void attn_bwd_mfma_kernel(const AttnBwdArgs a) {
+    constexpr int LDP = 65, DQ = HD / 4, T = 64, FR = HD / 8;      // FR float4 per lane fragment (HD/2 floats)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem; float* Os = Qs + T * HD; float* Ks = Os + T * HD;
+    float* Ps = Ks + T * HD; float* Dl = Ps + T * LDP; float* Ll = Dl + T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, khalf = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;               // quadrant of a 64x64 (or 64xHD) tile owned by this wave
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int D = a.H * HD, rs1 = 3 * D, rs0 = 2 * D;
+    const int Skv = a.S0 + a.Sq;
+    const float* q_base = a.qkv1 + (size_t)b * a.Sq * rs1 + h * HD;
+    float* dq_base = a.dqkv1 + (size_t)b * a.Sq * rs1 + h * HD;
+    const bool colq = wc * 32 < HD;                         // HD = 32: only the wc = 0 waves own an output quadrant
+    // column of this lane inside a row-major [row][HD] tile for the B-operand fetches of rows (2j + khalf)
+    const int bcol = HD == 64 ? ((wc * 32 + l32) ^ (32 * khalf)) : l32;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int k0 = 0; k0 < Skv; k0 += T) {
+        const int kn = min(T, Skv - k0);
+        __syncthreads();                                    // previous key tile fully consumed
+        for (int idx = tid; idx < T * DQ; idx += 256) {     // K tile -> LDS (B operand of dQ)
+            const int c4 = idx % DQ, row = idx / DQ, kr = k0 + row;
+            float4 kx = z4;
+            if (row < kn)
+                kx = kr < a.S0 ? *reinterpret_cast<const float4*>(a.kv0 + ((size_t)b * a.S0 + kr) * rs0 + h * HD + c4 * 4)
+                               : *reinterpret_cast<const float4*>(q_base + (size_t)(kr - a.S0) * rs1 + D + c4 * 4);
+            const int col = HD == 64 ? ((c4 * 4) ^ (32 * (row & 1))) : c4 * 4;
+            *reinterpret_cast<float4*>(Ks + row * HD + col) = kx;
+        }
+        // K / V register fragments of this wave's key rows (wc) for the S and dP products
+        float4 kf[FR], vf[FR];
+        {
+            const int row = wc * 32 + l32, kr = k0 + row;
+#pragma unroll
+            for (int i = 0; i < FR; ++i) { kf[i] = z4; vf[i] = z4; }
+            if (row < kn) {
+                const float* kb = kr < a.S0 ? a.kv0 + ((size_t)b * a.S0 + kr) * rs0 + h * HD : q_base + (size_t)(kr - a.S0) * rs1 + D;
+                const float* vb = kb + D;
+#pragma unroll
+                for (int i = 0; i < FR; ++i) {
+                    kf[i] = *reinterpret_cast<const float4*>(kb + khalf * (HD / 2) + 4 * i);
+                    vf[i] = *reinterpret_cast<const float4*>(vb + khalf * (HD / 2) + 4 * i);
+                }
+            }
+        }
+        f32x16 dk_acc, dv_acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk_acc[r] = 0.f; dv_acc[r] = 0.f; }
+
+        for (int q0 = 0; q0 < a.Sq; q0 += T) {
+            const int qn = min(T, a.Sq - q0);
+            __syncthreads();                                // previous query tile fully consumed (and K staged)
+            for (int idx = tid; idx < T * DQ; idx += 256) {             // DQ consecutive lanes own one row
+                const int c4 = idx % DQ, row = idx / DQ;
+                float4 qx = z4, ox = z4, tx = z4;
+                if (row < qn) {
+                    const size_t o = ((size_t)b * a.Sq + q0 + row) * D + h * HD + c4 * 4;
+                    qx = *reinterpret_cast<const float4*>(q_base + (size_t)(q0 + row) * rs1 + c4 * 4);
+                    ox = *reinterpret_cast<const float4*>(a.dout + o);
+                    tx = *reinterpret_cast<const float4*>(a.out + o);
+                }
+                const int col = HD == 64 ? ((c4 * 4) ^ (32 * (row & 1))) : c4 * 4;
+                *reinterpret_cast<float4*>(Qs + row * HD + col) = qx;
+                *reinterpret_cast<float4*>(Os + row * HD + col) = ox;
+                // D[q] = sum_d dO[q][d] * O[q][d]: reduce the DQ per-lane partials inside the 16-lane DPP row
+                float part = ox.x * tx.x + ox.y * tx.y + ox.z * tx.z + ox.w * tx.w;
+                part += dpp_mov_f<0x111, 0xf>(0.f, part);
+                part += dpp_mov_f<0x112, 0xf>(0.f, part);
+                part += dpp_mov_f<0x114, 0xf>(0.f, part);
+                if (DQ == 16) part += dpp_mov_f<0x118, 0xf>(0.f, part);
+                if (c4 == DQ - 1) Dl[row] = part;
+                if (c4 == 0) Ll[row] = row < qn ? a.lse[((size_t)b * a.H + h) * a.Sq + q0 + row] : 0.f;
+            }
+            // ---- S and dP quadrants [32 queries (wr) x 32 keys (wc)], reduction over the head dimension from registers
+            f32x16 s_acc, p_acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s_acc[r] = 0.f; p_acc[r] = 0.f; }
+            if (wr * 32 < qn && wc * 32 < kn) {             // quadrants made of padding only stay zero
+                const int row = wr * 32 + l32;
+                float4 qf[FR], of[FR];
+#pragma unroll
+                for (int i = 0; i < FR; ++i) { qf[i] = z4; of[i] = z4; }
+                if (row < qn) {
+                    const float* qb = q_base + (size_t)(q0 + row) * rs1 + khalf * (HD / 2);
+                    const float* ob = a.dout + ((size_t)b * a.Sq + q0 + row) * D + h * HD + khalf * (HD / 2);
+#pragma unroll
+                    for (int i = 0; i < FR; ++i) {
+                        qf[i] = *reinterpret_cast<const float4*>(qb + 4 * i);
+                        of[i] = *reinterpret_cast<const float4*>(ob + 4 * i);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < FR; ++i) {
+                    s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[i].x, kf[i].x, s_acc, 0, 0, 0);
+                    p_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(of[i].x, vf[i].x, p_acc, 0, 0, 0);
+                    s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[i].y, kf[i].y, s_acc, 0, 0, 0);
+                    p_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(of[i].y, vf[i].y, p_acc, 0, 0, 0);
+                    s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[i].z, kf[i].z, s_acc, 0, 0, 0);
+                    p_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(of[i].z, vf[i].z, p_acc, 0, 0, 0);
+                    s_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[i].w, kf[i].w, s_acc, 0, 0, 0);
+                    p_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(of[i].w, vf[i].w, p_acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();                                // Q / dO tiles, D and lse visible
+            const int kk = wc * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const float p = (qq < qn && kk < kn) ? __expf(a.scale * s_acc[r] - Ll[qq]) : 0.f;
+                Ps[qq * LDP + kk] = p;
+                s_acc[r] = p * (p_acc[r] - Dl[qq]) * a.scale;          // dS, kept in registers until P has been consumed
+            }
+            __syncthreads();
+            const int qn2 = (qn + 7) & ~7, kn2 = (kn + 7) & ~7;       // reductions stop at the valid rows (zero padding beyond)
+            // ---- dV[k][d] += sum_q P[q][k] dO[q][d]     quadrant: keys wr, dims wc
+            if (colq && wr * 32 < kn) {
+                const float* pa = Ps + khalf * LDP + wr * 32 + l32;
+                const float* ob = Os + khalf * HD + bcol;
+#pragma unroll 4
+                for (int q = 0; q < qn2; q += 2)
+                    dv_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[q * LDP], ob[q * HD], dv_acc, 0, 0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                Ps[qq * LDP + kk] = s_acc[r];
+            }
+            __syncthreads();
+            if (colq && wr * 32 < kn) {
+                // ---- dK[k][d] += sum_q dS[q][k] Q[q][d]
+                const float* pa = Ps + khalf * LDP + wr * 32 + l32;
+                const float* qb = Qs + khalf * HD + bcol;
+#pragma unroll 4
+                for (int q = 0; q < qn2; q += 2)
+                    dk_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[q * LDP], qb[q * HD], dk_acc, 0, 0, 0);
+            }
+            if (colq && wr * 32 < qn) {
+                // ---- dQ[q][d] (+)= sum_k dS[q][k] K[k][d]   quadrant: queries wr, dims wc
+                f32x16 dq_acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq_acc[r] = 0.f;
+                const float* sa = Ps + (wr * 32 + l32) * LDP + khalf;
+                const float* kb2 = Ks + khalf * HD + bcol;
+#pragma unroll 4
+                for (int k = 0; k < kn2; k += 2)
+                    dq_acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[k], kb2[k * HD], dq_acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qq = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (qq < qn) {
+                        float* dst = dq_base + (size_t)(q0 + qq) * rs1 + wc * 32 + l32;
+                        *dst = k0 == 0 ? dq_acc[r] : *dst + dq_acc[r];
+                    }
+                }
+            }
+        }
+        if (colq) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kq = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf, kr = k0 + kq;
+                if (kq < kn) {
+                    if (kr < a.S0) {
+                        float* dst = a.dkv0 + ((size_t)b * a.S0 + kr) * rs0 + h * HD + wc * 32 + l32;
+                        dst[0] = dk_acc[r]; dst[D] = dv_acc[r];
+                    } else {
+                        float* dst = dq_base + (size_t)(kr - a.S0) * rs1 + wc * 32 + l32;
+                        dst[D] = dk_acc[r]; dst[2 * D] = dv_acc[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int HD>
+static int launch_attn_bwd_mfma_t(const AttnBwdArgs& a, hipStream_t s) {
+    const size_t smem = ((size_t)3 * 64 * HD + 64 * 65 + 128) * sizeof(float);
+    static const int occ = [] { const char* e = getenv("ACT_ATTN_BWD_OCC"); return e ? atoi(e) : 2; }();     // dev knob
+    auto k = occ == 1 ? attn_bwd_mfma_kernel<HD, 1> : attn_bwd_mfma_kernel<HD, 2>;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)(a.B * a.H)), dim3(256), smem, s, a);
+    ACT_LAUNCH_CHECK();
+    return 0;
+}
+static int launch_attn_bwd_mfma(const AttnBwdArgs& a, int head_dim, hipStream_t s) {
+    return head_dim == 64 ? launch_attn_bwd_mfma_t<64>(a, s) : launch_attn_bwd_mfma_t<32>(a, s);
+}
+
 template <int HD, int JT, int QT>
 static int launch_attn_fwd3(const AttnFwdArgs& a, hipStream_t s) {
     constexpr int pairs = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
@@ -447,6 +661,15 @@ extern "C" int act_attention_bwd_f32(const float* qkv, const float* out, const f
     if (!qkv || !out || !dout || !lse || !dqkv) return ACT_E_NULLPTR;
     if (B < 0 || S <= 0 || H <= 0 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
     if (B == 0) return 0;
+    static const bool use_valu = [] { const char* e = getenv("ACT_ATTN_BWD_VALU"); return e && e[0] == '1'; }();   // dev A/B knob
+    if (!use_valu) {
+        hipStream_t s = (hipStream_t)stream;
+        ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)S * S * head_dim, 28.0 * B * S * (double)H * head_dim);
+        AttnBwdArgs a;
+        a.kv0 = nullptr; a.qkv1 = qkv; a.out = out; a.dout = dout; a.lse = lse; a.dkv0 = nullptr; a.dqkv1 = dqkv;
+        a.B = B; a.S0 = 0; a.Sq = S; a.H = H; a.scale = scale;
+        return launch_attn_bwd_mfma(a, head_dim, s);
+    }
     const int S4 = (S + 3) & ~3;
     const int KR = S4 < ATT_KC ? S4 : ATT_KC;
     const size_t smem = ((size_t)2 * KR * (head_dim + 4) + (size_t)2 * ATT_QC * (head_dim + 4) + (size_t)ATT_QC * (KR + 4) + 2 * ATT_QC) * sizeof(float);
@@ -459,4 +682,20 @@ extern "C" int act_attention_bwd_f32(const float* qkv, const float* out, const f
 #undef BWD
     ACT_LAUNCH_CHECK();
     return 0;
+}
+
+// backward of act_attention_fwd_prefix_f32: dqkv1 [B,Sq,3,H,hd] (dQ, and dK/dV of the Sq own rows), dkv0 [B,S0,2,H,hd].
+extern "C" int act_attention_bwd_prefix_f32(const float* kv0, int S0, const float* qkv1, int Sq, const float* out, const float* dout,
+                                            const float* lse, float* dkv0, float* dqkv1, int B, int H, int head_dim, float scale,
+                                            act_stream_t stream) {
+    if (!qkv1 || !out || !dout || !lse || !dqkv1 || (S0 > 0 && (!kv0 || !dkv0))) return ACT_E_NULLPTR;
+    if (B < 0 || Sq <= 0 || S0 < 0 || H <= 0 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)Sq * (S0 + Sq) * head_dim,
+                    4.0 * B * (double)H * head_dim * (8.0 * Sq + 4.0 * S0));
+    AttnBwdArgs a;
+    a.kv0 = kv0; a.qkv1 = qkv1; a.out = out; a.dout = dout; a.lse = lse; a.dkv0 = dkv0; a.dqkv1 = dqkv1;
+    a.B = B; a.S0 = S0; a.Sq = Sq; a.H = H; a.scale = scale;
+    return launch_attn_bwd_mfma(a, head_dim, s);
 }

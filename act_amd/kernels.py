@@ -573,19 +573,74 @@ def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, 
     return out, index, logits
 
 
-_C._declare({"act_attention_fwd_prefix_f32": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]})
+_C._declare({"act_attention_fwd_prefix_f32": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp],
+             "act_attention_bwd_prefix_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]})
 _C.lib.act_layernorm_bwd_workspace.restype = _sz
 _C.lib.act_colsum_workspace.restype = _sz
 _C.lib.act_colstats_workspace.restype = _sz
 _C.SIGNATURES.setdefault("act_attention_fwd_prefix_f32", _C.lib.act_attention_fwd_prefix_f32.argtypes)
+_C.SIGNATURES.setdefault("act_attention_bwd_prefix_f32", _C.lib.act_attention_bwd_prefix_f32.argtypes)
 
 
-def attention_fwd_prefix(kv0, S0, qkv1, Sq, B, H, hd):
+def attention_fwd_prefix(kv0, S0, qkv1, Sq, B, H, hd, want_lse=False):
     """queries = the Sq rows of qkv1 [B*Sq, 3*H*hd]; keys/values = S0 rows of kv0 [B*S0, 2*H*hd] then the rows of qkv1."""
     out = torch.empty(B * Sq, H * hd, dtype=torch.float32, device=qkv1.device)
-    check(lib.act_attention_fwd_prefix_f32(ptr(_f32c(kv0)), S0, ptr(_f32c(qkv1)), Sq, ptr(out), None, B, H, hd, float(hd) ** -0.5,
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=qkv1.device) if want_lse else None
+    check(lib.act_attention_fwd_prefix_f32(ptr(_f32c(kv0)), S0, ptr(_f32c(qkv1)), Sq, ptr(out), ptr(lse), B, H, hd, float(hd) ** -0.5,
                                            stream()), "act_attention_fwd_prefix_f32")
-    return out
+    return (out, lse) if want_lse else out
+
+
+def attention_bwd_prefix(kv0, S0, qkv1, Sq, out, dout, lse, B, H, hd):
+    """-> (dkv0 [B*S0, 2*H*hd], dqkv1 [B*Sq, 3*H*hd])"""
+    dkv0 = torch.empty_like(kv0)
+    dqkv1 = torch.empty_like(qkv1)
+    check(lib.act_attention_bwd_prefix_f32(ptr(kv0), S0, ptr(qkv1), Sq, ptr(out), ptr(_f32c(dout)), ptr(lse), ptr(dkv0), ptr(dqkv1),
+                                           B, H, hd, float(hd) ** -0.5, stream()), "act_attention_bwd_prefix_f32")
+    return dkv0, dqkv1
+
+
+class PrefixBlockFn(torch.autograd.Function):
+    """Pre-LN block on G patch tokens per cloud with P prompt tokens acting as keys/values only, WITH backward to the patch
+    tokens, their positions and the prompts (Stage-I prompt tuning of the frozen Transformer, models/dvae.py:536-576: every
+    layer replaces the prompt rows of its input and the output drops them, so prompt rows never need queries / proj / MLP).
+    The block weights are frozen (freeze_visual_embed: True); inputs x2d [B*G,D], pos2d [B*G,D], prm2d [B*P,D] = prompt+pos."""
+
+    @staticmethod
+    def forward(ctx, x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps):
+        D = x2d.shape[1]
+        hd = D // heads
+        n1p, _, meanp, rstdp = layernorm_fwd(_f32c(prm2d), None, n1w, n1b, eps, want_stats=True)
+        kvp = gemm(n1p, wqkv[D:], True, True, bias=(bqkv[D:] if bqkv is not None else None))
+        n1x, xin, mean1, rstd1 = layernorm_fwd(_f32c(x2d), _f32c(pos2d), n1w, n1b, eps, want_stats=True)
+        qkvx = gemm(n1x, wqkv, True, True, bias=bqkv)
+        att, lse = attention_fwd_prefix(kvp, P, qkvx, G, B, heads, hd, want_lse=True)
+        x1 = gemm(att, wproj, True, True, bias=bproj, res=xin)
+        n2, _, mean2, rstd2 = layernorm_fwd(x1, None, n2w, n2b, eps, want_stats=True)
+        hpre = torch.empty(B * G, w1.shape[0], dtype=torch.float32, device=x2d.device)
+        a = gemm(n2, w1, True, True, bias=b1, act=EPI_GELU, aux=hpre)
+        x2 = gemm(a, w2, True, True, bias=b2, res=x1)
+        ctx.save_for_backward(prm2d, meanp, rstdp, kvp, xin, mean1, rstd1, qkvx, att, lse, x1, mean2, rstd2, hpre,
+                              n1w, wqkv, wproj, n2w, w1, w2)
+        ctx.dims = (B, P, G, D, heads, hd)
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (prm2d, meanp, rstdp, kvp, xin, mean1, rstd1, qkvx, att, lse, x1, mean2, rstd2, hpre,
+         n1w, wqkv, wproj, n2w, w1, w2) = ctx.saved_tensors
+        B, P, G, D, heads, hd = ctx.dims
+        dx2 = _f32c(dx2)
+        dh = gemm(dx2, w2, True, False, act=EPI_MUL_GELU_GRAD, aux=hpre)
+        dn2 = gemm(dh, w1, True, False)
+        dx1, _, _ = layernorm_bwd(dn2, x1, n2w, mean2, rstd2, dres=dx2, want_params=False)
+        datt = gemm(dx1, wproj, True, False)
+        dkvp, dqkvx = attention_bwd_prefix(kvp, P, qkvx, G, att, datt, lse, B, heads, hd)
+        dn1x = gemm(dqkvx, wqkv, True, False)
+        dxin, _, _ = layernorm_bwd(dn1x, xin, n1w, mean1, rstd1, dres=dx1, want_params=False)
+        dn1p = gemm(dkvp, wqkv[D:], True, False)
+        dprm, _, _ = layernorm_bwd(dn1p, prm2d, n1w, meanp, rstdp, dres=None, want_params=False)
+        return (dxin, dxin, dprm) + (None,) * 17
 
 
 def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps):

@@ -350,10 +350,34 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         feature = K.layer_norm(x, nrm.weight, nrm.bias, nrm.eps)
         return K.linear(feature, self.proj_post.weight, self.proj_post.bias).reshape(B, G, -1)
 
+    def _visual_embedding_prefix_train(self, input, center, draws=None):
+        """Stage-I training form of the same restructuring (frozen block weights, learnable prompts / projections): gradients
+        reach the prompts through their keys/values only, exactly as in the reference graph."""
+        B, G, _ = input.shape
+        Pn, D = self.num_prompt_token, self.visual_embed_dim
+        vp = self.visual_pos_embed
+        pos = K.mlp(center, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias).reshape(B * G, D)
+        x = K.linear(input, self.proj_pre.weight, self.proj_pre.bias).reshape(B * G, D)
+        blocks = self.visual_embed[0]
+        for i in range(self.visual_embed_depth):
+            tok = self.visual_prompt_token[0] if i == 0 else self.deep_prompt_tokens[i - 1]
+            ppos = self.visual_prompt_pos[0] if i == 0 else self.deep_prompt_pos[i - 1]
+            prm = (self._drop(tok.unsqueeze(0).expand(B, -1, -1), draws, f"prompt.{i}") + ppos).reshape(B * Pn, D)
+            blk = blocks[i]
+            a, m = blk.attn, blk.mlp
+            x = K.PrefixBlockFn.apply(x, pos, prm, B, Pn, G, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias,
+                                      a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias,
+                                      m.fc2.weight, m.fc2.bias, blk.num_heads, blk.eps)
+        nrm = self.visual_embed[1]
+        feature = K.layer_norm(x, nrm.weight, nrm.bias, nrm.eps)
+        return K.linear(feature, self.proj_post.weight, self.proj_post.bias).reshape(B, G, -1)
+
     def visual_embedding_deep_prompt(self, input, center, permute_feature=False, draws=None):
         """models/dvae.py:536-576 (+ incorporate_prompt :485-498): prompts replaced (not appended) at layers 1..L-1."""
         if not torch.is_grad_enabled():
             return self._visual_embedding_prefix(input, center, draws)
+        if self.freeze_visual_embed:
+            return self._visual_embedding_prefix_train(input, center, draws)
         B, G, _ = input.shape
         Pn = self.num_prompt_token
         vp = self.visual_pos_embed

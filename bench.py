@@ -67,9 +67,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="clouds per GPU (configs[1]: 128)")
-    ap.add_argument("--stage", type=int, default=2, choices=(1, 2),
-                    help="2: Stage-II distillation step (BASELINE metric, default); 1: Stage-I autoencoder step (configs[2])")
+    ap.add_argument("--batch", type=int, default=None, help="clouds per GPU (default: 128 for stages 1/2/4, 32 for stage 3)")
+    ap.add_argument("--stage", type=int, default=2, choices=(1, 2, 3, 4),
+                    help="2: Stage-II distillation step (BASELINE metric, default); 1: Stage-I autoencoder step (configs[2]); "
+                         "3: PointTransformer finetune step (finetune_modelnet.yaml: 8192 raw pts -> FPS 1200 -> 1024, fwd+bwd+AdamW); "
+                         "4: PointTransformer inference (eval, FPS 8192 -> 1024 + forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true")
     args = ap.parse_args()
@@ -98,11 +100,15 @@ def main():
     for n in ("ACT", "Transformer"):
         get_logger(n).setLevel(logging.ERROR)
 
+    if args.batch is None:
+        args.batch = 32 if args.stage == 3 else 128
     if args.stage == 2:
         config = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml")
         config.model.dvae_config.ckpt = "none"
-    else:
+    elif args.stage == 1:
         config = cfg_from_yaml_file("cfgs/autoencoder/act_dvae_with_pretrained_transformer.yaml")
+    else:
+        config = cfg_from_yaml_file("cfgs/finetune_classification/full/finetune_modelnet.yaml")
     torch.manual_seed(0)                                # identical initial weights on every rank
     model = build_model_from_cfg(config.model)
     freeze_unused_heads(model)
@@ -113,12 +119,24 @@ def main():
     torch.manual_seed(1234 + rank)                      # per-rank draws (main.py:67 seed + local_rank)
 
     B, N = args.batch, 1024
-    pool = [synthetic_clouds(B, N, 1234 + rank * 100 + i, device) for i in range(4)]
+    n_raw = 8192 if args.stage >= 3 else N              # the finetune loaders hand over 8192-point clouds (ModelNet40.yaml)
+    pool = [synthetic_clouds(B, n_raw, 1234 + rank * 100 + i, device) for i in range(4)]
 
     if args.stage == 1:
         from act_amd.tools.runner_autoencoder import train_step as train_step_ae
+    if args.stage >= 3:
+        from act_amd.tools.runner_finetune import train_step as train_step_ft
+        from act_amd.utils import misc
+        labels = torch.randint(0, config.model.cls_dim, (B,), device=device)
+        if args.stage == 4:
+            model.eval()
 
     def step(i):
+        if args.stage == 3:
+            return train_step_ft(wrapped, optimizer, pool[i % len(pool)], labels, config)[0]
+        if args.stage == 4:
+            with torch.no_grad():
+                return model(misc.fps(pool[i % len(pool)], N)).sum()
         if args.stage == 1:
             l1, l2, _ = train_step_ae(wrapped, optimizer, pool[i % len(pool)], config, 20000 + i)
             return l1 + l2
@@ -144,12 +162,18 @@ def main():
     loss_val = float(loss.item())
 
     out = {
-        "metric": "stage2_pretrain_point_clouds_per_sec" if args.stage == 2 else "stage1_autoencoder_point_clouds_per_sec", "value": B * world * args.steps / elapsed, "unit": "clouds/s",
+        "metric": {1: "stage1_autoencoder_point_clouds_per_sec", 2: "stage2_pretrain_point_clouds_per_sec",
+                   3: "finetune_cls_point_clouds_per_sec", 4: "inference_cls_point_clouds_per_sec"}[args.stage], "value": B * world * args.steps / elapsed, "unit": "clouds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": ("configs[1]: ACT Stage-II pretrain step (pretrain_act_distill.yaml geometry): "
                                 "B=128 clouds/GPU x 1024 pts, 64 groups x 32 nbrs, 12L d=384 student + 2L decoder, "
                                 "frozen 12L ViT-B teacher (random init), aug+fwd+bwd+AdamW") if args.stage == 2 else
+                               ("PointTransformer finetune step (finetune_modelnet.yaml): B=%d clouds/GPU x 8192 raw pts -> FPS 1200 -> "
+                                "random 1024, rotate, 64 groups x 32 nbrs, 12L d=384 + mlp-3 head, CE loss, fwd+bwd+clip+AdamW" % B)
+                               if args.stage == 3 else
+                               ("PointTransformer inference (eval mode): B=%d clouds/GPU x 8192 raw pts -> FPS 1024 -> forward" % B)
+                               if args.stage == 4 else
                                ("configs[2]: ACT Stage-I autoencoder step (act_dvae_with_pretrained_transformer.yaml geometry): "
                                 "B=%d clouds/GPU x 1024 pts, tokenizer + prompt-tuned frozen ViT-B + FoldingNet, "
                                 "Chamfer-L1 + KL losses, fwd+bwd+AdamW" % B),
@@ -201,12 +225,13 @@ def main():
         # ---- FPS + kNN "Group" throughput (BASELINE metric part 2), hipEvents on the current stream ------------------
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         grp = model.group_divider if hasattr(model, "group_divider") else None
+        gpts = pool[0][:, :N].contiguous()
         for _ in range(3):
-            grp(pool[0])
+            grp(gpts)
         reps = 20
         ev0.record()
         for _ in range(reps):
-            grp(pool[0])
+            grp(gpts)
         ev1.record(); torch.cuda.synchronize()
         gms = ev0.elapsed_time(ev1) / reps
         fps_b, knn_b = 13312.0 * B, 54016.0 * B                    # algorithmic bytes / cloud

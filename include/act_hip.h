@@ -133,6 +133,11 @@ int act_attention_fwd_prefix_f32(const float* kv0, int S0, const float* qkv1, in
                                  int H, int head_dim, float scale, act_stream_t stream);
 int act_attention_bwd_f32(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                           int B, int S, int H, int head_dim, float scale, act_stream_t stream);
+/* backward of the prefix variant: dqkv1 [B,Sq,3,H,hd] receives dQ and the dK/dV of the Sq own rows, dkv0 [B,S0,2,H,hd] the
+ * dK/dV of the prefix rows (gradients of the learnable prompts of Stage I, models/dvae.py:420-437). */
+int act_attention_bwd_prefix_f32(const float* kv0, int S0, const float* qkv1, int Sq, const float* out, const float* dout,
+                                 const float* lse, float* dkv0, float* dqkv1, int B, int H, int head_dim, float scale,
+                                 act_stream_t stream);
 
 /* Cosine distillation loss (models/act.py:1243-1254; lightly NegativeCosineSimilarity(dim=1, eps=1e-8)):
  * loss = mean over rows of 1 - cos(student_r, teacher_r).  row_loss [R], stats [R,3] are scratch kept for backward. */

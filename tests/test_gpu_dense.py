@@ -346,6 +346,51 @@ def test_attention_prefix_and_teacher_block_prefix(K):
     assert _rel(out, ref) <= 2e-5
 
 
+@pytest.mark.parametrize("B,S0,Sq,H,hd", [(2, 20, 33, 3, 64), (2, 64, 64, 12, 64), (3, 8, 16, 2, 32), (1, 100, 70, 2, 64),
+                                           (2, 0, 40, 2, 64), (1, 130, 129, 1, 32)])
+def test_attention_prefix_backward(K, B, S0, Sq, H, hd):
+    """dQ / dK / dV of the own rows and dK / dV of the prefix rows against a float64 reference."""
+    kv0 = _rnd(f"pb.kv{S0}{Sq}", B * max(S0, 1), 2 * H * hd)[:B * S0]; qkv = _rnd(f"pb.qkv{S0}{Sq}", B * Sq, 3 * H * hd)
+    do = _rnd(f"pb.do{S0}{Sq}", B * Sq, H * hd)
+    kd = kv0.double().requires_grad_(True); qd = qkv.double().requires_grad_(True)
+    q, k1, v1 = qd.view(B, Sq, 3, H, hd).permute(2, 0, 3, 1, 4)
+    k0, v0 = kd.view(B, S0, 2, H, hd).permute(2, 0, 3, 1, 4)
+    kk = torch.cat((k0, k1), 2); vv = torch.cat((v0, v1), 2)
+    ref = (torch.softmax(q @ kk.transpose(-2, -1) * hd ** -0.5, -1) @ vv).transpose(1, 2).reshape(B * Sq, H * hd)
+    (ref * do.double()).sum().backward()
+    kg, qg = kv0.cuda(), qkv.cuda()
+    if S0 == 0:
+        kg = torch.zeros(1, 2 * H * hd, device="cuda")[:0]
+    out, lse = K.attention_fwd_prefix(kg if S0 else torch.zeros(1, device="cuda"), S0, qg, Sq, B, H, hd, want_lse=True)
+    assert _rel(out, ref) <= 2e-5
+    dkv0, dqkv = K.attention_bwd_prefix(kg, S0, qg, Sq, out, do.cuda(), lse, B, H, hd)
+    assert _rel(dqkv, qd.grad) <= 5e-5
+    if S0:
+        assert _rel(dkv0, kd.grad) <= 5e-5
+
+
+def test_prefix_block_training_matches_full_block_autograd(K):
+    """PrefixBlockFn (prompts as keys/values only) == autograd through the oracle block on cat(prompt, x), patch rows only:
+    output and the gradients w.r.t. the patch tokens, their positions and the prompts."""
+    from oracle import layers as L
+    B, P, G, D, H = 2, 24, 40, 128, 2
+    blk = fill_module(L.Block(D, H, qkv_bias=True, eps=1e-6), "pfx.")
+    x = _rnd("pt.x", B, G, D).requires_grad_(True); pos = (_rnd("pt.p", B, G, D) * 0.2).requires_grad_(True)
+    prm = (_rnd("pt.m", B, P, D) * 0.3).requires_grad_(True)
+    w = _rnd("pt.w", B, G, D)
+    full = blk(torch.cat((prm, x + pos), 1), L.Draws())[:, P:]
+    (full * w).sum().backward()
+    p = _load_block(blk)
+    names = ["n1w", "n1b", "wqkv", "bqkv", "wproj", "bproj", "n2w", "n2b", "w1", "b1", "w2", "b2"]
+    xg = x.detach().cuda().reshape(B * G, D).requires_grad_(True); pg = pos.detach().cuda().reshape(B * G, D).requires_grad_(True)
+    mg = prm.detach().cuda().reshape(B * P, D).requires_grad_(True)
+    y = K.PrefixBlockFn.apply(xg, pg, mg, B, P, G, *[p[n] for n in names], H, 1e-6)
+    (y * w.cuda().reshape(B * G, D)).sum().backward()
+    assert _rel(y.reshape(B, G, D), full) <= TOL
+    assert _rel(xg.grad.reshape(B, G, D), x.grad) <= TOL and _rel(pg.grad.reshape(B, G, D), pos.grad) <= TOL
+    assert _rel(mg.grad.reshape(B, P, D), prm.grad) <= TOL
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_gemm_explicit_configs_and_pipelined_loop(K, tile):
     """every tile shape, with and without the software-pipelined main loop, with and without split-K, all layouts."""
