@@ -170,6 +170,147 @@ extern "C" int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, con
     ACT_LAUNCH_CHECK(); return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ edge-conv tail, backward
+// Forward (above): out[b,g,c] = max_j lrelu(GN(pre[b,g,c,j])), pre = Y[b, idx[b,j,g], c] + Z[b,g,c].  With j* the selected
+// neighbour, dact = dout * lrelu'(.) at j* and zero elsewhere, and GroupNorm's backward over the (C/groups, G, k) group is
+//   dpre[g,c,j] = rstd * ( gamma[c] * dact * [j == j*]  -  m1  -  xhat[g,c,j] * m2 )
+//   m1 = mean(gamma * dact) , m2 = mean(gamma * dact * xhat)   (means over the whole group, zeros included)
+//   dZ[b,g,c] = sum_j dpre ;  dY[b,r,c] = sum over the edges (g,j) with idx[b,j,g] == r of dpre   (fixed order: deterministic)
+//   dgamma[c] = sum_{b,g} dact * xhat* ; dbeta[c] = sum_{b,g} dact.
+__device__ __forceinline__ void edge_select(const float* __restrict__ yz, int ldy, const int64_t* __restrict__ idx, int b, int g, int G,
+                                            int k, int c, float a, float& vsel, int& jsel) {
+    vsel = 0.f; jsel = 0;
+    for (int j = 0; j < k; ++j) {
+        const int src = idx ? (int)idx[((size_t)b * k + j) * G + g] : g;
+        const float v = yz[((size_t)b * G + src) * ldy + c];
+        if (j == 0 || (a >= 0.f ? v > vsel : v < vsel)) { vsel = v; jsel = j; }     // first extremum wins (torch.max)
+    }
+}
+// pass 1: per (sample, channel) partial sums over g:  part[0][b][c] = sum_g dact*xhat*, part[1][b][c] = sum_g dact
+__global__ __launch_bounds__(256) void edge_gn_bwd_partials_kernel(const float* __restrict__ yz, int ldy, int zoff,
+                                                                   const int64_t* __restrict__ idx, int B, int G, int k, int C, int groups,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float slope, const float* __restrict__ dout, int ldd,
+                                                                   float* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    const int gi = c / (C / groups);
+    const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi], gm = gamma[c], bt = beta[c], a = rs * gm;
+    float sg = 0.f, sb = 0.f;
+    for (int g = 0; g < G; ++g) {
+        float v; int js;
+        edge_select(yz, ldy, idx, b, g, G, k, c, a, v, js);
+        if (zoff >= 0) v += yz[((size_t)b * G + g) * ldy + zoff + c];
+        const float xh = (v - mu) * rs;
+        const float y = xh * gm + bt;
+        const float da = dout[((size_t)b * G + g) * ldd + c] * (y > 0.f ? 1.f : slope);
+        sg += da * xh; sb += da;
+    }
+    part[((size_t)0 * B + b) * C + c] = sg;
+    part[((size_t)1 * B + b) * C + c] = sb;
+}
+// pass 2: one workgroup per (sample, group): m1 = sum_c gamma*db_part / N, m2 = sum_c gamma*dg_part / N
+__global__ __launch_bounds__(256) void edge_gn_bwd_means_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int B,
+                                                                int C, int groups, float inv_n, float* __restrict__ mstat) {
+    __shared__ float sh[2][4];
+    const int b = blockIdx.x / groups, gi = blockIdx.x % groups, cpg = C / groups;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = gi * cpg + threadIdx.x; c < (gi + 1) * cpg; c += 256) {
+        s1 += gamma[c] * part[((size_t)1 * B + b) * C + c];
+        s2 += gamma[c] * part[((size_t)0 * B + b) * C + c];
+    }
+    s1 = wave_sum_f32(s1); s2 = wave_sum_f32(s2);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mstat[blockIdx.x] = ((sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3])) * inv_n;
+        mstat[(size_t)B * groups + blockIdx.x] = ((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3])) * inv_n;
+    }
+}
+// pass 3 (graph layers): workgroup = (sample, chunk of CC channels), thread = channel; dY rows accumulate in LDS [G][CC]
+__global__ void edge_gn_bwd_apply_kernel(const float* __restrict__ yz, int ldy, int zoff, const int64_t* __restrict__ idx, int B, int G,
+                                         int k, int C, int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                         const float* __restrict__ dout, int ldd, const float* __restrict__ mstat,
+                                         float* __restrict__ dyz) {
+    extern __shared__ float acc[];                          // [G][CC]
+    const int CC = blockDim.x, t = threadIdx.x;
+    const int c = blockIdx.x * CC + t, b = blockIdx.y;
+    const bool live = c < C;
+    for (int r = 0; r < G; ++r) acc[r * CC + t] = 0.f;
+    if (live) {
+        const int gi = c / (C / groups);
+        const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi], gm = gamma[c], bt = beta[c], a = rs * gm;
+        const float m1 = mstat[b * groups + gi], m2 = mstat[(size_t)B * groups + b * groups + gi];
+        for (int g = 0; g < G; ++g) {
+            float vs; int js;
+            edge_select(yz, ldy, idx, b, g, G, k, c, a, vs, js);
+            const float z = zoff >= 0 ? yz[((size_t)b * G + g) * ldy + zoff + c] : 0.f;
+            const float xs = (vs + z - mu) * rs;
+            const float da = dout[((size_t)b * G + g) * ldd + c] * (xs * gm + bt > 0.f ? 1.f : slope) * gm;
+            float dz = 0.f;
+            for (int j = 0; j < k; ++j) {
+                const int src = idx ? (int)idx[((size_t)b * k + j) * G + g] : g;
+                const float xh = (yz[((size_t)b * G + src) * ldy + c] + z - mu) * rs;
+                const float dp = rs * ((j == js ? da : 0.f) - m1 - xh * m2);
+                dz += dp;
+                acc[src * CC + t] += dp;                    // own column only: no cross-thread races, fixed order
+            }
+            if (zoff >= 0) dyz[((size_t)b * G + g) * ldy + zoff + c] = dz;
+        }
+        for (int r = 0; r < G; ++r) dyz[((size_t)b * G + r) * ldy + c] = acc[r * CC + t];
+    }
+}
+// pass 3 (head, k = 1, no gather, no Z): plain elementwise
+__global__ __launch_bounds__(256) void gn_lrelu_bwd_apply_kernel(const float* __restrict__ h, int G, int C, int groups,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                                 const float* __restrict__ dout, int ldd, const float* __restrict__ mstat,
+                                                                 int B, float* __restrict__ dh, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long long row = i / C; const int b = (int)(row / G);
+        const int gi = c / (C / groups);
+        const float rs = rstd[b * groups + gi], gm = gamma[c];
+        const float xh = (h[i] - mean[b * groups + gi]) * rs;
+        const float da = dout[(size_t)row * ldd + c] * (xh * gm + beta[c] > 0.f ? 1.f : slope) * gm;
+        dh[i] = rs * (da - mstat[b * groups + gi] - xh * mstat[(size_t)B * groups + b * groups + gi]);
+    }
+}
+
+extern "C" int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C, int groups,
+                                             const float* gamma, const float* beta, const float* stats, float slope,
+                                             const float* dout, int ldd, float* dyz, float* part /* [2][B][C] */,
+                                             float* mstat /* [2][B*groups] */, act_stream_t stream) {
+    if (!yz || !gamma || !beta || !stats || !dout || !dyz || !part || !mstat) return ACT_E_NULLPTR;
+    if (B <= 0 || G <= 0 || k <= 0 || C <= 0 || groups <= 0 || C % groups || (!idx && (k != 1 || zoff >= 0))) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * (k + (zoff >= 0 ? 1 : 0)) + 2.0 + (zoff >= 0 ? 2 : 1)));
+    const float* mean = stats; const float* rstd = stats + (size_t)B * groups;
+    hipLaunchKernelGGL(edge_gn_bwd_partials_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, yz, ldy, zoff, idx, B, G, k, C, groups, mean,
+                       rstd, gamma, beta, slope, dout, ldd, part);
+    const float inv_n = 1.0f / ((float)(C / groups) * (float)G * (float)k);
+    hipLaunchKernelGGL(edge_gn_bwd_means_kernel, dim3(B * groups), dim3(256), 0, s, part, gamma, B, C, groups, inv_n, mstat);
+    if (!idx) {
+        const long long total = (long long)B * G * C;
+        hipLaunchKernelGGL(gn_lrelu_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, yz, G, C, groups, mean, rstd, gamma, beta,
+                           slope, dout, ldd, mstat, B, dyz, total);
+    } else {
+        int CC = G <= 128 ? 128 : (G <= 256 ? 64 : 32);
+        if (G > 512) return ACT_E_BADARG;
+        while (CC > 32 && CC / 2 >= C) CC /= 2;
+        const size_t smem = (size_t)G * CC * sizeof(float);
+        auto kfn = edge_gn_bwd_apply_kernel;
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((C + CC - 1) / CC, B), dim3(CC), smem, s, yz, ldy, zoff, idx, B, G, k, C, groups, mean, rstd, gamma,
+                           beta, slope, dout, ldd, mstat, dyz);
+    }
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
 extern "C" int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int C, int groups, const float* gamma, const float* beta,
                                                float eps, float slope, const float* noise, uint64_t seed, float tau,
                                                const float* codebook, int D, float* stats, int64_t* index_out, float* out,

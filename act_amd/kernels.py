@@ -536,11 +536,12 @@ _u64 = ctypes.c_uint64
 _C._declare({
     "act_edge_gn_lrelu_max_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _vp],
     "act_gn_gumbel_argmax_gather_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _u64, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "act_edge_gn_lrelu_max_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
 })
 _C.lib.act_layernorm_bwd_workspace.restype = _sz
 _C.lib.act_colsum_workspace.restype = _sz
 _C.lib.act_colstats_workspace.restype = _sz
-for _n in ("act_edge_gn_lrelu_max_f32", "act_gn_gumbel_argmax_gather_f32"):
+for _n in ("act_edge_gn_lrelu_max_f32", "act_gn_gumbel_argmax_gather_f32", "act_edge_gn_lrelu_max_bwd_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
 
 
@@ -554,6 +555,40 @@ def edge_gn_lrelu_max(yz, zoff, idx, B, G, k, C, gn, out=None, ooff=0, slope=0.2
                                         ptr(gn.bias), float(gn.eps), float(slope), ptr(stats), ptr(out), out.stride(0), int(ooff),
                                         stream()), "act_edge_gn_lrelu_max_f32")
     return out
+
+
+class EdgeGnLreluMaxFn(torch.autograd.Function):
+    """differentiable tail of a DGCNN layer: out[b*G+g, c] = max_j LeakyReLU(GroupNorm(Y[b, idx[b,j,g], c] + Z[b,g,c])) with
+    yz = [Y | Z] (zoff = column of Z, -1: none); idx None: the k = 1 GroupNorm + LeakyReLU head.  Backward = three HIP launches
+    (csrc/dgcnn.hip) + two column sums for dgamma / dbeta."""
+
+    @staticmethod
+    def forward(ctx, yz, gamma, beta, idx, zoff, B, G, k, C, groups, eps, slope):
+        yz = _f32c(yz)
+        out = torch.empty(B * G, C, dtype=torch.float32, device=yz.device)
+        stats = torch.empty(18 * B * groups, dtype=torch.float32, device=yz.device)
+        check(lib.act_edge_gn_lrelu_max_f32(ptr(yz), yz.stride(0), int(zoff), ptr(idx), B, G, k, C, groups, ptr(gamma), ptr(beta),
+                                            float(eps), float(slope), ptr(stats), ptr(out), C, 0, stream()), "act_edge_gn_lrelu_max_f32")
+        ctx.save_for_backward(yz, gamma, beta, idx, stats)
+        ctx.cfg = (int(zoff), B, G, k, C, groups, float(slope))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        yz, gamma, beta, idx, stats = ctx.saved_tensors
+        zoff, B, G, k, C, groups, slope = ctx.cfg
+        dout = _f32c(dout)
+        dyz = torch.empty_like(yz)
+        part = torch.empty(2, B, C, dtype=torch.float32, device=yz.device)
+        mstat = torch.empty(2 * B * groups, dtype=torch.float32, device=yz.device)
+        check(lib.act_edge_gn_lrelu_max_bwd_f32(ptr(yz), yz.stride(0), zoff, ptr(idx), B, G, k, C, groups, ptr(gamma), ptr(beta),
+                                                ptr(stats), slope, ptr(dout), dout.stride(0), ptr(dyz), ptr(part), ptr(mstat),
+                                                stream()), "act_edge_gn_lrelu_max_bwd_f32")
+        return (dyz, colsum(part[0]), colsum(part[1])) + (None,) * 9
+
+
+def edge_gn_lrelu_max_train(yz, zoff, idx, B, G, k, C, gn, slope=0.2):
+    return EdgeGnLreluMaxFn.apply(yz, gn.weight, gn.bias, idx, zoff, B, G, k, C, gn.num_groups, gn.eps, slope)
 
 
 def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, want_logits=False, slope=0.2):

@@ -117,17 +117,9 @@ class DGCNN(nn.Module):
         conv, gn, _ = layer
         cout = conv.weight.shape[0]
         yz = K.linear(f, DGCNN._stacked_weight(conv), None)               # [BG, 2*Cout] = [Y | Z]
-        if not torch.is_grad_enabled():                                   # frozen teacher (Stage II): fused HIP tail
+        if not torch.is_grad_enabled():                                   # frozen teacher (Stage II): written into the cat buffer
             return K.edge_gn_lrelu_max(yz, cout, idx, B, G, idx.shape[1], cout, gn, out=out, ooff=ooff)
-        y = yz[:, :cout].reshape(B, G, cout)
-        z = yz[:, cout:].reshape(B, 1, G, cout)
-        nb = y[torch.arange(B, device=f.device).view(B, 1, 1), idx]      # [B,k,G,Cout]
-        pre = (nb + z).permute(0, 3, 2, 1)                               # [B,Cout,G,k]
-        act = F.leaky_relu(F.group_norm(pre, 4, gn.weight, gn.bias, gn.eps), 0.2)
-        res = act.max(dim=-1)[0].transpose(1, 2).reshape(B * G, cout)    # rows [BG,Cout]
-        if out is not None:
-            out[:, ooff:ooff + cout] = res
-        return res
+        return K.edge_gn_lrelu_max_train(yz, cout, idx, B, G, idx.shape[1], cout, gn)     # Stage I: same kernels + HIP backward
 
     def features(self, f, coor, idx=None):
         """everything up to (not including) layer5's GroupNorm: -> pre-norm head output rows [B*G, C']"""
@@ -156,9 +148,7 @@ class DGCNN(nn.Module):
         gn = self.layer5[1]
         if not torch.is_grad_enabled():
             return K.edge_gn_lrelu_max(h, -1, None, B, G, 1, h.shape[1], gn).view(B, G, -1)
-        h = h.view(B, G, -1).transpose(1, 2)                             # [B,C',G]
-        h = F.leaky_relu(F.group_norm(h, 4, gn.weight, gn.bias, gn.eps), 0.2)
-        return h.transpose(1, 2)
+        return K.edge_gn_lrelu_max_train(h, -1, None, B, G, 1, h.shape[1], gn).view(B, G, -1)
 
 
 class Decoder(nn.Module):

@@ -184,6 +184,13 @@ int act_group_sum_f32(const float* in, int G, int n, int C, float* out, act_stre
 int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C,
                               int groups, const float* gamma, const float* beta, float eps, float slope, float* stats,
                               float* out, int ldo, int ooff, act_stream_t stream);
+/* backward of act_edge_gn_lrelu_max_f32 (DGCNN backward of Stage I): stats = the mean/rstd the forward left in its
+ * stats buffer; dout [B*G, ldd]; dyz [B*G, ldy] receives dY (columns 0..C) and dZ (columns zoff..zoff+C; idx == NULL: k = 1 head,
+ * dY only); part [2][B][C] receives the per-sample partial sums of dgamma / dbeta (column-sum them for the parameter
+ * gradients); mstat [2][B*groups] scratch.  Deterministic (no atomics). */
+int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C, int groups,
+                                  const float* gamma, const float* beta, const float* stats, float slope,
+                                  const float* dout, int ldd, float* dyz, float* part, float* mstat, act_stream_t stream);
 /* Tokenizer head: logits = LeakyReLU(GroupNorm(h [B*G, C])); index = argmax_c((logits + gumbel) / tau);
  * out [B*G, D] = codebook[index]  (F.gumbel_softmax(hard=True) + einsum with the codebook, models/dvae.py:587-588).
  * noise [B*G, C] (nullable: Philox4x32-10 keyed by seed); index_out / logits_out nullable. */

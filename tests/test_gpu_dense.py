@@ -296,6 +296,43 @@ def test_dgcnn_edge_tail_and_head(K):
     assert _rel(K.edge_gn_lrelu_max(h.cuda(), -1, None, B, G, 1, C, gn), href.transpose(1, 2).reshape(B * G, C)) <= 2e-5
 
 
+@pytest.mark.parametrize("B,G,k,C", [(3, 64, 4, 256), (2, 16, 4, 32), (2, 200, 3, 64), (1, 512, 4, 64)])
+def test_dgcnn_edge_tail_backward(K, B, G, k, C):
+    """HIP backward of the edge-conv tail (gather + GroupNorm + LeakyReLU + max over neighbours) and of the k = 1 head
+    against float64 autograd through the reference formulation (models/dvae.py:59-117)."""
+    import torch.nn.functional as F
+    yz = _rnd(f"eb.yz{G}{C}", B * G, 2 * C); do = _rnd(f"eb.do{G}{C}", B * G, C)
+    gw = _rnd(f"eb.w{C}", C); gb = 0.1 * _rnd(f"eb.b{C}", C)                  # negative gammas exercise the min branch
+    gen = torch.Generator().manual_seed(G * 7 + C)
+    idx = torch.stack([torch.stack([torch.randint(0, G, (G,), generator=gen) for j in range(k)]) for b in range(B)])
+    idx[:, 0] = torch.arange(G)                                                # k-NN graphs contain the point itself
+    yd = yz.double().requires_grad_(True); wd = gw.double().requires_grad_(True); bd = gb.double().requires_grad_(True)
+    y = yd[:, :C].reshape(B, G, C); z = yd[:, C:].reshape(B, 1, G, C)
+    pre = (y[torch.arange(B).view(B, 1, 1), idx] + z).permute(0, 3, 2, 1)
+    ref = F.leaky_relu(F.group_norm(pre, 4, wd, bd, 1e-5), 0.2).max(dim=-1)[0].transpose(1, 2).reshape(B * G, C)
+    (ref * do.double()).sum().backward()
+    gn = torch.nn.GroupNorm(4, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(gw); gn.bias.copy_(gb)
+    yg = yz.cuda().requires_grad_(True)
+    out = K.edge_gn_lrelu_max_train(yg, C, idx.cuda(), B, G, k, C, gn)
+    (out * do.cuda()).sum().backward()
+    assert _rel(out, ref) <= 2e-5
+    assert _rel(yg.grad, yd.grad) <= 5e-5
+    assert _rel(gn.weight.grad, wd.grad) <= 5e-5 and _rel(gn.bias.grad, bd.grad) <= 5e-5
+    # head: GroupNorm + LeakyReLU only
+    h = _rnd(f"eb.h{G}{C}", B * G, C) * 2 + 0.3
+    hd = h.double().requires_grad_(True); wd2 = gw.double().requires_grad_(True); bd2 = gb.double().requires_grad_(True)
+    href = F.leaky_relu(F.group_norm(hd.view(B, G, C).transpose(1, 2), 4, wd2, bd2, 1e-5), 0.2).transpose(1, 2).reshape(B * G, C)
+    (href * do.double()).sum().backward()
+    gn.zero_grad()
+    hg = h.cuda().requires_grad_(True)
+    o2 = K.edge_gn_lrelu_max_train(hg, -1, None, B, G, 1, C, gn)
+    (o2 * do.cuda()).sum().backward()
+    assert _rel(o2, href) <= 2e-5 and _rel(hg.grad, hd.grad) <= 5e-5
+    assert _rel(gn.weight.grad, wd2.grad) <= 5e-5 and _rel(gn.bias.grad, bd2.grad) <= 5e-5
+
+
 def test_gumbel_argmax_codebook_fused(K):
     import torch.nn.functional as F
     B, G, C, D = 4, 16, 512, 48
