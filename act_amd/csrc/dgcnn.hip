@@ -328,3 +328,152 @@ extern "C" int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int
                        1.0f / tau, codebook, D, index_out, out, logits_out);
     ACT_LAUNCH_CHECK(); return 0;
 }
+
+// ------------------------------------------------------------------------------------- Stage-I tokenizer: soft gumbel-softmax + KL
+// y[row,:] = softmax((logits[row,:] + gumbel) / tau)  (F.gumbel_softmax(hard=False), models/dvae.py:600); one workgroup per row,
+// the row lives in LDS between the three passes so the Philox noise is generated exactly once.
+__global__ __launch_bounds__(256) void gumbel_softmax_fwd_kernel(const float* __restrict__ logits, int C, const float* __restrict__ noise,
+                                                                 uint64_t seed, float inv_tau, float* __restrict__ y) {
+    extern __shared__ float row_s[];
+    __shared__ float red[4];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -3.0e38f;
+    for (int c4 = threadIdx.x * 4; c4 < C; c4 += 1024) {
+        const float4 x = *reinterpret_cast<const float4*>(logits + (size_t)row * C + c4);
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        if (!noise) philox4x32_10((uint32_t)(c4 >> 2), (uint32_t)row, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float g = noise ? noise[(size_t)row * C + c4 + u] : gumbel_from_bits(rnd[u]);
+            const float t = (xs[u] + g) * inv_tau;
+            row_s[c4 + u] = t; m = fmaxf(m, t);
+        }
+    }
+    m = wave_max_f32(m, -3.4e38f);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float e = __expf(row_s[c] - m); row_s[c] = e; se += e; }
+    se = wave_sum_f32(se);
+    if (lane == 0) red[wave] = se;
+    __syncthreads();
+    const float inv = 1.0f / ((red[0] + red[1]) + (red[2] + red[3]));
+    for (int c = threadIdx.x; c < C; c += 256) y[(size_t)row * C + c] = row_s[c] * inv;
+}
+// dlogits = y * (dy - sum_c y*dy) / tau
+__global__ __launch_bounds__(256) void gumbel_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, int C,
+                                                                 float inv_tau, float* __restrict__ dl) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* yr = y + (size_t)row * C; const float* dr = dy + (size_t)row * C;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += yr[c] * dr[c];
+    s = wave_sum_f32(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int c = threadIdx.x; c < C; c += 256) dl[(size_t)row * C + c] = yr[c] * (dr[c] - s) * inv_tau;
+}
+// KL(mean_g softmax(logits) || uniform), 'batchmean' (models/dvae.py:470-476):
+//   lse[row] = logsumexp(logits[row,:]) ; qbar[b,c] = mean_g exp(logits[b,g,c] - lse[b,g]) ;
+//   klv = (1/B) sum_{b,c} u (log u - log qbar[b,c]),  u = 1/C
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ logits, int C, float* __restrict__ lse) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* lr = logits + (size_t)row * C;
+    float m = -3.0e38f;
+    for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, lr[c]);
+    m = wave_max_f32(m, -3.4e38f);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) se += __expf(lr[c] - m);
+    se = wave_sum_f32(se);
+    if (lane == 0) red[wave] = se;
+    __syncthreads();
+    if (threadIdx.x == 0) lse[row] = m + __logf((red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void mean_softmax_kernel(const float* __restrict__ logits, const float* __restrict__ lse, int G, int C,
+                                                           float* __restrict__ qbar) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int g = 0; g < G; ++g) acc += __expf(logits[((size_t)b * G + g) * C + c] - lse[b * G + g]);
+    qbar[(size_t)b * C + c] = acc / (float)G;
+}
+__global__ __launch_bounds__(1024) void kl_uniform_kernel(const float* __restrict__ qbar, long long n, int B, int C, float* __restrict__ out) {
+    __shared__ float sh[16];
+    const float u = 1.0f / (float)C, lu = __logf(u);
+    float acc = 0.f;
+    const long long per = (n + 1023) / 1024, k0 = threadIdx.x * per, k1 = k0 + per < n ? k0 + per : n;
+    for (long long i = k0; i < k1; ++i) acc += u * (lu - __logf(qbar[i]));
+    acc = wave_sum_f32(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < 16; ++w) t += sh[w]; out[0] = t / (float)B; }
+}
+// dlogits[b,g,c] = p (w_c - sum_c' p_c' w_c'),  p = exp(logits - lse),  w_c = dklv * (-u / (B * qbar[b,c])) / G
+__global__ __launch_bounds__(256) void kl_uniform_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                             const float* __restrict__ qbar, const float* __restrict__ gout, int B, int G,
+                                                             int C, float* __restrict__ dl) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, b = row / G, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* lr = logits + (size_t)row * C; const float* qb = qbar + (size_t)b * C;
+    const float l0 = lse[row], k = -gout[0] / ((float)C * (float)B * (float)G);
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) s += __expf(lr[c] - l0) * (k / qb[c]);
+    s = wave_sum_f32(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int c = threadIdx.x; c < C; c += 256) dl[(size_t)row * C + c] = __expf(lr[c] - l0) * (k / qb[c] - s);
+}
+
+extern "C" int act_gumbel_softmax_fwd_f32(const float* logits, int R, int C, const float* noise, uint64_t seed, float tau, float* y,
+                                          act_stream_t stream) {
+    if (!logits || !y) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0 || (C & 3) || C > 16384 || tau <= 0.f) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GUMBEL_ARGMAX, s, 0.0, 4.0 * R * (double)C * (2 + (noise ? 1 : 0)));
+    const size_t smem = (size_t)C * sizeof(float);
+    auto k = gumbel_softmax_fwd_kernel;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3(R), dim3(256), smem, s, logits, C, noise, seed, 1.0f / tau, y);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_gumbel_softmax_bwd_f32(const float* y, const float* dy, int R, int C, float tau, float* dlogits, act_stream_t stream) {
+    if (!y || !dy || !dlogits) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0 || tau <= 0.f) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GUMBEL_ARGMAX, s, 0.0, 12.0 * R * (double)C);
+    hipLaunchKernelGGL(gumbel_softmax_bwd_kernel, dim3(R), dim3(256), 0, s, y, dy, C, 1.0f / tau, dlogits);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_kl_uniform_fwd_f32(const float* logits, int B, int G, int C, float* lse /*[B*G]*/, float* qbar /*[B,C]*/,
+                                      float* klv_out, act_stream_t stream) {
+    if (!logits || !lse || !qbar || !klv_out) return ACT_E_NULLPTR;
+    if (B <= 0 || G <= 0 || C <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GUMBEL_ARGMAX, s, 0.0, 8.0 * B * G * (double)C);
+    hipLaunchKernelGGL(row_lse_kernel, dim3(B * G), dim3(256), 0, s, logits, C, lse);
+    hipLaunchKernelGGL(mean_softmax_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, logits, lse, G, C, qbar);
+    hipLaunchKernelGGL(kl_uniform_kernel, dim3(1), dim3(1024), 0, s, qbar, (long long)B * C, B, C, klv_out);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_kl_uniform_bwd_f32(const float* logits, const float* lse, const float* qbar, const float* grad_klv, int B, int G, int C,
+                                      float* dlogits, act_stream_t stream) {
+    if (!logits || !lse || !qbar || !grad_klv || !dlogits) return ACT_E_NULLPTR;
+    if (B <= 0 || G <= 0 || C <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_GUMBEL_ARGMAX, s, 0.0, 12.0 * B * G * (double)C);
+    hipLaunchKernelGGL(kl_uniform_bwd_kernel, dim3(B * G), dim3(256), 0, s, logits, lse, qbar, grad_klv, B, G, C, dlogits);
+    ACT_LAUNCH_CHECK(); return 0;
+}

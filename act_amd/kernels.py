@@ -537,11 +537,16 @@ _C._declare({
     "act_edge_gn_lrelu_max_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _vp],
     "act_gn_gumbel_argmax_gather_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _u64, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "act_edge_gn_lrelu_max_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
+    "act_gumbel_softmax_fwd_f32": [_vp, _i, _i, _vp, _u64, _f, _vp, _vp],
+    "act_gumbel_softmax_bwd_f32": [_vp, _vp, _i, _i, _f, _vp, _vp],
+    "act_kl_uniform_fwd_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "act_kl_uniform_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
 })
 _C.lib.act_layernorm_bwd_workspace.restype = _sz
 _C.lib.act_colsum_workspace.restype = _sz
 _C.lib.act_colstats_workspace.restype = _sz
-for _n in ("act_edge_gn_lrelu_max_f32", "act_gn_gumbel_argmax_gather_f32", "act_edge_gn_lrelu_max_bwd_f32"):
+for _n in ("act_edge_gn_lrelu_max_f32", "act_gn_gumbel_argmax_gather_f32", "act_edge_gn_lrelu_max_bwd_f32",
+           "act_gumbel_softmax_fwd_f32", "act_gumbel_softmax_bwd_f32", "act_kl_uniform_fwd_f32", "act_kl_uniform_bwd_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
 
 
@@ -589,6 +594,64 @@ class EdgeGnLreluMaxFn(torch.autograd.Function):
 
 def edge_gn_lrelu_max_train(yz, zoff, idx, B, G, k, C, gn, slope=0.2):
     return EdgeGnLreluMaxFn.apply(yz, gn.weight, gn.bias, idx, zoff, B, G, k, C, gn.num_groups, gn.eps, slope)
+
+
+class GumbelSoftmaxFn(torch.autograd.Function):
+    """F.gumbel_softmax(logits, tau, hard=False, dim=-1) on rows [R,C]; noise: given gumbel draws or None -> in-kernel Philox."""
+
+    @staticmethod
+    def forward(ctx, logits, noise, seed, tau):
+        z = _f32c(logits)
+        C = z.shape[-1]
+        z2 = z.reshape(-1, C)
+        y = torch.empty_like(z2)
+        nz = _f32c(noise).reshape(-1, C) if noise is not None else None
+        check(lib.act_gumbel_softmax_fwd_f32(ptr(z2), z2.shape[0], C, ptr(nz), int(seed), float(tau), ptr(y), stream()),
+              "act_gumbel_softmax_fwd_f32")
+        ctx.save_for_backward(y)
+        ctx.tau, ctx.shp = float(tau), logits.shape
+        return y.reshape(logits.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        R, C = y.shape
+        dy = _f32c(dy).reshape(R, C)
+        dl = torch.empty_like(y)
+        check(lib.act_gumbel_softmax_bwd_f32(ptr(y), ptr(dy), R, C, ctx.tau, ptr(dl), stream()), "act_gumbel_softmax_bwd_f32")
+        return dl.reshape(ctx.shp), None, None, None
+
+
+def gumbel_softmax(logits, tau, noise=None, seed=0):
+    return GumbelSoftmaxFn.apply(logits, noise, seed, tau)
+
+
+class KLUniformFn(torch.autograd.Function):
+    """KL(mean_g softmax(logits[b,g,:]) || uniform), 'batchmean' (models/dvae.py:470-476); logits [B,G,C] -> scalar."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        z = _f32c(logits)
+        B, G, C = z.shape
+        lse = torch.empty(B * G, dtype=torch.float32, device=z.device)
+        qbar = torch.empty(B, C, dtype=torch.float32, device=z.device)
+        out = torch.empty(1, dtype=torch.float32, device=z.device)
+        check(lib.act_kl_uniform_fwd_f32(ptr(z), B, G, C, ptr(lse), ptr(qbar), ptr(out), stream()), "act_kl_uniform_fwd_f32")
+        ctx.save_for_backward(z, lse, qbar)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, lse, qbar = ctx.saved_tensors
+        B, G, C = z.shape
+        dl = torch.empty_like(z)
+        check(lib.act_kl_uniform_bwd_f32(ptr(z), ptr(lse), ptr(qbar), ptr(_f32c(g).reshape(-1)), B, G, C, ptr(dl), stream()),
+              "act_kl_uniform_bwd_f32")
+        return dl
+
+
+def kl_to_uniform(logits):
+    return KLUniformFn.apply(logits).reshape(())
 
 
 def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, want_logits=False, slope=0.2):

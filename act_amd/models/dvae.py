@@ -295,11 +295,7 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
 
     def get_loss(self, ret, gt):
         loss_recon = self.recon_loss(ret, gt)
-        logits = ret[-1]
-        mean_softmax = F.softmax(logits, dim=-1).mean(dim=1)
-        log_qy = torch.log(mean_softmax)
-        log_uniform = torch.log(torch.tensor([1. / self.num_tokens], device=gt.device))
-        loss_klv = F.kl_div(log_qy, log_uniform.expand(log_qy.size(0), log_qy.size(1)), None, None, 'batchmean', log_target=True)
+        loss_klv = K.kl_to_uniform(ret[-1])        # KL(mean_g softmax(logits) || uniform), 'batchmean' (models/dvae.py:470-476)
         return loss_recon, loss_klv
 
     # ---- prompt-tuned frozen Transformer ---------------------------------------------------------
@@ -389,15 +385,17 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
 
     # ---- tokenizer ----------------------------------------------------------------------------------
     def _gumbel_codes(self, logits, tau, hard, draws):
-        if draws is not None:
+        g = None
+        if draws is not None and (draws.has("gumbel") or draws.record):
             g = draws.get("gumbel", lambda: -torch.empty_like(logits).exponential_().log())
-        else:
-            g = -torch.empty_like(logits).exponential_().log()
-        y = (logits + g) / tau
         if hard:
-            index = y.argmax(dim=-1)                       # one-hot x codebook == row gather (models/dvae.py:587-588)
+            if g is None:
+                g = -torch.empty_like(logits).exponential_().log()
+            index = ((logits + g) / tau).argmax(dim=-1)    # one-hot x codebook == row gather (models/dvae.py:587-588)
             return F.embedding(index, self.codebook)
-        return K.linear(y.softmax(dim=-1), self.codebook.t().contiguous(), None)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if g is None else 0       # host RNG (no device sync)
+        y = K.gumbel_softmax(logits, tau, noise=g, seed=seed)                       # soft one-hot [B,G,N], noise from Philox in-kernel
+        return K.linear(y, self.codebook.t().contiguous(), None)
 
     def forward_tokenizer(self, neighborhood, center):
         gt_logits = self.dgcnn_1(self.encoder(neighborhood), center)

@@ -198,6 +198,15 @@ int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int C, int gro
                                     float eps, float slope, const float* noise, uint64_t seed, float tau,
                                     const float* codebook, int D, float* stats, int64_t* index_out, float* out,
                                     float* logits_out, act_stream_t stream);
+/* Stage-I tokenizer (models/dvae.py:600, 470-476).  Soft gumbel-softmax over rows: y = softmax((logits + G)/tau), G = noise
+ * (parity tests) or Philox keyed by (seed,row,c/4) when noise == NULL; C % 4 == 0, C <= 16384.  backward: dlogits = y (dy - <y,dy>)/tau. */
+int act_gumbel_softmax_fwd_f32(const float* logits, int R, int C, const float* noise, uint64_t seed, float tau, float* y,
+                               act_stream_t stream);
+int act_gumbel_softmax_bwd_f32(const float* y, const float* dy, int R, int C, float tau, float* dlogits, act_stream_t stream);
+/* klv = KL(mean_g softmax(logits[b,g,:]) || uniform), reduction 'batchmean'; lse [B*G] and qbar [B,C] are kept for backward. */
+int act_kl_uniform_fwd_f32(const float* logits, int B, int G, int C, float* lse, float* qbar, float* klv_out, act_stream_t stream);
+int act_kl_uniform_bwd_f32(const float* logits, const float* lse, const float* qbar, const float* grad_klv, int B, int G, int C,
+                           float* dlogits, act_stream_t stream);
 
 #ifdef __cplusplus
 }

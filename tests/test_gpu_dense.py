@@ -333,6 +333,38 @@ def test_dgcnn_edge_tail_backward(K, B, G, k, C):
     assert _rel(gn.weight.grad, wd2.grad) <= 5e-5 and _rel(gn.bias.grad, bd2.grad) <= 5e-5
 
 
+@pytest.mark.parametrize("B,G,C,tau", [(2, 16, 64, 0.7), (3, 8, 8192, 1.0), (2, 5, 1000, 0.0625)])
+def test_soft_gumbel_softmax_and_kl_to_uniform(K, B, G, C, tau):
+    """Stage-I tokenizer: F.gumbel_softmax(hard=False) with injected noise and the KL(mean softmax || uniform) term
+    (models/dvae.py:600, 470-476), forward and backward against float64 autograd."""
+    import torch.nn.functional as F
+    logits = _rnd(f"gs.l{C}", B, G, C) * 2.0
+    torch.manual_seed(C)
+    noise = -torch.empty(B, G, C).exponential_().log()
+    dy = _rnd(f"gs.d{C}", B, G, C)
+    ld = logits.double().requires_grad_(True)
+    yr = F.softmax((ld + noise.double()) / tau, dim=-1)
+    (yr * dy.double()).sum().backward()
+    lg = logits.cuda().requires_grad_(True)
+    y = K.gumbel_softmax(lg, tau, noise=noise.cuda())
+    (y * dy.cuda()).sum().backward()
+    assert _rel(y, yr) <= 2e-5 and _rel(lg.grad, ld.grad) <= 5e-5
+    # in-kernel Philox noise: rows are proper distributions, deterministic per seed
+    y1 = K.gumbel_softmax(logits.cuda(), tau, seed=11); y2 = K.gumbel_softmax(logits.cuda(), tau, seed=11); y3 = K.gumbel_softmax(logits.cuda(), tau, seed=12)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3) and (y1.sum(-1) - 1).abs().max() < 1e-4 and (y1 >= 0).all()
+    # KL term
+    ld2 = logits.double().requires_grad_(True)
+    lq = torch.log(F.softmax(ld2, dim=-1).mean(dim=1))
+    lu = torch.log(torch.tensor([1.0 / C], dtype=torch.float64)).expand(B, C)
+    ref = F.kl_div(lq, lu, None, None, 'batchmean', log_target=True)
+    (ref * 1.7).backward()
+    lg2 = logits.cuda().requires_grad_(True)
+    kl = K.kl_to_uniform(lg2)
+    (kl * 1.7).backward()
+    assert abs(kl.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item()))
+    assert _rel(lg2.grad, ld2.grad) <= 5e-5
+
+
 def test_gumbel_argmax_codebook_fused(K):
     import torch.nn.functional as F
     B, G, C, D = 4, 16, 512, 48
