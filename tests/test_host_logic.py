@@ -1,0 +1,57 @@
+"""CPU: host-side logic of the finetune / inference path that needs no GPU (config surface, registry, synthetic labelled
+dataset, accuracy metrics, FPS-pool table of tools/runner_finetune.py:141-150)."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_finetune_yaml_surface_and_registry():
+    from act_amd.models import MODELS
+    from act_amd.utils.config import cfg_from_yaml_file
+    assert "PointTransformer" in MODELS
+    for path, ttype in [("cfgs/finetune_classification/full/finetune_modelnet.yaml", "full"),
+                        ("cfgs/finetune_classification/linear/finetune_modelnet_linear.yaml", "linear"),
+                        ("cfgs/finetune_classification/mlp3/finetune_modelnet_mlp3.yaml", "mlp-3")]:
+        cfg = cfg_from_yaml_file(path)
+        assert cfg.model.NAME == "PointTransformer" and cfg.model.transfer_type == ttype
+        assert (cfg.npoints, cfg.total_bs, cfg.grad_norm_clip, cfg.model.num_group, cfg.model.group_size) == (1024, 32, 10, 64, 32)
+        assert cfg.dataset.train._base_.NAME == "ModelNet" and cfg.dataset.train._base_.N_POINTS == 8192
+
+
+def test_synthetic_modelnet_item_contract():
+    from act_amd.datasets import build_dataset_from_cfg
+    from act_amd.utils.config import EasyDict
+    ds = build_dataset_from_cfg(EasyDict(NAME="ModelNet", N_POINTS=512, NUM_CATEGORY=7, SYNTHETIC=True, NUM_SAMPLES=5, DATA_PATH="none"),
+                                EasyDict(subset="train"))
+    assert len(ds) == 5
+    tax, mid, (pts, label) = ds[3]
+    assert (tax, mid) == ("ModelNet", "sample") and pts.shape == (512, 3) and pts.dtype == torch.float32 and 0 <= label < 7
+    assert abs(pts.norm(dim=1).max().item() - 1.0) < 1e-5 and pts.mean(0).abs().max().item() < 1e-5       # pc_norm semantics
+    assert torch.equal(ds[3][2][0], pts)                                                                   # deterministic per index
+
+
+def test_accuracy_scores_and_fps_pool_table():
+    from act_amd.tools.runner_finetune import accuracy_scores, point_all_for, Acc_Metric
+    label = torch.tensor([0, 0, 0, 1, 1, 3]); pred = torch.tensor([0, 0, 1, 1, 0, 3])
+    acc, bal = accuracy_scores(label, pred)
+    assert abs(acc - 100 * 4 / 6) < 1e-4 and abs(bal - 100 * (2 / 3 + 1 / 2 + 1) / 3) < 1e-4
+    assert [point_all_for(n) for n in (1024, 2048, 4096, 8192)] == [1200, 2400, 4800, 8192]
+    with pytest.raises(NotImplementedError):
+        point_all_for(512)
+    with pytest.raises(NotImplementedError):
+        point_all_for(2048, train=False)                     # the reference's vote loop has no 2048 branch (:311-318)
+    assert Acc_Metric(91.0, 88.0).better_than(Acc_Metric({"acc": 90.5, "acc_avg": 89.0}))
+    assert Acc_Metric(Acc_Metric(1.0, 2.0)).state_dict() == {"acc": 1.0, "acc_avg": 2.0}
+
+
+def test_point_transformer_freezing_rules_match_reference_names():
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from tests.conftest import golden
+    from tests.golden.fill import TINY_FINETUNE
+    g = golden("g10_finetune")
+    for ttype in ("full", "side"):
+        m = build_model_from_cfg(EasyDict(dict(TINY_FINETUNE, transfer_type=ttype)))
+        assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == sorted(str(n) for n in g[f"{ttype}_trainable"])
+    m = build_model_from_cfg(EasyDict(dict(TINY_FINETUNE, transfer_type="bit-fit")))
+    assert all(("bias" in n or "cls" in n) == p.requires_grad for n, p in m.named_parameters())
