@@ -260,6 +260,47 @@ __global__ void sgemm_splitk_reduce(const float* __restrict__ partial, int split
     }
 }
 
+// Skinny weight gradients (TN, min(M,N) <= 8, K = tokens): e.g. dW of the 3->128 first conv, of the 512->3 / 5->512 FoldingNet
+// convs.  A 64x64 MFMA tile would be >90 % padding and the tile grid cannot fill the chip, so this is a streaming reduction
+// instead: the wide operand is read once, coalesced (thread <-> wide column, 4 k-lanes per workgroup), the skinny operand is
+// wave-uniform, partial sums per K range go to the split-K workspace and the ordinary deterministic reduce + epilogue finishes.
+template <bool SMALL_N>
+__global__ __launch_bounds__(256) void sgemm_tn_skinny_kernel(const float* __restrict__ wide, int ldw, int W, const float* __restrict__ skinny,
+                                                              int lds, int ns, int K, int rows_per_part, int M, int N,
+                                                              float* __restrict__ partial) {
+    __shared__ float red[3][64][8];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), klane = threadIdx.x >> 6;
+    const int kbeg = blockIdx.y * rows_per_part, kend = min(K, kbeg + rows_per_part);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (col < W) {
+#pragma unroll 4
+        for (int k = kbeg + klane; k < kend; k += 4) {
+            const float w = wide[(size_t)k * ldw + col];
+            const float* sk = skinny + (size_t)k * lds;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < ns) acc[j] += w * sk[j];
+        }
+    }
+    if (klane > 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[klane - 1][threadIdx.x & 63][j] = acc[j];
+    }
+    __syncthreads();
+    if (klane == 0 && col < W) {
+        float* dst = partial + (size_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < ns) {
+                const float v = (acc[j] + red[0][threadIdx.x][j]) + (red[1][threadIdx.x][j] + red[2][threadIdx.x][j]);
+                if (SMALL_N) dst[(size_t)col * N + j] = v;      // C[m = col][n = j]
+                else         dst[(size_t)j * N + col] = v;      // C[m = j][n = col]
+            }
+    }
+}
+
 template <int BM, int BN, int BK>
 static void launch_variant(const GemmParams& p, int ak, int bk, bool vec, bool full, bool pipe, dim3 grid, hipStream_t s) {
 #define L(AK, BKK, V, F, P) hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, AK, BKK, V, F, P>), grid, dim3(256), 0, s, p)
@@ -296,6 +337,23 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     const int kid = (a_kmajor && b_kmajor) ? KID_GEMM_NT : (a_kmajor ? KID_GEMM_NN : KID_GEMM_TN);
     ActProfScope ps(kid, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 
+    if (!a_kmajor && !b_kmajor && tile == 0 && (M <= 8 || N <= 8) && K >= 2048 && workspace) {
+        int nparts = K / 1024; if (nparts > 256) nparts = 256; if (nparts < 1) nparts = 1;
+        const int rpp = ((K + nparts - 1) / nparts + 3) / 4 * 4;
+        nparts = (K + rpp - 1) / rpp;
+        if ((size_t)nparts * M * N * sizeof(float) <= workspace_bytes) {
+            if (N <= 8) hipLaunchKernelGGL(sgemm_tn_skinny_kernel<true>, dim3((M + 63) / 64, nparts), dim3(256), 0, s, A, lda, M, B, ldb, N, K,
+                                           rpp, M, N, workspace);
+            else        hipLaunchKernelGGL(sgemm_tn_skinny_kernel<false>, dim3((N + 63) / 64, nparts), dim3(256), 0, s, B, ldb, N, A, lda, M, K,
+                                           rpp, M, N, workspace);
+            ACT_LAUNCH_CHECK();
+            const long long total = (long long)M * N;
+            long long g = (total + 255) / 256; if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(sgemm_splitk_reduce, dim3((unsigned)g), dim3(256), 0, s, workspace, nparts, M, N, C, ldc, p.epi);
+            ACT_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     // vector path: every float4 is fully in range or fully out, and 16-byte aligned
     const bool vec = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && (lda & 3) == 0 &&
                      (ldb & 3) == 0 && (a_kmajor ? (K & 3) == 0 : (M & 3) == 0) && (b_kmajor ? (K & 3) == 0 : (N & 3) == 0);

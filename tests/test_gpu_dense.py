@@ -460,6 +460,18 @@ def test_prefix_block_training_matches_full_block_autograd(K):
     assert _rel(mg.grad.reshape(B, P, D), prm.grad) <= TOL
 
 
+@pytest.mark.parametrize("M,N,Kd", [(128, 3, 262144), (3, 512, 65536), (512, 5, 40000), (1, 70, 4099), (100, 8, 2048)])
+def test_gemm_skinny_weight_gradient(K, M, N, Kd):
+    """TN products with one dimension <= 8 (first conv / FoldingNet weight gradients) run the streaming-reduction kernel."""
+    a = _rnd(f"sk.a{M}{N}", Kd, M); b = _rnd(f"sk.b{M}{N}", Kd, N)
+    ref = a.double().t() @ b.double()
+    c = K.gemm(a.cuda(), b.cuda(), False, False)
+    assert _rel(c, ref) <= 2e-5
+    base = _rnd(f"sk.c{M}{N}", M, N).cuda()
+    c2 = K.gemm(a.cuda(), b.cuda(), False, False, out=base.clone(), accumulate=True, alpha=0.5)
+    assert _rel(c2, 0.5 * ref + base.double().cpu()) <= 2e-5
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_gemm_explicit_configs_and_pipelined_loop(K, tile):
     """every tile shape, with and without the software-pipelined main loop, with and without split-K, all layouts."""
