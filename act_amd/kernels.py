@@ -50,12 +50,55 @@ _WS_BYTES = 64 << 20
 
 
 def workspace(device, nbytes=_WS_BYTES):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """scratch buffer of the CURRENT stream on ``device`` (kernels of different streams may run concurrently)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     w = _WS.get(key)
     if w is None or w.numel() * 4 < nbytes:
         w = torch.empty(max(nbytes, _WS_BYTES) // 4, dtype=torch.float32, device=device)
         _WS[key] = w
     return w
+
+
+_SIDE = {}
+
+
+def side_stream(device):
+    """one auxiliary HIP stream per device for work that is independent of the main chain (frozen teacher forward)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+OVERLAP_DW = os.environ.get("ACT_OVERLAP_DW", "1") != "0"
+
+
+class fork_side:
+    """``with fork_side(dev):`` enqueues the body on the auxiliary stream, ordered after everything already enqueued on the
+    current stream.  Used for weight-gradient GEMMs / bias column sums, which nothing in the rest of the backward chain reads:
+    they then share the chip with the (small, latency-bound) dX GEMMs of the student instead of running back to back."""
+
+    def __init__(self, device):
+        self.main, self.side = torch.cuda.current_stream(device), side_stream(device)
+
+    def __enter__(self):
+        self.side.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def join_side(device, *tensors):
+    """the current stream waits for the auxiliary stream; ``tensors`` (allocated there) are handed over to the current stream."""
+    main = torch.cuda.current_stream(device)
+    main.wait_stream(side_stream(device))
+    for t in tensors:
+        if t is not None:
+            t.record_stream(main)
 
 
 def _f32c(t, name="tensor"):
@@ -344,25 +387,38 @@ class BlockFn(torch.autograd.Function):
         (xin, mean1, rstd1, n1, qkv, att, lse, x1, mean2, rstd2, n2, hpre, a, gate1, gate2,
          n1w, wqkv, wproj, n2w, w1, w2) = ctx.saved_tensors
         B, S, D, heads, hd = ctx.dims
-        tw = ctx.train_w
+        tw = bool(ctx.train_w)
         dx2 = _f32c(dx2).reshape(B * S, D)
         dy2 = dx2 if gate2 is None else scale_rows(dx2, gate2, S)
+        dev = dx2.device
+        # train_w == 2: weight gradients on the auxiliary stream, concurrent with the dX chain (measured: +1 % on the Stage-II step,
+        # -7 % on the finetune step, so only ACT_PointDistillation asks for it)
+        par = ctx.train_w == 2 and OVERLAP_DW and dx2.is_cuda
+        dw2 = db2 = dw1 = db1 = dwproj = dbproj = dwqkv = dbqkv = None
+
+        def wgrad(dy, x, want_bias=True):
+            """dW = dy^T x, db = column sums of dy"""
+            if not tw:
+                return None, None
+            if par:
+                with fork_side(dev):
+                    return gemm(dy, x, False, False), (colsum(dy) if want_bias else None)
+            return gemm(dy, x, False, False), (colsum(dy) if want_bias else None)
+
+        dw2, db2 = wgrad(dy2, a)
         dh = gemm(dy2, w2, True, False, act=EPI_MUL_GELU_GRAD, aux=hpre)
-        dw2 = gemm(dy2, a, False, False) if tw else None
-        db2 = colsum(dy2) if tw else None
+        dw1, db1 = wgrad(dh, n2)
         dn2 = gemm(dh, w1, True, False)
-        dw1 = gemm(dh, n2, False, False) if tw else None
-        db1 = colsum(dh) if tw else None
         dx1, dg2, dbt2 = layernorm_bwd(dn2, x1, n2w, mean2, rstd2, dres=dx2, want_params=tw)
         dy1 = dx1 if gate1 is None else scale_rows(dx1, gate1, S)
+        dwproj, dbproj = wgrad(dy1, att)
         datt = gemm(dy1, wproj, True, False)
-        dwproj = gemm(dy1, att, False, False) if tw else None
-        dbproj = colsum(dy1) if tw else None
         dqkv = attention_bwd(qkv, att, datt, lse, B, S, heads, hd)
+        dwqkv, dbqkv = wgrad(dqkv, n1, ctx.has_bqkv)
         dn1 = gemm(dqkv, wqkv, True, False)
-        dwqkv = gemm(dqkv, n1, False, False) if tw else None
-        dbqkv = colsum(dqkv) if (tw and ctx.has_bqkv) else None
         dxin, dg1, dbt1 = layernorm_bwd(dn1, xin, n1w, mean1, rstd1, dres=dx1, want_params=tw)
+        if par:
+            join_side(dev, dw2, db2, dw1, db1, dwproj, dbproj, dwqkv, dbqkv)
         dxin = dxin.reshape(B, S, D)
         return (dxin, dxin if ctx.has_pos else None, None, None, dg1, dbt1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbt2,
                 dw1, db1, dw2, db2, None, None, None)

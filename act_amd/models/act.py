@@ -16,6 +16,10 @@ from .build import MODELS
 from .dvae import Group, Encoder, ACTPromptedDiscreteVAEwithVIT, trunc_normal_
 
 
+import os
+_OVERLAP_TEACHER = os.environ.get("ACT_OVERLAP_TEACHER", "1") != "0"
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
         super().__init__()
@@ -54,6 +58,7 @@ class Block(nn.Module):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.overlap_wgrad = False          # set by ACT_PointDistillation: weight-gradient GEMMs on the auxiliary stream
 
     def gates(self, B, device, draws, tag):
         """per-sample DropPath gates floor(keep + U) / keep for the two residual branches (or None)."""
@@ -72,7 +77,7 @@ class Block(nn.Module):
         a, m = self.attn, self.mlp
         return K.BlockFn.apply(x, pos, g1, g2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
                                a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
-                               m.fc2.bias, a.num_heads, self.norm1.eps, True)
+                               m.fc2.bias, a.num_heads, self.norm1.eps, 2 if self.overlap_wgrad else 1)
 
 
 class TransformerEncoder(nn.Module):
@@ -381,6 +386,9 @@ class ACT_PointDistillation(nn.Module):
         else:
             self.proj_head = nn.Identity()
         self.build_masked_decoder()
+        for m in self.modules():
+            if isinstance(m, Block):
+                m.overlap_wgrad = True
         self.loss_type = config.loss
         if self.loss_type != 'cosine':
             raise NotImplementedError("only loss: cosine (the ACT recipe) is on this path")
@@ -419,10 +427,19 @@ class ACT_PointDistillation(nn.Module):
         if noaug:
             return self.forward_eval(pts)
         neighborhood, center = self.group_divider(pts)
+        # The frozen teacher only depends on the grouped points: it runs on a second HIP stream, concurrently with the student's
+        # forward (whose 1,792-row GEMMs leave most CUs idle), and is joined right before the loss.
+        overlap = _OVERLAP_TEACHER and pts.is_cuda
+        if overlap:
+            main, side = torch.cuda.current_stream(pts.device), K.side_stream(pts.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                teacher_feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
         x_vis, mask = self.ACT_encoder(neighborhood, center, draws=draws)
         B, _, C = x_vis.shape
-        with torch.no_grad():
-            teacher_feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
+        if not overlap:
+            with torch.no_grad():
+                teacher_feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
         num_mask = self.ACT_encoder.num_mask
         vis_idx, msk_idx = split_indices(mask, num_mask)
         dp = self.decoder_pos_embed
@@ -437,6 +454,9 @@ class ACT_PointDistillation(nn.Module):
             student_feat = K.linear(x_rec, c.weight.view(c.weight.shape[0], -1), c.bias)
         else:
             student_feat = x_rec
+        if overlap:
+            main.wait_stream(side)
+            teacher_feat.record_stream(main)
         teacher_feat = take_rows(teacher_feat, msk_idx)
         assert teacher_feat.shape == student_feat.shape
         return K.cosine_distill_loss(student_feat, teacher_feat)
