@@ -62,9 +62,10 @@ def workspace(device, nbytes=_WS_BYTES):
 _SIDE = {}
 
 
-def side_stream(device):
-    """one auxiliary HIP stream per device for work that is independent of the main chain (frozen teacher forward)."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+def side_stream(device, which=0):
+    """auxiliary HIP streams per device for work that is independent of the main chain: 0 = frozen teacher forward (may run a
+    whole step ahead), 1 = weight-gradient GEMMs of the student's backward (forked and joined inside one block's backward)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     st = _SIDE.get(key)
     if st is None:
         st = _SIDE[key] = torch.cuda.Stream(device=device)
@@ -80,7 +81,7 @@ class fork_side:
     they then share the chip with the (small, latency-bound) dX GEMMs of the student instead of running back to back."""
 
     def __init__(self, device):
-        self.main, self.side = torch.cuda.current_stream(device), side_stream(device)
+        self.main, self.side = torch.cuda.current_stream(device), side_stream(device, 1)
 
     def __enter__(self):
         self.side.wait_stream(self.main)
@@ -95,7 +96,7 @@ class fork_side:
 def join_side(device, *tensors):
     """the current stream waits for the auxiliary stream; ``tensors`` (allocated there) are handed over to the current stream."""
     main = torch.cuda.current_stream(device)
-    main.wait_stream(side_stream(device))
+    main.wait_stream(side_stream(device, 1))
     for t in tensors:
         if t is not None:
             t.record_stream(main)

@@ -18,6 +18,7 @@ from .dvae import Group, Encoder, ACTPromptedDiscreteVAEwithVIT, trunc_normal_
 
 import os
 _OVERLAP_TEACHER = os.environ.get("ACT_OVERLAP_TEACHER", "1") != "0"
+_PREFETCH_TEACHER = os.environ.get("ACT_PREFETCH_TEACHER", "1") != "0"
 
 
 class Mlp(nn.Module):
@@ -389,6 +390,7 @@ class ACT_PointDistillation(nn.Module):
         for m in self.modules():
             if isinstance(m, Block):
                 m.overlap_wgrad = True
+        self._prefetched = None
         self.loss_type = config.loss
         if self.loss_type != 'cosine':
             raise NotImplementedError("only loss: cosine (the ACT recipe) is on this path")
@@ -423,18 +425,45 @@ class ACT_PointDistillation(nn.Module):
             neighborhood, center = self.group_divider(pts)
             return self.ACT_encoder(neighborhood, center, only_cls_tokens=True, noaug=True)
 
+    def prefetch_teacher(self, next_pts):
+        """Software pipelining across steps (exact: the teacher is frozen, so its features for batch i+1 do not depend on the
+        optimizer step of batch i).  Enqueues grouping + teacher forward of the NEXT batch on the auxiliary stream; called by the
+        runner between forward and backward of the current batch, so the teacher's large GEMMs share the chip with the student's
+        small backward kernels.  ``forward(next_pts)`` picks the result up (same tensor object, unmodified since)."""
+        if not (_OVERLAP_TEACHER and _PREFETCH_TEACHER and next_pts.is_cuda and self.training):
+            return
+        main, side = torch.cuda.current_stream(next_pts.device), K.side_stream(next_pts.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            neighborhood, center = self.group_divider(next_pts)
+            grouped = torch.cuda.Event()
+            grouped.record(side)
+            feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=None)
+        self._prefetched = (next_pts, next_pts._version, neighborhood, center, feat, grouped)
+
     def forward(self, pts, noaug=False, draws=None, **kwargs):
         if noaug:
             return self.forward_eval(pts)
-        neighborhood, center = self.group_divider(pts)
-        # The frozen teacher only depends on the grouped points: it runs on a second HIP stream, concurrently with the student's
-        # forward (whose 1,792-row GEMMs leave most CUs idle), and is joined right before the loss.
+        # The frozen teacher only depends on the grouped points: it runs on a second HIP stream, concurrently with the student
+        # (whose 1,792-row GEMMs leave most CUs idle), and is joined right before the loss.  If the runner announced this batch
+        # with prefetch_teacher() during the previous step, grouping + teacher are already in flight (or done).
         overlap = _OVERLAP_TEACHER and pts.is_cuda
-        if overlap:
+        pre = self._prefetched
+        self._prefetched = None
+        if pre is not None and pre[0] is pts and pre[1] == pts._version and draws is None:
+            _, _, neighborhood, center, teacher_feat, grouped = pre
             main, side = torch.cuda.current_stream(pts.device), K.side_stream(pts.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side), torch.no_grad():
-                teacher_feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
+            main.wait_event(grouped)                     # the student needs the grouping now, the teacher features only at the loss
+            for t in (neighborhood, center):
+                t.record_stream(main)
+            overlap = True
+        else:
+            neighborhood, center = self.group_divider(pts)
+            if overlap:
+                main, side = torch.cuda.current_stream(pts.device), K.side_stream(pts.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side), torch.no_grad():
+                    teacher_feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
         x_vis, mask = self.ACT_encoder(neighborhood, center, draws=draws)
         B, _, C = x_vis.shape
         if not overlap:

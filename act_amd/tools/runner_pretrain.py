@@ -60,11 +60,22 @@ class _Single(nn.Module):
         return self.module(*a, **k)
 
 
-def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, draws=None):
-    """one optimisation step on a device batch [B,N,3]; returns the detached loss tensor (no host sync)."""
-    if augment:
+def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, draws=None, next_points=None):
+    """one optimisation step on a device batch [B,N,3]; returns the detached loss tensor (no host sync).
+
+    ``next_points`` (optional): the NEXT batch.  It is augmented here and announced to the model, which starts its grouping and
+    frozen-teacher forward on the auxiliary stream while this batch's backward runs; pass that same tensor as ``points`` of the
+    next call (it is not augmented twice)."""
+    if augment and not getattr(points, "_act_augmented", False):
         points = train_transforms(points)
     loss = base_model(points, draws=draws) if draws is not None else base_model(points)
+    if next_points is not None:
+        if augment:
+            next_points = train_transforms(next_points)
+            next_points._act_augmented = True
+        inner = base_model.module if hasattr(base_model, "module") else base_model
+        if hasattr(inner, "prefetch_teacher"):
+            inner.prefetch_teacher(next_points)
     loss.backward()
     if num_iter == config.step_per_update:
         optimizer.step()
@@ -111,20 +122,32 @@ def run_net(args, config, train_writer=None, val_writer=None, max_steps=None, lo
         num_iter = 0
         n_batches = len(train_dataloader)
         pending = []
-        for idx, (taxonomy_ids, model_ids, data) in enumerate(train_dataloader):
+        npoints = config.dataset.train.others.npoints
+        dataset_name = config.dataset.train._base_.NAME
+
+        def to_points(data):
+            if dataset_name == 'ShapeNet':
+                pts = data.to(device, non_blocking=True)
+            elif dataset_name == 'ModelNet':
+                pts = misc.fps(data[0].to(device, non_blocking=True), npoints)
+            else:
+                raise NotImplementedError(f'Train phase do not support {dataset_name}')
+            assert pts.size(1) == npoints
+            return pts
+
+        loader = iter(train_dataloader)
+        nxt = next(loader, None)
+        points = to_points(nxt[2]) if nxt is not None else None
+        for idx in range(n_batches):
+            if points is None:
+                break
             num_iter += 1
             n_itr = epoch * n_batches + idx
             data_time.update(time.time() - batch_start_time)
-            npoints = config.dataset.train.others.npoints
-            dataset_name = config.dataset.train._base_.NAME
-            if dataset_name == 'ShapeNet':
-                points = data.to(device, non_blocking=True)
-            elif dataset_name == 'ModelNet':
-                points = misc.fps(data[0].to(device, non_blocking=True), npoints)
-            else:
-                raise NotImplementedError(f'Train phase do not support {dataset_name}')
-            assert points.size(1) == npoints
-            loss = train_step(base_model, optimizer, points, config, num_iter)
+            nxt = next(loader, None)                         # one batch of look-ahead: its teacher forward overlaps this backward
+            next_points = to_points(nxt[2]) if nxt is not None else None
+            loss = train_step(base_model, optimizer, points, config, num_iter, next_points=next_points)
+            points = next_points
             if num_iter == config.step_per_update:
                 num_iter = 0
             if args.distributed:

@@ -62,6 +62,9 @@ def cpu_baseline(cfg_model, seconds_budget=25.0, B=8):
             "sample": f"{n} Stage-II steps (fwd+bwd+AdamW) of the pure-PyTorch CPU oracle at B={B}, N=1024, same geometry"}
 
 
+_NEXT = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +143,12 @@ def main():
         if args.stage == 1:
             l1, l2, _ = train_step_ae(wrapped, optimizer, pool[i % len(pool)], config, 20000 + i)
             return l1 + l2
-        return train_step(wrapped, optimizer, pool[i % len(pool)].clone(), config)
+        # software pipelining across steps: the NEXT batch is handed over too, so its (frozen) teacher forward runs on the
+        # auxiliary stream during this batch's backward; every step still executes exactly one teacher forward
+        global _NEXT
+        cur = _NEXT if _NEXT is not None else pool[i % len(pool)].clone()
+        _NEXT = pool[(i + 1) % len(pool)].clone()
+        return train_step(wrapped, optimizer, cur, config, next_points=_NEXT)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of the same bench command.
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python bench.py ...
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python bench.py ...
+    python benchmarks/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/rNN_pmc_traffic.json
+
+Kernel names are folded onto the profiler ids bench.py reports (sgemm_nt / sgemm_nn / sgemm_tn by the operand-layout template
+arguments).  Units / corrections: both counters are in KiB (MI355X_MICROARCH.md, HBM section, which also warns that FETCH_SIZE
+under-reports wide coalesced reads by 2x on gfx950).  Rather than trusting a fixed factor, the script calibrates BOTH counters
+in the same run on a streaming kernel of this repo whose byte counts are known exactly: affine_act_kernel (BatchNorm apply)
+reads and writes one [262144, C] fp32 tensor per launch, C = 128 and 512 twice each per Stage-II step, i.e. 335,544,320 B
+read and written per launch on average; bn_bwd_apply_kernel (reads 2x, writes 1x that) is reported as a cross-check.
+Traffic is counted at the L2 <-> fabric boundary, i.e. it includes Infinity-Cache hits."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def fold(name):
+    n = name.replace("void ", "").split("(")[0]
+    m = re.match(r"sgemm_kernel<\d+, \d+, \d+, (true|false), (true|false)", n)
+    if not m:
+        m = re.match(r"sgemm16_kernel<\d+, \d+, (true|false), (true|false)", n)
+    if m:
+        ak, bk = m.group(1) == "true", m.group(2) == "true"
+        return "sgemm_nt" if ak and bk else ("sgemm_nn" if ak else ("sgemm_tn" if not bk else "sgemm_tt"))
+    if n.startswith("sgemm_nt16_kernel"):
+        return "sgemm_nt"
+    if n.startswith("sgemm_tn_skinny_kernel"):
+        return "sgemm_tn"
+    return re.sub(r"<.*", "", n)[:60]
+
+
+def collect(d, counter):
+    tot = collections.defaultdict(lambda: [0.0, set()])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            e = tot[fold(r["Kernel_Name"])]
+            e[0] += float(r["Counter_Value"]); e[1].add((f, r["Dispatch_Id"]))
+    return {k: (v[0] / max(1, len(v[1])), len(v[1])) for k, v in tot.items()}
+
+
+CAL_KERNEL, CAL_BYTES = "affine_act_kernel", 262144.0 * (128 + 512) / 2 * 4
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+kf = CAL_BYTES / (fetch[CAL_KERNEL][0] * 1024.0)
+kw = CAL_BYTES / (write[CAL_KERNEL][0] * 1024.0)
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
+                 "--no-cpu-baseline --no-instrument",
+       "units": "bytes per launch = counter [KiB] * 1024 * calibration factor",
+       "calibration": {"kernel": CAL_KERNEL, "known_bytes_read_and_written_per_launch": CAL_BYTES, "fetch_factor": kf, "write_factor": kw,
+                       "cross_check": "bn_bwd_apply_kernel must come out at 2x / 1x the calibration bytes"},
+       "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    fb = fetch.get(k, (0.0, 0))[0] * 1024.0 * kf
+    wb = write.get(k, (0.0, 0))[0] * 1024.0 * kw
+    out["kernels"][k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
+                         "launches_profiled": max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1])}
+print(json.dumps(out, indent=1, sort_keys=True))
