@@ -238,3 +238,36 @@ def test_state_dict_keys_match_reference_listing(dev):
               "ACT_decoder.blocks.0.attn.qkv.weight", "ACT_decoder.norm.weight"]:
         assert k in keys, k
     assert not any("qkv.bias" in k for k in keys if k.startswith("ACT_encoder.") or k.startswith("ACT_decoder."))   # qkv_bias=False
+
+
+def test_cross_step_teacher_prefetch_is_exact(dev):
+    """Software pipelining across steps (next batch's grouping + frozen-teacher forward on the auxiliary stream during this
+    batch's backward) must not change a single bit of the training trajectory: 4 AdamW steps, pipelined vs sequential."""
+    import copy
+    import argparse
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import train_step, _Single, freeze_unused_heads
+    from act_amd.utils.config import EasyDict
+    cfg = EasyDict(optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3, weight_decay=0.05)),
+                   scheduler=dict(type="CosLR", kwargs=dict(epochs=300, initial_epochs=10)), step_per_update=1)
+    batches = [torch.from_numpy(clouds(20 + i, TINY_B, TINY_N)).to(dev) for i in range(4)]
+    results = []
+    for pipelined in (False, True):
+        model = _tiny(dev)
+        model.dvae_tokenizer.prompt_dropout.p = 0.0          # prompt dropout shares the device RNG with the mask draws
+        freeze_unused_heads(model)
+        wrapped = _Single(model)
+        opt, _ = builder.build_opti_sche(wrapped, cfg)
+        torch.manual_seed(123)
+        pts = [b.clone() for b in batches]
+        losses = []
+        for i in range(4):
+            nxt = pts[i + 1] if (pipelined and i + 1 < 4) else None
+            losses.append(train_step(wrapped, opt, pts[i], cfg, next_points=nxt))
+            if pipelined and nxt is not None:
+                assert model._prefetched is not None and model._prefetched[0] is nxt
+        torch.cuda.synchronize()
+        results.append((torch.stack(losses).cpu(), {n: p.detach().clone().cpu() for n, p in model.named_parameters()}))
+    assert torch.equal(results[0][0], results[1][0]), (results[0][0], results[1][0])
+    for n, p in results[0][1].items():
+        assert torch.equal(p, results[1][1][n]), n
