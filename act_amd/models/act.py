@@ -73,12 +73,25 @@ class Block(nn.Module):
             out.append(torch.floor(keep + u.to(device)) / keep)
         return out
 
-    def forward(self, x, pos=None, draws=None, tag="blk"):
-        g1, g2 = self.gates(x.shape[0], x.device, draws, tag)
+    def forward(self, x, pos=None, draws=None, tag="blk", gates=None):
+        g1, g2 = gates if gates is not None else self.gates(x.shape[0], x.device, draws, tag)
         a, m = self.attn, self.mlp
         return K.BlockFn.apply(x, pos, g1, g2, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
                                a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
                                m.fc2.bias, a.num_heads, self.norm1.eps, 2 if self.overlap_wgrad else 1)
+
+
+def stack_gates(blocks, B, device, draws, cache):
+    """DropPath gates floor(keep + U) / keep of ALL blocks of a stack in four launches (instead of four per branch per block);
+    -> list of (gate_attn, gate_mlp) per block, None for blocks whose rate is 0.  With injected draws the per-block path is kept."""
+    if draws is not None or not blocks[0].training or not any(b.drop_prob > 0 for b in blocks):
+        return [None] * len(blocks)
+    keep = cache.get(device)
+    if keep is None:
+        keep = cache[device] = torch.tensor([1.0 - b.drop_prob for b in blocks for _ in (0, 1)], dtype=torch.float32,
+                                            device=device).view(-1, 1)
+    g = torch.floor(keep + torch.rand(2 * len(blocks), B, dtype=torch.float32, device=device)) / keep
+    return [(g[2 * i], g[2 * i + 1]) if b.drop_prob > 0 else None for i, b in enumerate(blocks)]
 
 
 class TransformerEncoder(nn.Module):
@@ -92,8 +105,9 @@ class TransformerEncoder(nn.Module):
             for i in range(depth)])
 
     def forward(self, x, pos, draws=None, tag="enc"):
+        gates = stack_gates(self.blocks, x.shape[0], x.device, draws, self.__dict__.setdefault("_keep_cache", {}))
         for i, block in enumerate(self.blocks):
-            x = block(x, pos, draws, f"{tag}.{i}")
+            x = block(x, pos, draws, f"{tag}.{i}", gates[i])
         return x
 
 
@@ -120,8 +134,9 @@ class TransformerDecoder(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward(self, x, pos, return_token_num, draws=None, tag="dec"):
+        gates = stack_gates(self.blocks, x.shape[0], x.device, draws, self.__dict__.setdefault("_keep_cache", {}))
         for i, block in enumerate(self.blocks):
-            x = block(x, pos, draws, f"{tag}.{i}")
+            x = block(x, pos, draws, f"{tag}.{i}", gates[i])
         x = x[:, -return_token_num:].contiguous()          # only the mask tokens are predicted
         return K.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
 
