@@ -251,6 +251,79 @@ extern "C" int act_layernorm_fwd_f32(const float* x, const float* pos, const flo
     ACT_LAUNCH_CHECK(); return 0;
 }
 
+// Prompt rows of the prompt-tuned Transformer (models/dvae.py:485-498,556-566), frozen-teacher form: for every cloud b and prompt p
+//   v = dropout(tok[p,:]) + ppos[p,:]   (inverted dropout, keep mask from Philox keyed by (seed, b*P+p, c/4))   ->  LN(v) * gamma + beta
+// one launch instead of expand + dropout + add + LayerNorm, and the [B*P, D] intermediate is never written.
+__global__ __launch_bounds__(256) void prompt_layernorm_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ ppos, int P,
+                                                                   float drop_p, uint64_t seed, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float* __restrict__ y, int T, int D,
+                                                                   float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const int nv = D >> 2, pr = row % P;
+    const float4* __restrict__ xr = reinterpret_cast<const float4*>(tok + (size_t)pr * D);
+    const float4* __restrict__ qr = reinterpret_cast<const float4*>(ppos + (size_t)pr * D);
+    const float inv_keep = 1.0f / (1.0f - drop_p);
+    const uint32_t thr = (uint32_t)(drop_p * 16777216.0f);              // drop when the top 24 random bits < thr
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 a = xr[c];
+            if (drop_p > 0.f) {
+                uint32_t r[4];
+                philox4x32_10((uint32_t)c, (uint32_t)row, 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+                a.x = (r[0] >> 8) < thr ? 0.f : a.x * inv_keep; a.y = (r[1] >> 8) < thr ? 0.f : a.y * inv_keep;
+                a.z = (r[2] >> 8) < thr ? 0.f : a.z * inv_keep; a.w = (r[3] >> 8) < thr ? 0.f : a.w * inv_keep;
+            }
+            const float4 b = qr[c];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            v[i] = a;
+            s += (a.x + a.y) + (a.z + a.w);
+        } else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float mean = wave_sum_f32(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum_f32(q) / (float)D + eps);
+    float4* __restrict__ yr = reinterpret_cast<float4*>(y + (size_t)row * D);
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 g = g4[c], b = b4[c];
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            yr[c] = o;
+        }
+    }
+}
+
+extern "C" int act_prompt_layernorm_fwd_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
+                                            const float* gamma, const float* beta, float eps, float* y, act_stream_t stream) {
+    if (!tok || !ppos || !gamma || !beta || !y) return ACT_E_NULLPTR;
+    if (B < 0 || P <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV || drop_p < 0.f || drop_p >= 1.f) return ACT_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = B * P;
+    ActProfScope ps(KID_LAYERNORM_FWD, s, 0.0, 4.0 * T * (double)D);
+    hipLaunchKernelGGL(prompt_layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, tok, ppos, P, drop_p, seed, gamma, beta, y, T, D, eps);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
 static int ln_rows_per_block(int T) { int r = (T + 1023) / 1024; r = (r + 3) / 4 * 4; return r < 16 ? 16 : r; }
 extern "C" size_t act_layernorm_bwd_workspace(int T, int D) {
     const int rpb = ln_rows_per_block(T); const int nblk = (T + rpb - 1) / rpb;

@@ -832,13 +832,28 @@ class PrefixBlockFn(torch.autograd.Function):
         return (dxin, dxin, dprm) + (None,) * 17
 
 
-def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps):
+_C._declare({"act_prompt_layernorm_fwd_f32": [_vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _f, _vp, _vp]})
+_C.SIGNATURES.setdefault("act_prompt_layernorm_fwd_f32", _C.lib.act_prompt_layernorm_fwd_f32.argtypes)
+
+
+def prompt_layernorm(tok, ppos, B, drop_p, seed, gamma, beta, eps):
+    """LN(dropout(tok) + ppos) for the B x P prompt rows of one layer of the frozen teacher, dropout mask from in-kernel Philox."""
+    P, D = tok.shape
+    y = torch.empty(B * P, D, dtype=torch.float32, device=tok.device)
+    check(lib.act_prompt_layernorm_fwd_f32(ptr(_f32c(tok)), ptr(_f32c(ppos)), B, P, D, float(drop_p), int(seed), ptr(gamma), ptr(beta),
+                                           float(eps), ptr(y), stream()), "act_prompt_layernorm_fwd_f32")
+    return y
+
+
+def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, n1p=None):
     """Inference-only pre-LN block on G 'patch' tokens per cloud with P extra 'prompt' tokens that act as keys/values only
-    (their outputs are discarded by the caller): x2d [B*G, D] (+ pos2d), prm2d [B*P, D] = prompt + prompt_pos.
+    (their outputs are discarded by the caller): x2d [B*G, D] (+ pos2d), prm2d [B*P, D] = prompt + prompt_pos (or n1p = its
+    LayerNorm, already computed by prompt_layernorm).
     Exactly the patch-token rows of  blk(cat(prompt, x) + cat(prompt_pos, pos))  of models/dvae.py:549-571."""
     D = x2d.shape[1]
     hd = D // heads
-    n1p, _, _, _ = layernorm_fwd(prm2d, None, n1w, n1b, eps, want_stats=False)
+    if n1p is None:
+        n1p, _, _, _ = layernorm_fwd(prm2d, None, n1w, n1b, eps, want_stats=False)
     kvp = gemm(n1p, wqkv[D:], True, True, bias=(bqkv[D:] if bqkv is not None else None))          # K,V of the prompts
     n1x, xin, _, _ = layernorm_fwd(x2d, pos2d, n1w, n1b, eps, want_stats=False)
     qkvx = gemm(n1x, wqkv, True, True, bias=bqkv)

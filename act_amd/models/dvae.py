@@ -323,15 +323,22 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         pos = K.mlp(center, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias).reshape(B * G, D)
         x = K.linear(input, self.proj_pre.weight, self.proj_pre.bias).reshape(B * G, D)
         blocks = self.visual_embed[0]
+        drop_p = self.prompt_dropout.p if self.training else 0.0
+        fused = draws is None or not (draws.record or any(draws.has(f"prompt.{i}") for i in range(self.visual_embed_depth)))
+        seeds = torch.randint(0, 2 ** 62, (self.visual_embed_depth,)).tolist() if fused else None      # host RNG: no device sync
         for i in range(self.visual_embed_depth):
             tok = self.visual_prompt_token[0] if i == 0 else self.deep_prompt_tokens[i - 1]
             ppos = self.visual_prompt_pos[0] if i == 0 else self.deep_prompt_pos[i - 1]
-            prm = (self._drop(tok.unsqueeze(0).expand(B, -1, -1), draws, f"prompt.{i}") + ppos).reshape(B * Pn, D)
             blk = blocks[i]
             a, m = blk.attn, blk.mlp
+            prm = n1p = None
+            if fused:       # dropout (in-kernel Philox) + prompt position + LayerNorm in one launch
+                n1p = K.prompt_layernorm(tok, ppos, B, drop_p, seeds[i], blk.norm1.weight, blk.norm1.bias, blk.eps)
+            else:           # injected / recorded dropout masks (parity tests)
+                prm = (self._drop(tok.unsqueeze(0).expand(B, -1, -1), draws, f"prompt.{i}") + ppos).reshape(B * Pn, D)
             x = K.block_forward_prefix(x, pos, prm, B, Pn, G, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias,
                                        a.proj.weight, a.proj.bias, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias,
-                                       m.fc2.weight, m.fc2.bias, blk.num_heads, blk.eps)
+                                       m.fc2.weight, m.fc2.bias, blk.num_heads, blk.eps, n1p=n1p)
         nrm = self.visual_embed[1]
         feature = K.layer_norm(x, nrm.weight, nrm.bias, nrm.eps)
         return K.linear(feature, self.proj_post.weight, self.proj_post.bias).reshape(B, G, -1)

@@ -111,6 +111,10 @@ int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const floa
  * `x = blk(x + pos)` of :109-112,140-143 fused in).  xin_out / mean / rstd are nullable. D % 4 == 0, D <= 2048. */
 int act_layernorm_fwd_f32(const float* x, const float* pos, const float* gamma, const float* beta, float* xin_out,
                           float* y, float* mean, float* rstd, int T, int D, float eps, act_stream_t stream);
+/* Frozen-teacher prompt rows (models/dvae.py:485-498,556-566): y[b*P+p,:] = LN(dropout(tok[p,:]) + ppos[p,:]) * gamma + beta,
+ * inverted dropout with rate drop_p, keep mask from Philox4x32-10 keyed by (seed, row, column/4); tok, ppos [P,D]; y [B*P,D]. */
+int act_prompt_layernorm_fwd_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
+                                 const float* gamma, const float* beta, float eps, float* y, act_stream_t stream);
 /* dx = dres (nullable, residual-stream gradient) + LayerNorm backward of dy; dgamma/dbeta (nullable) summed over
  * rows in a fixed order through `workspace` (act_layernorm_bwd_workspace bytes). */
 size_t act_layernorm_bwd_workspace(int T, int D);

@@ -365,6 +365,44 @@ def test_soft_gumbel_softmax_and_kl_to_uniform(K, B, G, C, tau):
     assert _rel(lg2.grad, ld2.grad) <= 5e-5
 
 
+def test_prompt_layernorm_fused_dropout(K):
+    """LN(dropout(tok) + ppos): exact against the oracle formula for p = 0; for p = 0.1 the rows are valid LayerNorm outputs of
+    a mask with the right drop rate, deterministic per seed and different per cloud."""
+    import torch.nn.functional as F
+    B, P, D = 6, 64, 768
+    tok = _rnd("pl.t", P, D); ppos = _rnd("pl.p", P, D) * 0.3; g = 1 + 0.2 * _rnd("pl.g", D); b = 0.1 * _rnd("pl.b", D)
+    ref = F.layer_norm((tok + ppos).double(), (D,), g.double(), b.double(), 1e-6)
+    y0 = K.prompt_layernorm(tok.cuda(), ppos.cuda(), B, 0.0, 5, g.cuda(), b.cuda(), 1e-6).view(B, P, D)
+    for bb in range(B):
+        assert _rel(y0[bb], ref) <= 2e-5
+    y1 = K.prompt_layernorm(tok.cuda(), ppos.cuda(), B, 0.1, 5, g.cuda(), b.cuda(), 1e-6).view(B, P, D)
+    y2 = K.prompt_layernorm(tok.cuda(), ppos.cuda(), B, 0.1, 5, g.cuda(), b.cuda(), 1e-6).view(B, P, D)
+    y3 = K.prompt_layernorm(tok.cuda(), ppos.cuda(), B, 0.1, 6, g.cuda(), b.cuda(), 1e-6).view(B, P, D)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3) and not torch.equal(y1[0], y1[1])
+    # invert the affine LayerNorm map per row to recover which elements were dropped: v = tok*keep/0.9 + ppos
+    xhat = (y1.double().cpu() - b.double()) / g.double()                        # = (v - mean) * rstd
+    # a dropped element has v == ppos; solve for (mean, rstd) per row by least squares on the two candidate values
+    cand_keep = (tok / 0.9 + ppos).double(); cand_drop = ppos.double()
+    frac = []
+    for bb in range(2):
+        for pp in range(4):
+            xr = xhat[bb, pp]
+            best = None
+            # rows are long (768): fit v = xr / rstd + mean using the assumption that most elements are kept
+            A = torch.stack((xr, torch.ones_like(xr)), 1)
+            sol = torch.linalg.lstsq(A, cand_keep[pp].unsqueeze(1)).solution.squeeze(1)
+            for _ in range(5):
+                v = xr * sol[0] + sol[1]
+                kept = (v - cand_keep[pp]).abs() < (v - cand_drop[pp]).abs()
+                target = torch.where(kept, cand_keep[pp], cand_drop[pp])
+                sol = torch.linalg.lstsq(A, target.unsqueeze(1)).solution.squeeze(1)
+            v = xr * sol[0] + sol[1]
+            err = torch.minimum((v - cand_keep[pp]).abs(), (v - cand_drop[pp]).abs()).max().item()
+            assert err < 1e-3, err                                               # every element is one of the two admissible values
+            frac.append(1.0 - kept.float().mean().item())
+    assert 0.06 < sum(frac) / len(frac) < 0.14                                   # drop rate 0.1
+
+
 def test_gumbel_argmax_codebook_fused(K):
     import torch.nn.functional as F
     B, G, C, D = 4, 16, 512, 48
