@@ -80,6 +80,17 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def ptr_rows(t):
+    """device pointer of a 2-D CUDA tensor with unit inner stride (row-strided views allowed: the callee takes a leading dimension)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ActHipError("act_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
+    if not (t.is_contiguous() or (t.dim() == 2 and t.stride(1) == 1)):
+        raise ActHipError("act_amd GEMM operands need unit inner stride")
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -108,11 +108,21 @@ def _f32c(t, name="tensor"):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _f32rows(t, name="tensor"):
+    """2-D operand with unit inner stride (row-strided views such as column slices of a weight are passed as is: the GEMM
+    takes a leading dimension)."""
+    if t.dtype != torch.float32:
+        raise _C.ActHipError(f"{name}: expected float32")
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return t.contiguous()
+
+
 # ---- raw wrappers ---------------------------------------------------------------------------------------
 def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, res=None, rowscale=None,
          rows_per_scale=0, out=None, accumulate=False, alpha=1.0, res_row_div=0, cfg=None):
     """C[M,N] = epilogue(op(a) @ op(b)); a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N]."""
-    a = _f32c(a, "a"); b = _f32c(b, "b")
+    a = _f32rows(a, "a"); b = _f32rows(b, "b")
     if a_kmajor:
         M, K = a.shape
     else:
@@ -130,7 +140,7 @@ def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, 
                      res_row_div=int(res_row_div), bias=ptr(bias), rowscale=ptr(rowscale), res=ptr(res), aux=ptr(aux))
     ws = workspace(a.device)
     tile, splits = cfg if cfg is not None else _gemm_config(a, b, a_kmajor, b_kmajor, M, N, K, ws)
-    check(lib.act_sgemm_ex_f32(int(a_kmajor), int(b_kmajor), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out),
+    check(lib.act_sgemm_ex_f32(int(a_kmajor), int(b_kmajor), M, N, K, _C.ptr_rows(a), a.stride(0), _C.ptr_rows(b), b.stride(0), ptr(out),
                                out.stride(0), ctypes.byref(e), ptr(ws), ws.numel() * 4, tile, splits, stream()), "act_sgemm_f32")
     return out
 
@@ -184,7 +194,7 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for tile, sp in cands:
         def run():
-            return lib.act_sgemm_ex_f32(int(ak), int(bk), M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(scratch), N,
+            return lib.act_sgemm_ex_f32(int(ak), int(bk), M, N, K, _C.ptr_rows(a), a.stride(0), _C.ptr_rows(b), b.stride(0), ptr(scratch), N,
                                         ctypes.byref(e), ptr(ws), ws.numel() * 4, tile, sp, stream())
         if run() != 0:
             continue

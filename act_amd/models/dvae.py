@@ -110,7 +110,16 @@ class DGCNN(nn.Module):
         w = _w2d(conv)
         cin = w.shape[1] // 2
         wa, wb = w[:, :cin], w[:, cin:]
-        return torch.cat((wa, wb - wa), dim=0)                            # rows: [Wa ; Wb - Wa]
+        if torch.is_grad_enabled() and w.requires_grad:
+            return torch.cat((wa, wb - wa), dim=0)                        # rows: [Wa ; Wb - Wa]
+        # frozen / no-grad use (Stage-II teacher): the stacked matrix only changes when the weight does
+        cache = conv.__dict__.get("_act_stacked")
+        key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.device)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, torch.cat((wa, wb - wa), dim=0))
+            conv.__dict__["_act_stacked"] = cache
+        return cache[1]
 
     @staticmethod
     def _edge_layer(f, idx, layer, B, G, out=None, ooff=0):
