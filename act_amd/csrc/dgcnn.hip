@@ -96,10 +96,12 @@ __global__ __launch_bounds__(256) void gumbel_argmax_gather_kernel(const float* 
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float slope, const float* __restrict__ noise, uint64_t seed,
+                                                                   const uint64_t* __restrict__ seed_dev,
                                                                    float inv_tau, const float* __restrict__ codebook, int D,
                                                                    int64_t* __restrict__ index_out, float* __restrict__ out,
                                                                    float* __restrict__ logits_out) {
     __shared__ float sv[4]; __shared__ int si[4]; __shared__ int swin;
+    if (seed_dev) seed ^= seed_dev[0] * 0x9E3779B97F4A7C15ull;      // device-resident step counter (replayable from a hipGraph)
     const int row = blockIdx.x, b = row / G;
     const int cpg = C / groups;
     float best = -3.0e38f; int bi = 0;
@@ -300,8 +302,8 @@ extern "C" int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff,
 }
 
 extern "C" int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int C, int groups, const float* gamma, const float* beta,
-                                               float eps, float slope, const float* noise, uint64_t seed, float tau,
-                                               const float* codebook, int D, float* stats, int64_t* index_out, float* out,
+                                               float eps, float slope, const float* noise, uint64_t seed, const uint64_t* seed_dev,
+                                               float tau, const float* codebook, int D, float* stats, int64_t* index_out, float* out,
                                                float* logits_out, act_stream_t stream) {
     if (!h || !gamma || !beta || !codebook || !stats || !out) return ACT_E_NULLPTR;
     if (B <= 0 || G <= 0 || C <= 0 || (C & 3) || groups <= 0 || C % groups || D <= 0 || tau <= 0.f) return ACT_E_BADARG;
@@ -313,7 +315,7 @@ extern "C" int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int
     hipLaunchKernelGGL(edge_gn_finalize_kernel, dim3((B * groups + 63) / 64), dim3(64), 0, s, h, C, -1, nullptr, G, 1, C, groups, B * groups,
                        part, eps, mean, rstd);
     hipLaunchKernelGGL(gumbel_argmax_gather_kernel, dim3(B * G), dim3(256), 0, s, h, G, C, groups, mean, rstd, gamma, beta, slope, noise, seed,
-                       1.0f / tau, codebook, D, index_out, out, logits_out);
+                       seed_dev, 1.0f / tau, codebook, D, index_out, out, logits_out);
     ACT_LAUNCH_CHECK(); return 0;
 }
 

@@ -255,9 +255,11 @@ extern "C" int act_layernorm_fwd_f32(const float* x, const float* pos, const flo
 //   v = dropout(tok[p,:]) + ppos[p,:]   (inverted dropout, keep mask from Philox keyed by (seed, b*P+p, c/4))   ->  LN(v) * gamma + beta
 // one launch instead of expand + dropout + add + LayerNorm, and the [B*P, D] intermediate is never written.
 __global__ __launch_bounds__(256) void prompt_layernorm_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ ppos, int P,
-                                                                   float drop_p, uint64_t seed, const float* __restrict__ gamma,
+                                                                   float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
+                                                                   const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float* __restrict__ y, int T, int D,
                                                                    float eps) {
+    if (seed_dev) seed ^= seed_dev[0] * 0x9E3779B97F4A7C15ull;      // device-resident step counter (replayable from a hipGraph)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -313,14 +315,15 @@ __global__ __launch_bounds__(256) void prompt_layernorm_fwd_kernel(const float* 
 }
 
 extern "C" int act_prompt_layernorm_fwd_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
-                                            const float* gamma, const float* beta, float eps, float* y, act_stream_t stream) {
+                                            const uint64_t* seed_dev, const float* gamma, const float* beta, float eps, float* y,
+                                            act_stream_t stream) {
     if (!tok || !ppos || !gamma || !beta || !y) return ACT_E_NULLPTR;
     if (B < 0 || P <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV || drop_p < 0.f || drop_p >= 1.f) return ACT_E_BADARG;
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int T = B * P;
     ActProfScope ps(KID_LAYERNORM_FWD, s, 0.0, 4.0 * T * (double)D);
-    hipLaunchKernelGGL(prompt_layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, tok, ppos, P, drop_p, seed, gamma, beta, y, T, D, eps);
+    hipLaunchKernelGGL(prompt_layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, tok, ppos, P, drop_p, seed, seed_dev, gamma, beta, y, T, D, eps);
     ACT_LAUNCH_CHECK(); return 0;
 }
 

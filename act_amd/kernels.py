@@ -636,7 +636,7 @@ def linear_group_add(x, w, g, n):
 _u64 = ctypes.c_uint64
 _C._declare({
     "act_edge_gn_lrelu_max_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _vp],
-    "act_gn_gumbel_argmax_gather_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _u64, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "act_gn_gumbel_argmax_gather_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _u64, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "act_edge_gn_lrelu_max_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
     "act_gumbel_softmax_fwd_f32": [_vp, _i, _i, _vp, _u64, _f, _vp, _vp],
     "act_gumbel_softmax_bwd_f32": [_vp, _vp, _i, _i, _f, _vp, _vp],
@@ -755,7 +755,7 @@ def kl_to_uniform(logits):
     return KLUniformFn.apply(logits).reshape(())
 
 
-def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, want_logits=False, slope=0.2):
+def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, want_logits=False, slope=0.2, seed_dev=None):
     """fused layer5 GroupNorm + LeakyReLU + hard gumbel-softmax + codebook lookup -> (codes [B,G,D], index [B,G], logits|None)."""
     h = _f32c(h)
     C = h.shape[1]
@@ -767,7 +767,7 @@ def gn_gumbel_argmax_gather(h, B, G, gn, codebook, noise=None, seed=0, tau=1.0, 
     logits = torch.empty(B, G, C, dtype=torch.float32, device=dev) if want_logits else None
     noise = _f32c(noise) if noise is not None else None
     check(lib.act_gn_gumbel_argmax_gather_f32(ptr(h), B, G, C, gn.num_groups, ptr(gn.weight), ptr(gn.bias), float(gn.eps), float(slope),
-                                              ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF, float(tau), ptr(_f32c(codebook)), D, ptr(stats),
+                                              ptr(noise), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(seed_dev), float(tau), ptr(_f32c(codebook)), D, ptr(stats),
                                               ptr(index), ptr(out), ptr(logits), stream()), "act_gn_gumbel_argmax_gather_f32")
     return out, index, logits
 
@@ -842,15 +842,15 @@ class PrefixBlockFn(torch.autograd.Function):
         return (dxin, dxin, dprm) + (None,) * 17
 
 
-_C._declare({"act_prompt_layernorm_fwd_f32": [_vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _f, _vp, _vp]})
+_C._declare({"act_prompt_layernorm_fwd_f32": [_vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp, _f, _vp, _vp]})
 _C.SIGNATURES.setdefault("act_prompt_layernorm_fwd_f32", _C.lib.act_prompt_layernorm_fwd_f32.argtypes)
 
 
-def prompt_layernorm(tok, ppos, B, drop_p, seed, gamma, beta, eps):
+def prompt_layernorm(tok, ppos, B, drop_p, seed, gamma, beta, eps, seed_dev=None):
     """LN(dropout(tok) + ppos) for the B x P prompt rows of one layer of the frozen teacher, dropout mask from in-kernel Philox."""
     P, D = tok.shape
     y = torch.empty(B * P, D, dtype=torch.float32, device=tok.device)
-    check(lib.act_prompt_layernorm_fwd_f32(ptr(_f32c(tok)), ptr(_f32c(ppos)), B, P, D, float(drop_p), int(seed), ptr(gamma), ptr(beta),
+    check(lib.act_prompt_layernorm_fwd_f32(ptr(_f32c(tok)), ptr(_f32c(ppos)), B, P, D, float(drop_p), int(seed), ptr(seed_dev), ptr(gamma), ptr(beta),
                                            float(eps), ptr(y), stream()), "act_prompt_layernorm_fwd_f32")
     return y
 

@@ -319,10 +319,20 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
             return t * keep / (1.0 - p)
         return F.dropout(t, p, True)
 
-    def visual_embedding(self, input, center, draws=None):
-        return self.visual_embedding_deep_prompt(input, center, draws=draws)
+    def visual_embedding(self, input, center, draws=None, rng=None):
+        return self.visual_embedding_deep_prompt(input, center, draws=draws, rng=rng)
 
-    def _visual_embedding_prefix(self, input, center, draws=None):
+    def _rng(self, device):
+        """(base seed, device-resident step counter) of the in-kernel Philox draws of the frozen-teacher path.  The counter lives
+        in HBM and is bumped by a device op per teacher forward, so a captured hipGraph of that forward draws fresh noise on
+        every replay and eager / replayed executions produce the same sequence."""
+        st = self.__dict__.get("_rng_state")
+        if st is None or st[1].device != device:
+            st = (int(torch.randint(0, 2 ** 62, (1,)).item()), torch.zeros(1, dtype=torch.int64, device=device))
+            self.__dict__["_rng_state"] = st
+        return st
+
+    def _visual_embedding_prefix(self, input, center, draws=None, rng=None):
         """Inference form of visual_embedding_deep_prompt.  Every layer REPLACES the prompt rows of its input
         (models/dvae.py:556-566) and the final output drops them (:574), so prompt tokens only ever act as keys/values:
         queries, projection and MLP are evaluated for the G patch tokens only (58 % of the FLOPs, identical outputs)."""
@@ -334,7 +344,7 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         blocks = self.visual_embed[0]
         drop_p = self.prompt_dropout.p if self.training else 0.0
         fused = draws is None or not (draws.record or any(draws.has(f"prompt.{i}") for i in range(self.visual_embed_depth)))
-        seeds = torch.randint(0, 2 ** 62, (self.visual_embed_depth,)).tolist() if fused else None      # host RNG: no device sync
+        base, ctr = rng if rng is not None else self._rng(input.device)
         for i in range(self.visual_embed_depth):
             tok = self.visual_prompt_token[0] if i == 0 else self.deep_prompt_tokens[i - 1]
             ppos = self.visual_prompt_pos[0] if i == 0 else self.deep_prompt_pos[i - 1]
@@ -342,7 +352,8 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
             a, m = blk.attn, blk.mlp
             prm = n1p = None
             if fused:       # dropout (in-kernel Philox) + prompt position + LayerNorm in one launch
-                n1p = K.prompt_layernorm(tok, ppos, B, drop_p, seeds[i], blk.norm1.weight, blk.norm1.bias, blk.eps)
+                n1p = K.prompt_layernorm(tok, ppos, B, drop_p, (base + 7919 * (i + 1)) & (2 ** 62 - 1), blk.norm1.weight, blk.norm1.bias,
+                                         blk.eps, seed_dev=ctr)
             else:           # injected / recorded dropout masks (parity tests)
                 prm = (self._drop(tok.unsqueeze(0).expand(B, -1, -1), draws, f"prompt.{i}") + ppos).reshape(B * Pn, D)
             x = K.block_forward_prefix(x, pos, prm, B, Pn, G, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias,
@@ -374,10 +385,10 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         feature = K.layer_norm(x, nrm.weight, nrm.bias, nrm.eps)
         return K.linear(feature, self.proj_post.weight, self.proj_post.bias).reshape(B, G, -1)
 
-    def visual_embedding_deep_prompt(self, input, center, permute_feature=False, draws=None):
+    def visual_embedding_deep_prompt(self, input, center, permute_feature=False, draws=None, rng=None):
         """models/dvae.py:536-576 (+ incorporate_prompt :485-498): prompts replaced (not appended) at layers 1..L-1."""
         if not torch.is_grad_enabled():
-            return self._visual_embedding_prefix(input, center, draws)
+            return self._visual_embedding_prefix(input, center, draws, rng)
         if self.freeze_visual_embed:
             return self._visual_embedding_prefix_train(input, center, draws)
         B, G, _ = input.shape
@@ -427,11 +438,16 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
             noise = None
             if draws is not None and (draws.has("gumbel") or draws.record):
                 noise = draws.get("gumbel", lambda: -torch.empty(B, G, h.shape[1], device=h.device).exponential_().log())
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if noise is None else 0
-            sampled, _, _ = K.gn_gumbel_argmax_gather(h, B, G, self.dgcnn_1.layer5[1], self.codebook, noise=noise, seed=seed)
-        else:
-            logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
-            sampled = self._gumbel_codes(logits, 1.0, True, draws)
+            rng = self._rng(h.device)
+            sampled, _, _ = K.gn_gumbel_argmax_gather(h, B, G, self.dgcnn_1.layer5[1], self.codebook, noise=noise,
+                                                      seed=rng[0] ^ 0x5bd1e995, seed_dev=rng[1])
+            feature = self.visual_embedding(sampled, center, draws, rng)
+            if return_global:
+                feature = self.dgcnn_2(feature, center, idx)
+            rng[1].add_(1)                                 # next teacher forward draws a fresh Philox stream
+            return feature
+        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
+        sampled = self._gumbel_codes(logits, 1.0, True, draws)
         feature = self.visual_embedding(sampled, center, draws)
         if return_global:
             feature = self.dgcnn_2(feature, center, idx)

@@ -161,6 +161,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+    host_issue = time.perf_counter() - t0                # host time to enqueue the K steps (the GPU may still be running)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -185,7 +186,8 @@ def main():
                                ("configs[2]: ACT Stage-I autoencoder step (act_dvae_with_pretrained_transformer.yaml geometry): "
                                 "B=%d clouds/GPU x 1024 pts, tokenizer + prompt-tuned frozen ViT-B + FoldingNet, "
                                 "Chamfer-L1 + KL losses, fwd+bwd+AdamW" % B),
-                   "clouds_per_gpu": B, "points_per_cloud": N, "parallelism": f"dp{world}", "final_loss": loss_val},
+                   "clouds_per_gpu": B, "points_per_cloud": N, "parallelism": f"dp{world}", "final_loss": loss_val,
+                   "host_enqueue_ms_per_step": 1e3 * host_issue / args.steps},
     }
 
     if rank == 0 and not args.no_instrument:

@@ -112,9 +112,11 @@ int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const floa
 int act_layernorm_fwd_f32(const float* x, const float* pos, const float* gamma, const float* beta, float* xin_out,
                           float* y, float* mean, float* rstd, int T, int D, float eps, act_stream_t stream);
 /* Frozen-teacher prompt rows (models/dvae.py:485-498,556-566): y[b*P+p,:] = LN(dropout(tok[p,:]) + ppos[p,:]) * gamma + beta,
- * inverted dropout with rate drop_p, keep mask from Philox4x32-10 keyed by (seed, row, column/4); tok, ppos [P,D]; y [B*P,D]. */
+ * inverted dropout with rate drop_p, keep mask from Philox4x32-10 keyed by (seed, row, column/4); tok, ppos [P,D]; y [B*P,D].
+ * seed_dev (nullable): device-resident 64-bit step counter mixed into the key, so a captured hipGraph draws fresh noise per replay. */
 int act_prompt_layernorm_fwd_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
-                                 const float* gamma, const float* beta, float eps, float* y, act_stream_t stream);
+                                 const uint64_t* seed_dev, const float* gamma, const float* beta, float eps, float* y,
+                                 act_stream_t stream);
 /* dx = dres (nullable, residual-stream gradient) + LayerNorm backward of dy; dgamma/dbeta (nullable) summed over
  * rows in a fixed order through `workspace` (act_layernorm_bwd_workspace bytes). */
 size_t act_layernorm_bwd_workspace(int T, int D);
@@ -199,7 +201,7 @@ int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff, const int6
  * out [B*G, D] = codebook[index]  (F.gumbel_softmax(hard=True) + einsum with the codebook, models/dvae.py:587-588).
  * noise [B*G, C] (nullable: Philox4x32-10 keyed by seed); index_out / logits_out nullable. */
 int act_gn_gumbel_argmax_gather_f32(const float* h, int B, int G, int C, int groups, const float* gamma, const float* beta,
-                                    float eps, float slope, const float* noise, uint64_t seed, float tau,
+                                    float eps, float slope, const float* noise, uint64_t seed, const uint64_t* seed_dev, float tau,
                                     const float* codebook, int D, float* stats, int64_t* index_out, float* out,
                                     float* logits_out, act_stream_t stream);
 /* Stage-I tokenizer (models/dvae.py:600, 470-476).  Soft gumbel-softmax over rows: y = softmax((logits + G)/tau), G = noise
