@@ -91,8 +91,19 @@ def ptr_rows(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def stream_handle(device_index=None):
+    """raw hipStream_t (int) of torch's current stream on the device: the cheap C accessor when this torch build has it
+    (torch.cuda.current_stream() costs ~7 us of Python per call, and a step makes ~4,000 of them)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device() if device_index is None else device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(stream_handle())
 
 
 # ---- profiler helpers -------------------------------------------------------------------------

@@ -51,7 +51,8 @@ _WS_BYTES = 64 << 20
 
 def workspace(device, nbytes=_WS_BYTES):
     """scratch buffer of the CURRENT stream on ``device`` (kernels of different streams may run concurrently)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _C.stream_handle(idx))
     w = _WS.get(key)
     if w is None or w.numel() * 4 < nbytes:
         w = torch.empty(max(nbytes, _WS_BYTES) // 4, dtype=torch.float32, device=device)
