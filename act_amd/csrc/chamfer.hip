@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void chamfer_large_bwd(const float* __restrict
 
 extern "C" int act_chamfer_fwd_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
                                    int32_t* idx1, int32_t* idx2, act_stream_t stream) {
+    if (B == 0) return 0;
     if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2) return ACT_E_NULLPTR;
     if (B < 0 || n <= 0 || m <= 0 || B > 65535 * 4) return ACT_E_BADARG;
-    if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_CHAMFER_FWD, s, 0.0, (double)B * 20.0 * (n + m));      // 12(n+m) read + 8(n+m) write
     if (n <= 64 && m <= 64) {
@@ -150,9 +150,9 @@ extern "C" int act_chamfer_fwd_f32(const float* xyz1, const float* xyz2, int B, 
 extern "C" int act_chamfer_bwd_f32(const float* xyz1, const float* xyz2, const int32_t* idx1, const int32_t* idx2,
                                    const float* g1, const float* g2, int B, int n, int m, float* gx1, float* gx2,
                                    act_stream_t stream) {
+    if (B == 0) return 0;
     if (!xyz1 || !xyz2 || !idx1 || !idx2 || !g1 || !g2 || !gx1 || !gx2) return ACT_E_NULLPTR;
     if (B < 0 || n <= 0 || m <= 0) return ACT_E_BADARG;
-    if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_CHAMFER_BWD, s, 0.0, (double)B * 32.0 * (n + m));
     if (n <= 64 && m <= 64) {

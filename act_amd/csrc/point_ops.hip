@@ -167,9 +167,9 @@ static float* g_fps_temp = nullptr; static size_t g_fps_temp_n = 0;
 
 extern "C" int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_out, float* centers_out,
                            int skip_near_origin, act_stream_t stream) {
+    if (B == 0 || G == 0) return 0;                        // empty batch: nothing to do (empty tensors have NULL storage)
     if (!xyz || !idx_out) return ACT_E_NULLPTR;
     if (B < 0 || N <= 0 || G < 0) return ACT_E_BADARG;
-    if (B == 0 || G == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // algorithmic bytes: read xyz once, write idx (+ centers)  [SURVEY 8d]
     ActProfScope ps(KID_FPS, s, 0.0, (double)B * (12.0 * N + 4.0 * G + (centers_out ? 12.0 * G : 0.0)));
@@ -303,6 +303,7 @@ static int launch_knn(const float* ref, const float* query, int B, int N, int Q,
 
 extern "C" int act_knn_group_f32(const float* ref, const float* query, int B, int N, int Q, int K, int64_t* idx_out,
                                  int idx_kq, float* nbr_out, float* dist_out, act_stream_t stream) {
+    if (B == 0 || Q == 0) return 0;                        // empty batch: nothing to do (empty tensors have NULL storage)
     if (!ref || !query || !idx_out) return ACT_E_NULLPTR;
     if (B < 0 || N <= 0 || Q < 0 || K <= 0 || K > N) return ACT_E_BADARG;
     if (K > 64 && N <= 64 * 128) return ACT_E_BADARG;      // register path keeps the K winners one per lane
@@ -346,16 +347,16 @@ static inline unsigned grid_for(long long total, int block) {
     long long g = (total + block - 1) / block; if (g > 2048 * 4) g = 2048 * 4; if (g < 1) g = 1; return (unsigned)g;
 }
 extern "C" int act_gather_points_f32(const float* feat, const int32_t* idx, int B, int C, int N, int S, float* out, act_stream_t stream) {
-    if (!feat || !idx || !out) return ACT_E_NULLPTR;
     const long long total = (long long)B * C * S; if (total == 0) return 0;
+    if (!feat || !idx || !out) return ACT_E_NULLPTR;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_GATHER, s, 0.0, 8.0 * total + 4.0 * B * S);
     hipLaunchKernelGGL(gather_points_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, feat, idx, C, N, S, out, total);
     ACT_LAUNCH_CHECK(); return 0;
 }
 extern "C" int act_gather_points_bwd_f32(const float* go, const int32_t* idx, int B, int C, int N, int S, float* gf, act_stream_t stream) {
-    if (!go || !idx || !gf) return ACT_E_NULLPTR;
     const long long total = (long long)B * C * N; if (total == 0) return 0;
+    if (!go || !idx || !gf) return ACT_E_NULLPTR;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_GATHER_BWD, s, 0.0, 4.0 * total + 4.0 * B * C * S);
     hipLaunchKernelGGL(gather_points_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, go, idx, C, N, S, gf, total);
@@ -371,8 +372,8 @@ __global__ void scale_translate_kernel(float* __restrict__ pc, const float* __re
     }
 }
 extern "C" int act_scale_translate_f32(float* pc, const float* scale, const float* shift, int B, int N, act_stream_t stream) {
-    if (!pc || !scale || !shift) return ACT_E_NULLPTR;
     const long long total = (long long)B * N * 3; if (total == 0) return 0;
+    if (!pc || !scale || !shift) return ACT_E_NULLPTR;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_AUGMENT, s, 0.0, 8.0 * total);
     hipLaunchKernelGGL(scale_translate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, pc, scale, shift, N, total);
@@ -390,8 +391,8 @@ __global__ void rotate_points_kernel(float* __restrict__ pc, const float* __rest
     }
 }
 extern "C" int act_rotate_points_f32(float* pc, const float* rot, int B, int N, act_stream_t stream) {
-    if (!pc || !rot) return ACT_E_NULLPTR;
     const long long npts = (long long)B * N; if (npts == 0) return 0;
+    if (!pc || !rot) return ACT_E_NULLPTR;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_AUGMENT, s, 0.0, 24.0 * npts);
     hipLaunchKernelGGL(rotate_points_kernel, dim3(grid_for(npts, 256)), dim3(256), 0, s, pc, rot, N, npts);

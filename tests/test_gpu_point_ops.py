@@ -189,3 +189,69 @@ def test_profiler_reports_launches(dev):
     C.prof_enable(False)
     t = C.prof_table()
     assert t["fps"]["launches"] == 3 and t["fps"]["ms"] > 0 and t["fps"]["bytes"] == 3 * 8 * (12 * 1024 + 4 * 64)
+
+
+def test_edge_cases_empty_ragged_and_error_returns(dev):
+    """empty batches are no-ops, degenerate sizes work, bad arguments raise (the reference's wheels TORCH_CHECK -> RuntimeError;
+    its Chamfer extension only prints) -- never a silent wrong answer."""
+    import act_amd._C as C
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    from act_amd.knn_cuda import KNN
+    from act_amd.extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
+    from act_amd.utils import misc
+    # --- empty batch
+    e = torch.zeros(0, 128, 3, device=dev)
+    assert pu.furthest_point_sample(e, 8).shape == (0, 8)
+    d, i = KNN(k=4, transpose_mode=True)(e, torch.zeros(0, 8, 3, device=dev))
+    assert d.shape == (0, 8, 4) and i.shape == (0, 8, 4) and i.dtype == torch.int64
+    # --- N == G == K == 1
+    one = torch.tensor([[[0.25, -1.0, 3.0]]], device=dev)
+    assert pu.furthest_point_sample(one, 1).tolist() == [[0]]
+    d, i = KNN(k=1, transpose_mode=True)(one, one)
+    assert i.tolist() == [[[0]]] and d.abs().max().item() == 0.0
+    # --- ragged sizes: N not a multiple of the wave / tile sizes, K == N
+    pts = torch.from_numpy(clouds(30, 3, 37)).to(dev)
+    fi = pu.furthest_point_sample(pts, 37)
+    assert sorted(fi[0].tolist()) == list(range(37))                       # G == N: a permutation of all points
+    d, i = KNN(k=37, transpose_mode=True)(pts, pts[:, :5].contiguous())
+    assert (torch.sort(i, dim=-1)[0] == torch.arange(37, device=dev)).all() and (d[..., 1:] >= d[..., :-1]).all()
+    # --- bad arguments raise
+    over = pu.furthest_point_sample(pts, 40)                                # more samples than points (the reference wheel does not
+    assert sorted(over[0, :37].tolist()) == list(range(37))                 # check either): first N = all points, then all running
+    assert (over[:, 37:] == 0).all()                                        # distances are 0 -> lowest index, like the oracle
+    with pytest.raises(Exception):
+        KNN(k=38, transpose_mode=True)(pts, pts)                            # k > N
+    with pytest.raises(Exception):
+        pu.furthest_point_sample(pts.double(), 4)                           # wrong dtype
+    with pytest.raises(Exception):
+        pu.furthest_point_sample(pts.transpose(1, 2), 4)                    # wrong layout / non-contiguous
+    with pytest.raises(Exception):
+        ChamferDistanceL2()(pts, pts[:, :, :2].contiguous())                # not xyz
+    # --- Chamfer of a cloud with itself is exactly zero, L1 of identical clouds has zero loss
+    assert ChamferDistanceL2()(pts, pts.clone()).item() == 0.0
+    assert ChamferDistanceL1()(pts, pts.clone()).item() == 0.0
+    # --- misc.fps keeps gradient flow to the points like gather_operation does
+    x = pts.clone().requires_grad_(True)
+    misc.fps(x, 8).sum().backward()
+    assert x.grad is not None and x.grad.abs().sum().item() == 8 * 3 * 3   # one unit gradient per selected coordinate
+
+
+def test_maximum_sizes_stress_geometry_bit_exact(dev, oracle_c):
+    """C5 stress geometry of BASELINE.json (N=8192 points, 512 groups of 64) and a 20,000-point cloud through the rescan
+    fall-back: FPS / kNN indices bit-exact against the C oracle."""
+    import ctypes
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    from act_amd.knn_cuda import KNN
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for (B, N, G, M) in [(2, 8192, 512, 64), (1, 20000, 64, 32)]:
+        pts = clouds(40 + G, B, N)
+        fidx = np.empty((B, G), dtype=np.int32)
+        assert oracle_c.oracle_fps_f32(P(pts), B, N, G, P(fidx), 0) == 0
+        x = torch.from_numpy(pts).to(dev)
+        got = pu.furthest_point_sample(x, G)
+        assert np.array_equal(got.cpu().numpy(), fidx)
+        center = np.take_along_axis(pts, fidx[..., None].astype(np.int64), axis=1).copy()
+        kidx = np.empty((B, G, M), dtype=np.int64); kd = np.empty((B, G, M), dtype=np.float32)
+        assert oracle_c.oracle_knn_f32(P(pts), P(center), B, N, G, M, P(kidx), P(kd)) == 0
+        _, ki = KNN(k=M, transpose_mode=True)(x, torch.from_numpy(center).to(dev))
+        assert np.array_equal(ki.cpu().numpy(), kidx)
