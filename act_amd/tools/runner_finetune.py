@@ -58,8 +58,10 @@ def subsample(points, npoints, point_all, choice=None, fps_idx=None):
     if fps_idx is None:
         fps_idx = pointnet2_utils.furthest_point_sample(points, point_all)               # [B, point_all] int32
     if choice is None:
-        choice = np.random.choice(point_all, npoints, False)
-    sel = fps_idx[:, torch.as_tensor(choice, device=points.device, dtype=torch.long)].contiguous()
+        choice = torch.randperm(point_all, device=points.device)[:npoints]      # drawn on the device: a numpy choice would cost
+    else:                                                                       # a blocking pageable H2D copy every step
+        choice = torch.as_tensor(choice, device=points.device, dtype=torch.long)
+    sel = fps_idx[:, choice].contiguous()
     out = pointnet2_utils.gather_operation(points.transpose(1, 2).contiguous(), sel).transpose(1, 2).contiguous()
     return out, fps_idx
 
@@ -88,8 +90,10 @@ def train_step(base_model, optimizer, points, label, config, num_iter=1, augment
     loss.backward()
     if num_iter == config.step_per_update:
         if config.get('grad_norm_clip') is not None:
-            torch.nn.utils.clip_grad_norm_([p for p in base_model.parameters() if p.grad is not None], config.grad_norm_clip,
-                                           norm_type=2, foreach=True)
+            plist = base_model.__dict__.get("_act_trainable")
+            if plist is None:
+                plist = base_model.__dict__["_act_trainable"] = [p for p in base_model.parameters() if p.requires_grad]
+            torch.nn.utils.clip_grad_norm_([p for p in plist if p.grad is not None], config.grad_norm_clip, norm_type=2, foreach=True)
         optimizer.step()
         base_model.zero_grad(set_to_none=True)
     return loss.detach(), acc.detach()
