@@ -135,8 +135,11 @@ def main():
             model.eval()
 
     def step(i):
-        if args.stage == 3:
-            return train_step_ft(wrapped, optimizer, pool[i % len(pool)], labels, config)[0]
+        global _NEXT
+        if args.stage == 3:                                # look-ahead: the next raw batch is prepared (FPS pool etc.) during this backward
+            cur = _NEXT if _NEXT is not None else pool[i % len(pool)].clone()
+            _NEXT = pool[(i + 1) % len(pool)].clone()
+            return train_step_ft(wrapped, optimizer, cur, labels, config, next_points=_NEXT)[0]
         if args.stage == 4:
             with torch.no_grad():
                 return model(misc.fps(pool[i % len(pool)], N)).sum()
@@ -145,7 +148,6 @@ def main():
             return l1 + l2
         # software pipelining across steps: the NEXT batch is handed over too, so its (frozen) teacher forward runs on the
         # auxiliary stream during this batch's backward; every step still executes exactly one teacher forward
-        global _NEXT
         cur = _NEXT if _NEXT is not None else pool[i % len(pool)].clone()
         _NEXT = pool[(i + 1) % len(pool)].clone()
         return train_step(wrapped, optimizer, cur, config, next_points=_NEXT)
