@@ -114,8 +114,9 @@ def _f32rows(t, name="tensor"):
     takes a leading dimension)."""
     if t.dtype != torch.float32:
         raise _C.ActHipError(f"{name}: expected float32")
-    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
-        return t
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and (
+            t.is_contiguous() or (t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0)):
+        return t                              # strided views must keep the float4 path of the tuned kernels available
     return t.contiguous()
 
 

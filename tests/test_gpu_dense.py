@@ -498,6 +498,20 @@ def test_prefix_block_training_matches_full_block_autograd(K):
     assert _rel(mg.grad.reshape(B, P, D), prm.grad) <= TOL
 
 
+def test_gemm_row_strided_operands(K):
+    """column slices of a weight are passed with their leading dimension when that keeps the float4 path (stride % 4 == 0,
+    16-byte aligned) and copied otherwise -- FoldingNet's [512, 384+3+2] conv weight is the odd-stride case."""
+    x = _rnd("rs.x", 8192, 384).cuda()
+    for width, lo, hi in [(389, 0, 384), (512, 128, 512), (388, 4, 388), (389, 5, 389)]:
+        w = _rnd(f"rs.w{width}", 512, width).cuda()
+        ws = w[:, lo:hi]
+        xin = x[:, :hi - lo] if hi - lo <= 384 else _rnd("rs.x2", 8192, hi - lo).cuda()
+        ref = xin.double().cpu() @ ws.double().cpu().t()
+        assert _rel(K.gemm(xin, ws, True, True), ref) <= 2e-5, (width, lo, hi)
+        dy = _rnd(f"rs.dy{width}", 8192, 512).cuda()
+        assert _rel(K.gemm(dy, ws, True, False), dy.double().cpu() @ ws.double().cpu()) <= 2e-5       # NN with a strided B
+
+
 @pytest.mark.parametrize("M,N,Kd", [(128, 3, 262144), (3, 512, 65536), (512, 5, 40000), (1, 70, 4099), (100, 8, 2048)])
 def test_gemm_skinny_weight_gradient(K, M, N, Kd):
     """TN products with one dimension <= 8 (first conv / FoldingNet weight gradients) run the streaming-reduction kernel."""
