@@ -176,7 +176,8 @@ class Decoder(nn.Module):
         lin = torch.linspace(-0.05, 0.05, steps=self.grid_size, dtype=torch.float)
         a = lin.view(1, self.grid_size).expand(self.grid_size, self.grid_size).reshape(1, -1)
         b = lin.view(self.grid_size, 1).expand(self.grid_size, self.grid_size).reshape(1, -1)
-        self.folding_seed = torch.cat([a, b], dim=0).view(1, 2, self.grid_size ** 2)
+        # non-persistent buffer: follows .to(device) (a CPU attribute would cost a blocking H2D copy per step), not in the state_dict
+        self.register_buffer("folding_seed", torch.cat([a, b], dim=0).view(1, 2, self.grid_size ** 2), persistent=False)
 
     def forward(self, feature_global):
         """feature_global [B,G,C] -> coarse [B,G,M/4,3], fine [B,G,M,3]"""
