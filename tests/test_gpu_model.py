@@ -178,6 +178,40 @@ def test_no_host_sync_in_training_step(dev):
         torch.cuda.set_sync_debug_mode("default")
 
 
+def test_no_host_sync_in_stage1_and_finetune_steps(dev):
+    """the Stage-I autoencoder step and the finetune step (FPS pool, random subset, rotation, CE loss, accuracy, clipping,
+    AdamW) run without a device->host synchronisation as well (the reference: numpy-drawn index upload, two .item() per step)."""
+    from act_amd.models import build_model_from_cfg
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import _Single
+    from act_amd.tools import runner_autoencoder as RA, runner_finetune as RF
+    from act_amd.utils.config import EasyDict
+    from tests.golden.fill import TINY_FINETUNE
+    opt_cfg = dict(optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3, weight_decay=0.05)),
+                   scheduler=dict(type="CosLR", kwargs=dict(epochs=300, initial_epochs=10)), step_per_update=1)
+    # Stage I
+    mc = EasyDict(TINY_STAGE2["dvae_config"]); mc.NAME = "ACTPromptedDiscreteVAEwithVIT"
+    vae = _Single(fill_module(build_model_from_cfg(mc), "g7.").to(dev).train())
+    cfg1 = EasyDict(dict(opt_cfg, temp=dict(start=1, target=0.0625, ntime=100000), kldweight=dict(start=0, target=0.1, ntime=100000)))
+    opt1, _ = builder.build_opti_sche(vae, cfg1)
+    pts = torch.from_numpy(clouds(4, TINY_B, TINY_N)).to(dev)
+    # finetune
+    ft = _Single(fill_module(build_model_from_cfg(EasyDict(dict(TINY_FINETUNE, num_group=32, group_size=16))), "g10.full.").to(dev).train())
+    cfg3 = EasyDict(dict(opt_cfg, npoints=1024, grad_norm_clip=10))
+    opt3, _ = builder.build_opti_sche(ft, cfg3)
+    raw = torch.from_numpy(clouds(5, 4, 2048)).to(dev); label = torch.tensor([1, 0, 3, 2], device=dev)
+    for _ in range(2):                                   # warm-up (allocations, workspaces, first-use tuning)
+        RA.train_step(vae, opt1, pts, cfg1, 20000)
+        RF.train_step(ft, opt3, raw, label, cfg3, next_points=raw)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        RA.train_step(vae, opt1, pts, cfg1, 20001)
+        RF.train_step(ft, opt3, raw, label, cfg3, next_points=raw)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+
+
 def test_stress_geometry_vs_oracle(dev):
     """BASELINE configs[4] geometry (N=8192, 512 groups x 64 neighbours, 24-layer d=768 student, 104 / 512 / 576-token
     sequences) at B=1 against the CPU oracle: exercises the multi-wave FPS, 128-points-per-lane kNN, chunked (online-softmax)
