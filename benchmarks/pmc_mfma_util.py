@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-kernel MfmaUtil (rocprofv3 derived counter: MFMA-busy cycles / (GPU-active cycles * SIMDs), percent) from one PMC pass:
+
+    ACT_OVERLAP_TEACHER=0 ACT_OVERLAP_DW=0 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d gpurun_out/pmc_mfma -- \\
+        python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-instrument
+    python benchmarks/pmc_mfma_util.py gpurun_out/pmc_mfma > profiles/rNN_pmc_mfma_util.json
+"""
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import importlib.util
+spec = importlib.util.spec_from_file_location("pt", os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.py"))
+src = open(spec.origin).read().split("CAL_KERNEL, CAL_BYTES")[0]          # reuse fold() without running the traffic main
+ns = {}
+exec(compile(src, spec.origin, "exec"), ns)
+fold = ns["fold"]
+dur = {}
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+acc = collections.defaultdict(lambda: [0.0, 0, 0.0, 0.0])
+for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != "MfmaUtil":
+            continue
+        e = acc[fold(r["Kernel_Name"])]
+        d = dur.get(r["Dispatch_Id"], 0)
+        e[0] += float(r["Counter_Value"]); e[1] += 1; e[2] += float(r["Counter_Value"]) * d; e[3] += d
+out = {"source": "rocprofv3 --kernel-trace --pmc MfmaUtil (own pass, auxiliary streams serialised) -- python bench.py --steps 2 --warmup 1 "
+                 "--no-cpu-baseline --no-instrument",
+       "unit": "percent of MFMA-pipe busy cycles; duration-weighted mean (and plain mean) over launches",
+       "kernels": {k: {"mfma_util_percent_time_weighted": (v[2] / v[3] if v[3] else None), "mfma_util_percent_mean": v[0] / v[1],
+                       "launches_profiled": v[1]} for k, v in sorted(acc.items()) if v[0] > 0}}
+print(json.dumps(out, indent=1))
