@@ -193,3 +193,33 @@ def test_pretrained_student_checkpoint_loads_into_point_transformer(tmp_path, de
     assert torch.equal(ft.blocks.blocks[1].mlp.fc1.weight, sd["ACT_encoder.blocks.blocks.1.mlp.fc1.weight"])
     assert torch.equal(ft.encoder.first_conv[0].weight, sd["ACT_encoder.encoder.first_conv.0.weight"])
     assert torch.equal(ft.cls_pos, sd["ACT_encoder.cls_pos"])
+
+
+def test_modelnet_cache_is_built_with_the_hip_fps_kernel(tmp_path, dev):
+    """first use of a ModelNet split without a cache: every shape is reduced to N_POINTS by the HIP farthest-point sampler
+    (start index 0) and the reference's pickle cache is written."""
+    import pickle
+    from act_amd.datasets import build_dataset_from_cfg
+    from act_amd.utils.config import EasyDict
+    from oracle import point_ops as OP
+    root = tmp_path / "mn"
+    (root / "chair").mkdir(parents=True); (root / "night_stand").mkdir()
+    (root / "modelnet40_shape_names.txt").write_text("chair\nnight_stand\n")
+    (root / "modelnet40_train.txt").write_text("chair_0001\nnight_stand_0007\n")
+    (root / "modelnet40_test.txt").write_text("chair_0001\n")
+    rs = np.random.RandomState(3)
+    raw = {}
+    for shape, sid in (("chair", "chair_0001"), ("night_stand", "night_stand_0007")):
+        a = rs.standard_normal((500, 6)).astype(np.float32)
+        raw[sid] = a
+        np.savetxt(root / shape / f"{sid}.txt", a, delimiter=",", fmt="%.6f")
+    base = EasyDict(NAME="ModelNet", DATA_PATH=str(root), N_POINTS=128, NUM_CATEGORY=40, USE_NORMALS=False)
+    ds = build_dataset_from_cfg(base, EasyDict(subset="train"))
+    assert os.path.exists(root / "modelnet40_train_128pts_fps.dat") and len(ds) == 2
+    with open(root / "modelnet40_train_128pts_fps.dat", "rb") as f:
+        pts, labels = pickle.load(f)
+    assert [int(l[0]) for l in labels] == [0, 1] and pts[1].shape == (128, 6)
+    loaded = np.loadtxt(root / "night_stand" / "night_stand_0007.txt", delimiter=",").astype(np.float32)
+    want = OP.fps_ref(np.ascontiguousarray(loaded[None, :, :3]), 128)[0]
+    assert np.array_equal(pts[1], loaded[want])                          # bit-exact selection against the oracle
+    assert ds[1][2][1] == 1 and ds[1][2][0].shape == (128, 3)
