@@ -115,3 +115,43 @@ def test_modelnet_file_loader_from_cache(tmp_path):
     assert np.allclose(np.sort(p.numpy(), axis=0), np.sort(ref, axis=0), atol=1e-6)      # train: same points, shuffled
     dsn = build_dataset_from_cfg(_edict(**dict(base, USE_NORMALS=True)), _edict(subset="train"))
     assert dsn[0][2][0].shape == (64, 6)
+
+
+def test_state_dict_listing_equals_the_reference(tmp_path):
+    """checkpoint wire compatibility: names AND shapes of every parameter / buffer equal the reference's own models
+    (g11_state_dict.npz, generated by importing the reference classes), so {'base_model': sd} checkpoints interchange."""
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from tests.conftest import golden
+    from tests.golden.fill import TINY_STAGE2, TINY_FINETUNE
+    g = golden("g11_state_dict")
+
+    def listing(m):
+        return {k: "x".join(str(d) for d in v.shape) for k, v in m.state_dict().items()}
+
+    def ref(prefix):
+        return dict(zip((str(n) for n in g[prefix + "_names"]), (str(s) for s in g[prefix + "_shapes"])))
+
+    mc = dict(TINY_STAGE2["dvae_config"]); mc["NAME"] = "ACTPromptedDiscreteVAEwithVIT"
+    assert listing(build_model_from_cfg(EasyDict(mc))) == ref("dvae")
+    s2 = build_model_from_cfg(EasyDict(TINY_STAGE2))
+    assert listing(s2) == ref("stage2")
+    for ttype in ("full", "linear", "side"):
+        assert listing(build_model_from_cfg(EasyDict(dict(TINY_FINETUNE, transfer_type=ttype)))) == ref("ft_" + ttype), ttype
+    # and the checkpoint container written by the builder is the reference's (tools/builder.py:138-144)
+    import argparse
+    from act_amd.tools import builder
+    args = argparse.Namespace(local_rank=0, experiment_path=str(tmp_path))
+    opt = torch.optim.AdamW([p for p in s2.parameters() if p.requires_grad], lr=1e-3)
+
+    class M:
+        def state_dict(self):
+            return {"acc": 0.0}
+    builder.save_checkpoint(s2, opt, 3, M(), M(), "ckpt-last", args)
+    ck = torch.load(str(tmp_path / "ckpt-last.pth"), map_location="cpu")
+    assert set(ck) == {"base_model", "optimizer", "epoch", "metrics", "best_metrics"} and ck["epoch"] == 3
+    assert listing_keys(ck["base_model"]) == set(ref("stage2"))
+
+
+def listing_keys(sd):
+    return {k[len("module."):] if k.startswith("module.") else k for k in sd}
