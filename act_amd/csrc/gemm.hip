@@ -399,11 +399,13 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
 
     dim3 grid((unsigned)nt, 1, (unsigned)splits);
     const bool full = vec && (M % BM == 0) && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
+    // 16x16x4 kernels also take an M tail when A is K-major (rows = tokens): rows clamped on load, guarded on store
+    const bool full_mtail = vec && a_kmajor && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
     if (nt16) {
-        if (!full) return ACT_E_BADARG;
+        if (!(full || full_mtail)) return ACT_E_BADARG;
         launch_sgemm_nt16(p, BM == 128 ? (BN == 128 ? 0 : 1) : 2, grid, s);
     } else if (mi16) {
-        if (!full) return ACT_E_BADARG;
+        if (!(full || full_mtail)) return ACT_E_BADARG;
         launch_sgemm16(p, BM == 128 ? (BN == 128 ? 0 : 1) : 2, a_kmajor, b_kmajor, grid, s);
     } else if (BKsel == 32) {
         if (BM == 128 && BN == 128) launch_variant<128, 128, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);

@@ -14,7 +14,9 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, bool A_K, bool B_K>
+// MG (A_K only): M need not be a multiple of BM -- A rows are clamped on load, C rows guarded on store (token counts such as
+// 32 clouds x 65 tokens = 2080 rows keep the fast path instead of the fully guarded 32x32x2 kernels)
+template <int BM, int BN, bool A_K, bool B_K, bool MG = false>
 __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
     constexpr int BK = 16;
     constexpr int LDA_S = BM + 16, LDB_S = BN + 16;
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int v = tid + 256 * i;
-            if (A_K) ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)(m0 + (v >> 2)) * p.lda + k0 + (v & 3) * 4);
+            if (A_K) ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)(MG ? min(m0 + (v >> 2), p.M - 1) : m0 + (v >> 2)) * p.lda + k0 + (v & 3) * 4);
             else     ra[i] = *reinterpret_cast<const float4*>(p.A + (size_t)(k0 + v / (BM / 4)) * p.lda + m0 + (v % (BM / 4)) * 4);
         }
 #pragma unroll
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (BM / 2) + i * 16 + kl * 4 + r;
+                if (MG && row >= p.M) continue;
                 float v = acc[i][j][r];
                 if (p.partial) {
                     p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
 // Bank conflicts of the b128 reads (serviced in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) are removed
 // by XOR-swizzling the 16-byte chunk index with H[(row>>2)&3], H = {0,3,2,1}.  The main loop then contains no VALU address
 // arithmetic at all (row-block strides are ds_read immediates) and 4x fewer LDS instructions than the [k][row] kernels.
-template <int BM, int BN>
+template <int BM, int BN, bool MG = false>
 __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) {
     constexpr int BK = 16;
     constexpr int TM = BM / 32, TN = BN / 32;
@@ -167,10 +170,11 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
     // global -> register staging: thread v owns the float4 (row = v>>2 (+64 per extra load), chunk = v&3) of each operand tile;
     // rows 64 apart share the swizzle, so the extra loads are plain immediates on one pointer / one LDS offset per operand
     const int srow = tid >> 2, sch = tid & 3;
-    const float* ga = p.A + (size_t)(m0 + srow) * p.lda + kbeg + sch * 4;
+    const float* ga = p.A + (size_t)(MG ? min(m0 + srow, p.M - 1) : m0 + srow) * p.lda + kbeg + sch * 4;
     const float* gb = p.B + (size_t)(n0 + srow) * p.ldb + kbeg + sch * 4;
     const int s_off = srow * 16 + 4 * (sch ^ ((4 - ((srow >> 2) & 3)) & 3));
-    const size_t stride_a = (size_t)64 * p.lda, stride_b = (size_t)64 * p.ldb;
+    const size_t stride_a = MG ? (size_t)(min(m0 + srow + 64, p.M - 1) - min(m0 + srow, p.M - 1)) * p.lda : (size_t)64 * p.lda;
+    const size_t stride_b = (size_t)64 * p.ldb;
     // staging registers as named scalars (NA, NB <= 2): arrays indexed inside the helper lambdas are not promoted to
     // registers by hipcc here and would round-trip through scratch memory in the main loop
     float4 ra0, ra1, rb0, rb1;
@@ -236,6 +240,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm * (BM / 2) + i * 16 + kl * 4 + r;
+                if (MG && row >= p.M) continue;
                 float v = acc[i][j][r];
                 if (p.partial) {
                     p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
@@ -251,6 +256,11 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
 
 template <int BM, int BN>
 static void launch16(const GemmParams& p, int ak, int bk, dim3 grid, hipStream_t s) {
+    if (p.M % BM != 0) {                                 // M tail: A must be K-major (rows = tokens)
+        if (bk) hipLaunchKernelGGL((sgemm16_kernel<BM, BN, true, true, true>), grid, dim3(256), 0, s, p);
+        else    hipLaunchKernelGGL((sgemm16_kernel<BM, BN, true, false, true>), grid, dim3(256), 0, s, p);
+        return;
+    }
     if (ak && bk)        hipLaunchKernelGGL((sgemm16_kernel<BM, BN, true, true>), grid, dim3(256), 0, s, p);
     else if (ak && !bk)  hipLaunchKernelGGL((sgemm16_kernel<BM, BN, true, false>), grid, dim3(256), 0, s, p);
     else if (!ak && !bk) hipLaunchKernelGGL((sgemm16_kernel<BM, BN, false, false>), grid, dim3(256), 0, s, p);
@@ -258,6 +268,13 @@ static void launch16(const GemmParams& p, int ak, int bk, dim3 grid, hipStream_t
 }
 
 void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s) {
+    const int bm = tile == 2 ? 64 : 128;
+    if (p.M % bm != 0) {
+        if (tile == 0)      hipLaunchKernelGGL((sgemm_nt16_kernel<128, 128, true>), grid, dim3(256), 0, s, p);
+        else if (tile == 1) hipLaunchKernelGGL((sgemm_nt16_kernel<128, 64, true>), grid, dim3(256), 0, s, p);
+        else                hipLaunchKernelGGL((sgemm_nt16_kernel<64, 64, true>), grid, dim3(256), 0, s, p);
+        return;
+    }
     if (tile == 0)      hipLaunchKernelGGL((sgemm_nt16_kernel<128, 128>), grid, dim3(256), 0, s, p);
     else if (tile == 1) hipLaunchKernelGGL((sgemm_nt16_kernel<128, 64>), grid, dim3(256), 0, s, p);
     else                hipLaunchKernelGGL((sgemm_nt16_kernel<64, 64>), grid, dim3(256), 0, s, p);

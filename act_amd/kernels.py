@@ -187,6 +187,7 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
         cands += [(tile, s) for s in sp_list]
         if M % bm == 0 and N % bn == 0 and K % 32 == 0:
             cands += [(tile + 3, s) for s in sp_list if s <= 4 and (K // s) % 32 == 0]       # software-pipelined main loop
+        if (M % bm == 0 or ak) and N % bn == 0 and K % 32 == 0:                              # the 16x16x4 kernels take an M tail (K-major A)
             cands += [(tile + 6, s) for s in sp_list if (K // s) % 32 == 0]                  # v_mfma_f32_16x16x4_f32 main loop
             if ak and bk:
                 cands += [(tile + 9, s) for s in sp_list if (K // s) % 32 == 0]              # NT: K-contiguous LDS image, b128 fragments

@@ -498,6 +498,27 @@ def test_prefix_block_training_matches_full_block_autograd(K):
     assert _rel(mg.grad.reshape(B, P, D), prm.grad) <= TOL
 
 
+@pytest.mark.parametrize("tile", [7, 8, 9, 10, 11, 12])
+def test_gemm_m_tail_on_the_16x16x4_kernels(K, tile):
+    """token counts that are not a multiple of the tile height (32 clouds x 65 tokens = 2080 rows) stay on the fast kernels:
+    A rows clamped on load, C rows guarded on store, with and without split-K and a fused epilogue."""
+    for M in (2080, 200, 65):
+        N, Kd = 384, 768
+        a = _rnd(f"mt.a{M}", M, Kd); b = _rnd("mt.b", N, Kd); bias = _rnd("mt.bias", N); res = _rnd(f"mt.r{M}", M, N)
+        ref = a.double() @ b.double().t()
+        for sp in (1, 3):
+            c = K.gemm(a.cuda(), b.cuda(), True, True, cfg=(tile, sp))
+            assert c.shape == (M, N) and _rel(c, ref) <= 2e-5, (tile, M, sp)
+            if tile <= 9:                                   # NN layout exists on the 16x16x4 [k][row] kernels only
+                bt = b.t().contiguous().cuda()
+                assert _rel(K.gemm(a.cuda(), bt, True, False, cfg=(tile, sp)), ref) <= 2e-5, (tile, M, sp, "nn")
+        c2 = K.gemm(a.cuda(), b.cuda(), True, True, bias=bias.cuda(), res=res.cuda(), cfg=(tile, 1))
+        assert _rel(c2, ref + bias.double() + res.double()) <= 2e-5
+        guard = torch.full((M + 4, N), 7.0, device="cuda")  # rows beyond M must not be written
+        K.gemm(a.cuda(), b.cuda(), True, True, out=guard[:M], cfg=(tile, 1))
+        assert (guard[M:] == 7.0).all()
+
+
 def test_gemm_row_strided_operands(K):
     """column slices of a weight are passed with their leading dimension when that keeps the float4 path (stride % 4 == 0,
     16-byte aligned) and copied otherwise -- FoldingNet's [512, 384+3+2] conv weight is the odd-stride case."""
