@@ -242,17 +242,48 @@ def _collect(test_pred, test_label, args):
     return accuracy_scores(test_label, test_pred)
 
 
+def fps_ahead(points_raw, npoints):
+    """misc.fps(points_raw, npoints) enqueued on the auxiliary stream -> (points, event): the 8192 -> 1024 sampling of the NEXT
+    batch (a serial chain on one workgroup per cloud) overlaps the forward of the current one."""
+    dev = points_raw.device
+    main, side = torch.cuda.current_stream(dev), K.side_stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        pts = misc.fps(points_raw, npoints)
+        ev = torch.cuda.Event()
+        ev.record(side)
+    return pts, ev
+
+
+def sampled_batches(test_dataloader, npoints, dev):
+    """yields (fps-sampled points [B,npoints,3], labels) with one batch of look-ahead on the auxiliary stream"""
+    it = iter(test_dataloader)
+    nxt = next(it, None)
+    pending = None
+    if nxt is not None:
+        pending = (fps_ahead(nxt[2][0].to(dev, non_blocking=True), npoints), nxt[2][1].to(dev, non_blocking=True))
+    while pending is not None:
+        (pts, ev), label = pending
+        nxt = next(it, None)
+        pending = None
+        if nxt is not None:
+            pending = (fps_ahead(nxt[2][0].to(dev, non_blocking=True), npoints), nxt[2][1].to(dev, non_blocking=True))
+        main = torch.cuda.current_stream(dev)
+        main.wait_event(ev)
+        pts.record_stream(main)
+        yield pts, label
+
+
 def validate(base_model, test_dataloader, epoch, val_writer, args, config, logger=None):
     base_model.eval()
     test_pred, test_label = [], []
     npoints = config.npoints
     dev = next(base_model.parameters()).device
     with torch.no_grad():
-        for idx, (taxonomy_ids, model_ids, data) in enumerate(test_dataloader):
-            points = misc.fps(data[0].to(dev), npoints)
+        for points, label in sampled_batches(test_dataloader, npoints, dev):
             logits = base_model(points)
             test_pred.append(logits.argmax(-1).view(-1))
-            test_label.append(data[1].to(dev).view(-1))
+            test_label.append(label.view(-1))
         acc, acc_avg = _collect(test_pred, test_label, args)
         print_log('[Validation] EPOCH: %d  OA=%.4f  mAcc=%.4f' % (epoch, acc, acc_avg), logger=logger)
     if val_writer is not None:

@@ -140,9 +140,15 @@ def main():
             cur = _NEXT if _NEXT is not None else pool[i % len(pool)].clone()
             _NEXT = pool[(i + 1) % len(pool)].clone()
             return train_step_ft(wrapped, optimizer, cur, labels, config, next_points=_NEXT)[0]
-        if args.stage == 4:
+        if args.stage == 4:                                # as runner_finetune.validate: next batch's FPS on the auxiliary stream
+            from act_amd.tools.runner_finetune import fps_ahead
             with torch.no_grad():
-                return model(misc.fps(pool[i % len(pool)], N)).sum()
+                cur = _NEXT if _NEXT is not None else fps_ahead(pool[i % len(pool)], N)
+                _NEXT = fps_ahead(pool[(i + 1) % len(pool)], N)
+                main = torch.cuda.current_stream(device)
+                main.wait_event(cur[1])
+                cur[0].record_stream(main)
+                return model(cur[0]).sum()
         if args.stage == 1:
             l1, l2, _ = train_step_ae(wrapped, optimizer, pool[i % len(pool)], config, 20000 + i)
             return l1 + l2
