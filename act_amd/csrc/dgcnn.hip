@@ -177,28 +177,38 @@ __device__ __forceinline__ void edge_select(const float* __restrict__ yz, int ld
     }
 }
 // pass 1: per (sample, channel) partial sums over g:  part[0][b][c] = sum_g dact*xhat*, part[1][b][c] = sum_g dact
+// workgroup = 64 channels x 4 g-lanes (the g loop is a chain of dependent gathers: four lanes per channel + unrolling keep
+// enough loads in flight); lanes are folded through LDS in a fixed order
 __global__ __launch_bounds__(256) void edge_gn_bwd_partials_kernel(const float* __restrict__ yz, int ldy, int zoff,
                                                                    const int64_t* __restrict__ idx, int B, int G, int k, int C, int groups,
                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float slope, const float* __restrict__ dout, int ldd,
                                                                    float* __restrict__ part) {
-    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (c >= C) return;
-    const int gi = c / (C / groups);
-    const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi], gm = gamma[c], bt = beta[c], a = rs * gm;
+    __shared__ float red[2][3][64];
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
     float sg = 0.f, sb = 0.f;
-    for (int g = 0; g < G; ++g) {
-        float v; int js;
-        edge_select(yz, ldy, idx, b, g, G, k, c, a, v, js);
-        if (zoff >= 0) v += yz[((size_t)b * G + g) * ldy + zoff + c];
-        const float xh = (v - mu) * rs;
-        const float y = xh * gm + bt;
-        const float da = dout[((size_t)b * G + g) * ldd + c] * (y > 0.f ? 1.f : slope);
-        sg += da * xh; sb += da;
+    if (c < C) {
+        const int gi = c / (C / groups);
+        const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi], gm = gamma[c], bt = beta[c], a = rs * gm;
+#pragma unroll 2
+        for (int g = gl; g < G; g += 4) {
+            float v; int js;
+            edge_select(yz, ldy, idx, b, g, G, k, c, a, v, js);
+            if (zoff >= 0) v += yz[((size_t)b * G + g) * ldy + zoff + c];
+            const float xh = (v - mu) * rs;
+            const float y = xh * gm + bt;
+            const float da = dout[((size_t)b * G + g) * ldd + c] * (y > 0.f ? 1.f : slope);
+            sg += da * xh; sb += da;
+        }
     }
-    part[((size_t)0 * B + b) * C + c] = sg;
-    part[((size_t)1 * B + b) * C + c] = sb;
+    if (gl > 0) { red[0][gl - 1][cl] = sg; red[1][gl - 1][cl] = sb; }
+    __syncthreads();
+    if (gl == 0 && c < C) {
+        part[((size_t)0 * B + b) * C + c] = (sg + red[0][0][cl]) + (red[0][1][cl] + red[0][2][cl]);
+        part[((size_t)1 * B + b) * C + c] = (sb + red[1][0][cl]) + (red[1][1][cl] + red[1][2][cl]);
+    }
 }
 // pass 2: one workgroup per (sample, group): m1 = sum_c gamma*db_part / N, m2 = sum_c gamma*dg_part / N
 __global__ __launch_bounds__(256) void edge_gn_bwd_means_kernel(const float* __restrict__ part, const float* __restrict__ gamma, int B,
@@ -218,22 +228,26 @@ __global__ __launch_bounds__(256) void edge_gn_bwd_means_kernel(const float* __r
         mstat[(size_t)B * groups + blockIdx.x] = ((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3])) * inv_n;
     }
 }
-// pass 3 (graph layers): workgroup = (sample, chunk of CC channels), thread = channel; dY rows accumulate in LDS [G][CC]
-__global__ void edge_gn_bwd_apply_kernel(const float* __restrict__ yz, int ldy, int zoff, const int64_t* __restrict__ idx, int B, int G,
+// pass 3 (graph layers): workgroup = (sample, 64 channels) x GL g-lanes; every (g-lane, channel) thread owns one column of its
+// lane's LDS accumulator [G][64] for the dY scatter (no cross-thread races, fixed order), the GL lane images are summed at the end
+template <int GL>
+__global__ __launch_bounds__(64 * GL) void edge_gn_bwd_apply_kernel(const float* __restrict__ yz, int ldy, int zoff,
+                                                                     const int64_t* __restrict__ idx, int B, int G,
                                          int k, int C, int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
                                          const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
                                          const float* __restrict__ dout, int ldd, const float* __restrict__ mstat,
                                          float* __restrict__ dyz) {
-    extern __shared__ float acc[];                          // [G][CC]
-    const int CC = blockDim.x, t = threadIdx.x;
-    const int c = blockIdx.x * CC + t, b = blockIdx.y;
-    const bool live = c < C;
-    for (int r = 0; r < G; ++r) acc[r * CC + t] = 0.f;
-    if (live) {
+    extern __shared__ float acc[];                          // [GL][G][64]
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    float* mine = acc + (size_t)gl * G * 64;
+    for (int r = 0; r < G; ++r) mine[r * 64 + cl] = 0.f;
+    if (c < C) {
         const int gi = c / (C / groups);
         const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi], gm = gamma[c], bt = beta[c], a = rs * gm;
         const float m1 = mstat[b * groups + gi], m2 = mstat[(size_t)B * groups + b * groups + gi];
-        for (int g = 0; g < G; ++g) {
+#pragma unroll 2
+        for (int g = gl; g < G; g += GL) {
             float vs; int js;
             edge_select(yz, ldy, idx, b, g, G, k, c, a, vs, js);
             const float z = zoff >= 0 ? yz[((size_t)b * G + g) * ldy + zoff + c] : 0.f;
@@ -245,12 +259,19 @@ __global__ void edge_gn_bwd_apply_kernel(const float* __restrict__ yz, int ldy, 
                 const float xh = (yz[((size_t)b * G + src) * ldy + c] + z - mu) * rs;
                 const float dp = rs * ((j == js ? da : 0.f) - m1 - xh * m2);
                 dz += dp;
-                acc[src * CC + t] += dp;                    // own column only: no cross-thread races, fixed order
+                mine[src * 64 + cl] += dp;
             }
             if (zoff >= 0) dyz[((size_t)b * G + g) * ldy + zoff + c] = dz;
         }
-        for (int r = 0; r < G; ++r) dyz[((size_t)b * G + r) * ldy + c] = acc[r * CC + t];
     }
+    __syncthreads();
+    if (c < C)
+        for (int r = gl; r < G; r += GL) {
+            float v = acc[r * 64 + cl];
+#pragma unroll
+            for (int l = 1; l < GL; ++l) v += acc[((size_t)l * G + r) * 64 + cl];
+            dyz[((size_t)b * G + r) * ldy + c] = v;
+        }
 }
 // pass 3 (head, k = 1, no gather, no Z): plain elementwise
 __global__ __launch_bounds__(256) void gn_lrelu_bwd_apply_kernel(const float* __restrict__ h, int G, int C, int groups,
@@ -277,7 +298,7 @@ extern "C" int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff,
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * (k + (zoff >= 0 ? 1 : 0)) + 2.0 + (zoff >= 0 ? 2 : 1)));
     const float* mean = stats; const float* rstd = stats + (size_t)B * groups;
-    hipLaunchKernelGGL(edge_gn_bwd_partials_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, yz, ldy, zoff, idx, B, G, k, C, groups, mean,
+    hipLaunchKernelGGL(edge_gn_bwd_partials_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, yz, ldy, zoff, idx, B, G, k, C, groups, mean,
                        rstd, gamma, beta, slope, dout, ldd, part);
     const float inv_n = 1.0f / ((float)(C / groups) * (float)G * (float)k);
     hipLaunchKernelGGL(edge_gn_bwd_means_kernel, dim3(B * groups), dim3(256), 0, s, part, gamma, B, C, groups, inv_n, mstat);
@@ -286,17 +307,15 @@ extern "C" int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff,
         hipLaunchKernelGGL(gn_lrelu_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, yz, G, C, groups, mean, rstd, gamma, beta,
                            slope, dout, ldd, mstat, B, dyz, total);
     } else {
-        int CC = G <= 128 ? 128 : (G <= 256 ? 64 : 32);
         if (G > 512) return ACT_E_BADARG;
-        while (CC > 32 && CC / 2 >= C) CC /= 2;
-        const size_t smem = (size_t)G * CC * sizeof(float);
-        auto kfn = edge_gn_bwd_apply_kernel;
-        if (smem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(kfn, dim3((C + CC - 1) / CC, B), dim3(CC), smem, s, yz, ldy, zoff, idx, B, G, k, C, groups, mean, rstd, gamma,
-                           beta, slope, dout, ldd, mstat, dyz);
+        const int GL = G <= 128 ? 4 : (G <= 256 ? 2 : 1);                       // lane images of [G][64] floats each: <= 128 KB of LDS
+        const size_t smem = (size_t)GL * G * 64 * sizeof(float);
+#define APPLY(N) { auto kfn = edge_gn_bwd_apply_kernel<N>; \
+            if (smem > 48 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; } \
+            hipLaunchKernelGGL(kfn, dim3((C + 63) / 64, B), dim3(64 * N), smem, s, yz, ldy, zoff, idx, B, G, k, C, groups, mean, rstd, gamma, \
+                               beta, slope, dout, ldd, mstat, dyz); }
+        if (GL == 4) APPLY(4) else if (GL == 2) APPLY(2) else APPLY(1)
+#undef APPLY
     }
     ACT_LAUNCH_CHECK(); return 0;
 }
