@@ -46,14 +46,32 @@ __global__ __launch_bounds__(256) void colstats_stage1(const float* __restrict__
 }
 
 // BatchNorm finalize: mean, biased var -> scale = gamma*rstd, shift = beta - mean*scale; running stats (momentum, unbiased var)
-__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nparts, int C, int R, const float* __restrict__ gamma,
+// fold the stage-1 partial rows [nparts][2][C]: workgroup = 64 columns x 4 part-lanes, 8 loads in flight per thread, lanes folded
+// through LDS in a fixed order (a single thread per column walking ~1000 partial rows is a 150 us chain of dependent loads)
+__device__ __forceinline__ void fold_partials(const float* __restrict__ partial, int nparts, int C, int c, int lane, float (*red)[3][64],
+                                              float& s, float& q) {
+    s = 0.f; q = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int p = lane; p < nparts; p += 4) { s += partial[((size_t)p * 2) * C + c]; q += partial[((size_t)p * 2 + 1) * C + c]; }
+    }
+    const int cl = threadIdx.x & 63;
+    if (lane > 0) { red[0][lane - 1][cl] = s; red[1][lane - 1][cl] = q; }
+    __syncthreads();
+    if (lane == 0) {
+        s = (s + red[0][0][cl]) + (red[0][1][cl] + red[0][2][cl]);
+        q = (q + red[1][0][cl]) + (red[1][1][cl] + red[1][2][cl]);
+    }
+}
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nparts, int C, int R, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int p = 0; p < nparts; ++p) { s += partial[((size_t)p * 2) * C + c]; q += partial[((size_t)p * 2 + 1) * C + c]; }
+    __shared__ float red[2][3][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s, q;
+    fold_partials(partial, nparts, C, c, lane, red, s, q);
+    if (lane != 0 || c >= C) return;
     const float dm = s / (float)R;                      // mean of (x - pivot)
     const float mean = x[c] + dm;
     float var = q / (float)R - dm * dm;
@@ -68,12 +86,12 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
     }
 }
 // sums of stage 1 -> out0[c], out1[c]
-__global__ void colstats_stage2(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out0, float* __restrict__ out1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f, q = 0.f;
-    for (int p = 0; p < nparts; ++p) { s += partial[((size_t)p * 2) * C + c]; q += partial[((size_t)p * 2 + 1) * C + c]; }
-    out0[c] = s; out1[c] = q;
+__global__ __launch_bounds__(256) void colstats_stage2(const float* __restrict__ partial, int nparts, int C, float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float red[2][3][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s, q;
+    fold_partials(partial, nparts, C, c, lane, red, s, q);
+    if (lane == 0 && c < C) { out0[c] = s; out1[c] = q; }
 }
 
 // y = relu?(x*scale[c] + shift[c])   (float4)
@@ -169,7 +187,7 @@ extern "C" int act_bn_stats_f32(const float* x, int R, int C, const float* gamma
     ActProfScope ps(KID_BN_STATS, s, 0.0, 4.0 * R * (double)C);
     hipLaunchKernelGGL(colstats_stage1<0>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
                        R, C, rpb, workspace);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, x, workspace, nparts, C, R, gamma, beta, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, workspace, nparts, C, R, gamma, beta, eps, momentum,
                        running_mean, running_var, mean, rstd, scale, shift);
     ACT_LAUNCH_CHECK(); return 0;
 }
@@ -198,7 +216,7 @@ extern "C" int act_bn_bwd_f32(const float* x, const float* dy, const float* scal
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_BN_BWD, s, 0.0, 20.0 * R * (double)C);
     hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace);
-    hipLaunchKernelGGL(colstats_stage2, dim3((C + 63) / 64), dim3(64), 0, s, workspace, nparts, C, dbeta, dgamma);
+    hipLaunchKernelGGL(colstats_stage2, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nparts, C, dbeta, dgamma);
     const long long total = (long long)R * C;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, dbeta, dgamma, relu,
                        1.0f / (float)R, total, C, dx);
