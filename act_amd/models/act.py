@@ -181,8 +181,8 @@ class VisableOnlyMaskTransformer(nn.Module):
         self.encoder = Encoder(encoder_channel=self.encoder_dims)
         self.reduce_dim = nn.Linear(self.encoder_dims, self.embed_dim) if self.encoder_dims != self.embed_dim else nn.Identity()
         self.mask_type = tc.mask_type
-        if self.mask_type != 'rand':
-            raise NotImplementedError("only mask_type 'rand' (cfgs/pretrain/pretrain_act_distill.yaml) is on this path")
+        if self.mask_type not in ('rand', 'block'):
+            raise NotImplementedError(f"mask_type {self.mask_type!r}: the reference has 'rand' and 'block' (models/act.py:215-267)")
         self.cls_token = nn.Parameter(torch.randn(1, 1, self.embed_dim))
         self.cls_pos = nn.Parameter(torch.randn(1, 1, self.embed_dim))
         self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
@@ -213,8 +213,25 @@ class VisableOnlyMaskTransformer(nn.Module):
         mk = lambda: random_mask(B, G, self.num_mask, center.device)
         return (draws.get("mask", mk) if draws is not None else mk()).to(center.device)
 
+    def _mask_center_block(self, center, noaug=False, draws=None):
+        """mask the int(mask_ratio * G) centres nearest to one random seed centre per cloud (models/act.py:215-242), on the device:
+        no Python loop over the batch, no host round trip.  ``draws['mask_seed']`` [B] injects the seed indices."""
+        B, G, _ = center.shape
+        if noaug or self.mask_ratio == 0:
+            return torch.zeros(B, G, dtype=torch.bool, device=center.device)
+        self.num_mask = int(self.mask_ratio * G)
+        mk = lambda: torch.randint(0, G, (B,), device=center.device)
+        seed = (draws.get("mask_seed", mk) if draws is not None else mk()).to(center.device).long()
+        ref = center[torch.arange(B, device=center.device), seed]                           # [B,3]
+        dist = torch.linalg.vector_norm(ref.unsqueeze(1) - center, dim=-1)                  # [B,G]
+        order = torch.argsort(dist, dim=-1, descending=False, stable=True)
+        mask = torch.zeros(B, G, dtype=torch.bool, device=center.device)
+        mask.scatter_(1, order[:, :self.num_mask], True)
+        return mask
+
     def forward(self, neighborhood, center, register_shallow_hook=-1, only_cls_tokens=False, noaug=False, draws=None):
-        bool_masked_pos = self._mask_center_rand(center, noaug=noaug, draws=draws)          # B G
+        masker = self._mask_center_rand if self.mask_type == 'rand' else self._mask_center_block
+        bool_masked_pos = masker(center, noaug=noaug, draws=draws)                          # B G
         B, G, _ = center.shape
         num_mask = 0 if (noaug or self.mask_ratio == 0) else self.num_mask
         tokens = self.encoder(neighborhood)                                                 # B G C

@@ -90,10 +90,21 @@ def rand_mask(B, G, num_mask, generator=None):
     return mask
 
 
+def block_mask(center, num_mask, seed_index):
+    """the num_mask centres nearest to centre[seed_index[b]] per cloud (models/act.py:215-242, random.randint injected)."""
+    B, G, _ = center.shape
+    mask = torch.zeros(B, G, dtype=torch.bool)
+    for b in range(B):
+        d = torch.norm(center[b, int(seed_index[b])].reshape(1, 3) - center[b], p=2, dim=-1)
+        mask[b, torch.argsort(d, descending=False)[:num_mask]] = True
+    return mask
+
+
 class VisableOnlyMaskTransformer(nn.Module):
     def __init__(self, config):
         super().__init__()
         tc = config.transformer_config
+        self.mask_type = tc.get("mask_type", "rand") if hasattr(tc, "get") else "rand"
         self.mask_ratio, self.embed_dim, self.cls_dim = tc.mask_ratio, tc.embed_dim, tc.cls_dim
         self.depth, self.num_heads = tc.depth, tc.num_heads
         self.encoder_dims = config.dvae_config.encoder_dims
@@ -126,7 +137,11 @@ class VisableOnlyMaskTransformer(nn.Module):
         if noaug or self.mask_ratio == 0:
             mask = torch.zeros(B, G, dtype=torch.bool)
         else:
-            mask = draws.get("mask", lambda: rand_mask(B, G, int(self.mask_ratio * G)))
+            if self.mask_type == "block":
+                seed = draws.get("mask_seed", lambda: torch.randint(0, G, (B,)))
+                mask = block_mask(center, int(self.mask_ratio * G), seed)
+            else:
+                mask = draws.get("mask", lambda: rand_mask(B, G, int(self.mask_ratio * G)))
         tok = self.reduce_dim(self.encoder(neighborhood))
         C = tok.shape[-1]
         x_vis = tok[~mask].reshape(B, -1, C)

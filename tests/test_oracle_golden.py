@@ -220,3 +220,10 @@ def test_g10_point_transformer_finetune(ttype):
     model.eval()
     with torch.no_grad():
         np.testing.assert_allclose(model(pts).numpy(), g[f"{ttype}_logits_eval"], atol=2e-5, rtol=1e-4)
+
+
+def test_g12_block_mask_matches_reference():
+    g = golden("g12_block_mask")
+    center = torch.from_numpy(golden("g1_group")["center"])
+    m = M.block_mask(center, int(0.8 * 64), g["seed_index"])
+    assert np.array_equal(m.numpy(), g["mask"]) and (m.sum(1) == 51).all()
