@@ -436,6 +436,53 @@ extern "C" int act_softmax_xent_bwd_f32(const float* logits, const int64_t* labe
     ACT_LAUNCH_CHECK(); return 0;
 }
 
+// Alternative distillation losses of the reference (models/act.py:1186-1191,1255): 'l2' = nn.MSELoss(mean), 'smoothl1' =
+// nn.SmoothL1Loss(mean, beta = 1).  Per-row partial sums (one wave per row, fixed order) -> mean_kernel; deterministic.
+__global__ __launch_bounds__(256) void regression_loss_fwd_kernel(const float* __restrict__ s, const float* __restrict__ t, int R, int D,
+                                                                  int kind, float* __restrict__ row_loss) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    float acc = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float d = s[(size_t)row * D + c] - t[(size_t)row * D + c];
+        const float ad = fabsf(d);
+        acc += kind == 0 ? d * d : (ad < 1.f ? 0.5f * d * d : ad - 0.5f);
+    }
+    acc = wave_sum_f32(acc);
+    if (lane == 0) row_loss[row] = acc / (float)D;
+}
+__global__ __launch_bounds__(256) void regression_loss_bwd_kernel(const float* __restrict__ s, const float* __restrict__ t,
+                                                                  const float* __restrict__ gout, long long n, int kind, float inv_n,
+                                                                  float* __restrict__ ds) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float d = s[i] - t[i];
+        ds[i] = gout[0] * inv_n * (kind == 0 ? 2.f * d : fminf(fmaxf(d, -1.f), 1.f));
+    }
+}
+extern "C" int act_regression_loss_fwd_f32(const float* student, const float* teacher, int R, int D, int kind, float* loss_out,
+                                           float* row_loss, act_stream_t stream) {
+    if (!student || !teacher || !loss_out || !row_loss) return ACT_E_NULLPTR;
+    if (R <= 0 || D <= 0 || (kind != 0 && kind != 1)) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_COSINE_FWD, s, 0.0, 8.0 * R * (double)D);
+    hipLaunchKernelGGL(regression_loss_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, s, student, teacher, R, D, kind, row_loss);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, s, row_loss, R, loss_out);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_regression_loss_bwd_f32(const float* student, const float* teacher, const float* grad_loss, int R, int D, int kind,
+                                           float* grad_student, act_stream_t stream) {
+    if (!student || !teacher || !grad_loss || !grad_student) return ACT_E_NULLPTR;
+    if (R <= 0 || D <= 0 || (kind != 0 && kind != 1)) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_COSINE_BWD, s, 0.0, 12.0 * R * (double)D);
+    const long long n = (long long)R * D;
+    long long g = (n + 255) / 256; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(regression_loss_bwd_kernel, dim3((unsigned)g), dim3(256), 0, s, student, teacher, grad_loss, n, kind,
+                       1.0f / (float)n, grad_student);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
 extern "C" int act_cosine_loss_fwd_f32(const float* student, const float* teacher, int R, int D, float eps, float* loss_out,
                                        float* row_loss, float* stats, act_stream_t stream) {
     if (!student || !teacher || !loss_out || !row_loss || !stats) return ACT_E_NULLPTR;

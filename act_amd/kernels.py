@@ -32,6 +32,8 @@ _C._declare({
     "act_attention_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "act_cosine_loss_fwd_f32": [_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
     "act_cosine_loss_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp],
+    "act_regression_loss_fwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "act_regression_loss_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "act_softmax_xent_fwd_f32": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "act_softmax_xent_bwd_f32": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
 })
@@ -39,7 +41,8 @@ _C.lib.act_layernorm_bwd_workspace.restype = _sz
 _C.lib.act_colsum_workspace.restype = _sz
 for _n in ("act_sgemm_f32", "act_sgemm_ex_f32", "act_layernorm_fwd_f32", "act_layernorm_bwd_workspace", "act_layernorm_bwd_f32",
            "act_colsum_workspace", "act_colsum_f32", "act_attention_fwd_f32", "act_attention_bwd_f32",
-           "act_cosine_loss_fwd_f32", "act_cosine_loss_bwd_f32", "act_softmax_xent_fwd_f32", "act_softmax_xent_bwd_f32"):
+           "act_cosine_loss_fwd_f32", "act_cosine_loss_bwd_f32", "act_softmax_xent_fwd_f32", "act_softmax_xent_bwd_f32",
+           "act_regression_loss_fwd_f32", "act_regression_loss_bwd_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
 
 lib, ptr, stream, check = _C.lib, _C.ptr, _C.stream, _C.check
@@ -474,6 +477,35 @@ class CosineLossFn(torch.autograd.Function):
 
 def cosine_distill_loss(student, teacher):
     return CosineLossFn.apply(student, teacher).reshape(())
+
+
+class RegressionLossFn(torch.autograd.Function):
+    """loss: 'l2' (nn.MSELoss) / 'smoothl1' (nn.SmoothL1Loss), mean over all elements (models/act.py:1186-1191,1255)."""
+
+    @staticmethod
+    def forward(ctx, student, teacher, kind):
+        D = student.shape[-1]
+        s2 = _f32c(student).reshape(-1, D); t2 = _f32c(teacher).reshape(-1, D)
+        R = s2.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=s2.device)
+        row = torch.empty(R, dtype=torch.float32, device=s2.device)
+        check(lib.act_regression_loss_fwd_f32(ptr(s2), ptr(t2), R, D, int(kind), ptr(loss), ptr(row), stream()), "act_regression_loss_fwd_f32")
+        ctx.save_for_backward(s2, t2)
+        ctx.kind, ctx.shp = int(kind), student.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        s2, t2 = ctx.saved_tensors
+        R, D = s2.shape
+        ds = torch.empty_like(s2)
+        check(lib.act_regression_loss_bwd_f32(ptr(s2), ptr(t2), ptr(_f32c(g).reshape(-1)), R, D, ctx.kind, ptr(ds), stream()),
+              "act_regression_loss_bwd_f32")
+        return ds.reshape(ctx.shp), None, None
+
+
+def regression_distill_loss(student, teacher, kind):
+    return RegressionLossFn.apply(student, teacher, {"l2": 0, "smoothl1": 1}[kind]).reshape(())
 
 
 class SoftmaxXentFn(torch.autograd.Function):

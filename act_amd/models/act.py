@@ -429,8 +429,9 @@ class ACT_PointDistillation(nn.Module):
         self._prefetched = None
         self._teacher_graph = None
         self.loss_type = config.loss
-        if self.loss_type != 'cosine':
-            raise NotImplementedError("only loss: cosine (the ACT recipe) is on this path")
+        if self.loss_type not in ('cosine', 'l2', 'smoothl1'):
+            raise NotImplementedError(f"loss: {self.loss_type!r} -- 'cosine' (the ACT recipe), 'l2' and 'smoothl1' are on this path; "
+                                      "'ntxent' / 'barlow' need the lightly package the reference imports")
 
     def build_tokenizer(self, cfg):
         self.dvae_tokenizer = ACTPromptedDiscreteVAEwithVIT(cfg)
@@ -550,4 +551,6 @@ class ACT_PointDistillation(nn.Module):
             teacher_feat.record_stream(main)
         teacher_feat = take_rows(teacher_feat, msk_idx)
         assert teacher_feat.shape == student_feat.shape
-        return K.cosine_distill_loss(student_feat, teacher_feat)
+        if self.loss_type == 'cosine':
+            return K.cosine_distill_loss(student_feat, teacher_feat)
+        return K.regression_distill_loss(student_feat, teacher_feat, self.loss_type)

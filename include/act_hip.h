@@ -152,6 +152,13 @@ int act_cosine_loss_fwd_f32(const float* student, const float* teacher, int R, i
 int act_cosine_loss_bwd_f32(const float* student, const float* teacher, const float* stats, const float* grad_loss,
                             int R, int D, float eps, float* grad_student, act_stream_t stream);
 
+/* Alternative distillation losses (models/act.py:1186-1191,1255): kind 0 = 'l2' (nn.MSELoss, mean), kind 1 = 'smoothl1'
+ * (nn.SmoothL1Loss, mean, beta 1) over [R,D]; row_loss [R] scratch. */
+int act_regression_loss_fwd_f32(const float* student, const float* teacher, int R, int D, int kind, float* loss_out,
+                                float* row_loss, act_stream_t stream);
+int act_regression_loss_bwd_f32(const float* student, const float* teacher, const float* grad_loss, int R, int D, int kind,
+                                float* grad_student, act_stream_t stream);
+
 /* Classification loss of the finetune path (models/act.py:823-830: nn.CrossEntropyLoss(), mean over rows):
  * logits [R,C], labels int64 [R] -> loss_out[0] = mean_r (logsumexp(logits_r) - logits_r[label_r]); row_buf [3,R] =
  * {logsumexp (kept for backward), row loss, arg-max==label flag}; acc_out (nullable) [1] = fraction of rows whose arg-max

@@ -519,6 +519,21 @@ def test_gemm_m_tail_on_the_16x16x4_kernels(K, tile):
         assert (guard[M:] == 7.0).all()
 
 
+@pytest.mark.parametrize("kind", ["l2", "smoothl1"])
+def test_regression_distillation_losses(K, kind):
+    """loss: l2 / smoothl1 (models/act.py:1186-1191,1255) forward + backward against torch."""
+    import torch.nn.functional as F
+    s = _rnd("rl.s", 6, 51, 384) * 2.0; t = _rnd("rl.t", 6, 51, 384)
+    sd = s.double().requires_grad_(True)
+    ref = F.mse_loss(sd, t.double()) if kind == "l2" else F.smooth_l1_loss(sd, t.double())
+    (ref * 3.0).backward()
+    sg = s.cuda().requires_grad_(True)
+    loss = K.regression_distill_loss(sg, t.cuda(), kind)
+    (loss * 3.0).backward()
+    assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert _rel(sg.grad, sd.grad) <= 2e-6
+
+
 def test_gemm_row_strided_operands(K):
     """column slices of a weight are passed with their leading dimension when that keeps the float4 path (stride % 4 == 0,
     16-byte aligned) and copied otherwise -- FoldingNet's [512, 384+3+2] conv weight is the odd-stride case."""
