@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256, PIPE ? 3 : GEMM_MIN_WAVES) void sgemm_kernel(c
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int tile_m = wg / p.tiles_n, tile_n = wg % p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -389,6 +390,8 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         if (splits > 1 && (!workspace || (size_t)splits * M * N * sizeof(float) > workspace_bytes)) return ACT_E_BADARG;
     }
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+    static const int group_m_env = [] { const char* e = getenv("ACT_GEMM_GROUP_M"); return e ? atoi(e) : 8; }();
+    p.group_m = group_m_env;
     const long long nt = (long long)p.tiles_m * p.tiles_n;
     const int BKsel = gemm_bk();
     int kps = K;

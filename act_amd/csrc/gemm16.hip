@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_m = wg / p.tiles_n, tile_n = wg % p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int tile_m = wg / p.tiles_n, tile_n = wg % p.tiles_n;
+    int tile_m, tile_n;
+    tile_coords(p, wg, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);

@@ -16,7 +16,21 @@ struct GemmParams {
     float* partial;                  // split-K workspace [splits][M][N] (C untouched) or null
     act_gemm_epilogue_t epi;
     int tiles_m, tiles_n;
+    int group_m;                     // tile rasterisation: GROUP_M tile rows are swept column by column (1 = plain row-major)
 };
+
+// linear workgroup index (after the XCD remap) -> tile coordinates.  Grouped order: the tiles a (band of) CUs works on at the same
+// time form a compact 2-D block, so both the A row-panels and the B column-panels they touch are re-used out of the XCD's L2
+// instead of one of them streaming from fabric for every tile row.
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int wg, int& tile_m, int& tile_n) {
+    if (p.group_m <= 1) { tile_m = wg / p.tiles_n; tile_n = wg % p.tiles_n; return; }
+    const int per_group = p.group_m * p.tiles_n;
+    const int group = wg / per_group, first_m = group * p.group_m;
+    const int gsz = min(p.tiles_m - first_m, p.group_m);
+    const int in_group = wg - group * per_group;
+    tile_m = first_m + in_group % gsz;
+    tile_n = in_group / gsz;
+}
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
