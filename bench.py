@@ -195,7 +195,10 @@ def main():
                                 "B=%d clouds/GPU x 1024 pts, tokenizer + prompt-tuned frozen ViT-B + FoldingNet, "
                                 "Chamfer-L1 + KL losses, fwd+bwd+AdamW" % B),
                    "clouds_per_gpu": B, "points_per_cloud": N, "parallelism": f"dp{world}", "final_loss": loss_val,
-                   "host_enqueue_ms_per_step": 1e3 * host_issue / args.steps},
+                   "host_enqueue_ms_per_step": 1e3 * host_issue / args.steps,
+                   "schedule": ("every timed step = student fwd+bwd+AdamW of batch i on the main stream + grouping and frozen-teacher forward "
+                                "of batch i+1 on an auxiliary HIP stream (bit-identical to the sequential schedule; DESIGN section 4)")
+                               if args.stage == 2 else "sequential; next batch's FPS prepared on an auxiliary stream (stages 3, 4)"},
     }
 
     if rank == 0 and not args.no_instrument:
