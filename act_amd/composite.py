@@ -1,0 +1,442 @@
+"""Host side of the composite entry points of libact_hip.so (include/act_hip.h, csrc/composite.hip): one ctypes call enqueues
+every kernel of a module (Transformer block forward / backward, the whole frozen prompt-tuned Transformer of the teacher, the
+mini-PointNet patch embedding, DGCNN) instead of one call per kernel.
+
+Nothing is computed here.  Each autograd Function allocates its output, ONE slab for the activations the backward needs and ONE
+scratch slab per backward, fills a small parameter struct with device pointers and crosses the FFI once.
+
+GEMM launch configurations: the C side looks every GEMM up in a table keyed by (layout, M, N, K).  Before the first execution of a
+composite with given dimensions the shapes it will launch are collected (act_composite_collect_begin/_end: the call runs without
+launching anything), tuned exactly like the single-GEMM path (shipped table, else first-use timing) and registered, so results never
+depend on the call history.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _C
+from . import kernels as K
+
+_vp, _i, _f, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_uint64
+lib, check = _C.lib, _C.check
+
+ENABLED = os.environ.get("ACT_COMPOSITE", "1") != "0"       # 0: the one-call-per-kernel host path (A/B measurements, bit-identity test)
+
+
+class BlockParams(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b",
+                                   "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class BlockDims(ctypes.Structure):
+    _fields_ = [("B", _i), ("S", _i), ("D", _i), ("heads", _i), ("hidden", _i), ("eps", _f)]
+
+
+class PrefixVit(ctypes.Structure):
+    _fields_ = ([(n, _i) for n in ("B", "P", "G", "D", "heads", "hidden", "depth", "tokens_dims", "pos_hidden")] +
+                [("eps", _f), ("drop_p", _f), ("seed_base", _u64), ("seed_dev", _vp)] +
+                [(n, _vp) for n in ("pos_w0", "pos_b0", "pos_w1", "pos_b1", "pre_w", "pre_b", "post_w", "post_b", "norm_w", "norm_b")] +
+                [("prompt_tok", ctypes.POINTER(_vp)), ("prompt_pos", ctypes.POINTER(_vp)), ("blocks", ctypes.POINTER(BlockParams))])
+
+
+class PointnetParams(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("c1_w", "c1_b", "bn1_w", "bn1_b", "c2_w", "c2_b", "c3_w", "c3_b", "bn2_w", "bn2_b", "c4_w", "c4_b",
+                                   "bn1_mean", "bn1_var", "bn2_mean", "bn2_var")]
+
+
+class PointnetGrads(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("c1_w", "c1_b", "bn1_w", "bn1_b", "c2_w", "c2_b", "c3_w", "c3_b", "bn2_w", "bn2_b", "c4_w", "c4_b")]
+
+
+class PointnetDims(ctypes.Structure):
+    _fields_ = [("BG", _i), ("n", _i), ("C", _i), ("eps1", _f), ("eps2", _f), ("momentum1", _f), ("momentum2", _f)]
+
+
+class Dgcnn(ctypes.Structure):
+    _fields_ = ([(n, _i) for n in ("B", "G", "k", "Cin", "Cout", "groups")] + [("eps", _f), ("slope", _f)] +
+                [(n, _vp) for n in ("w_in", "b_in", "w5")] + [("stacked", _vp * 4), ("gn_w", _vp * 4), ("gn_b", _vp * 4)])
+
+
+_P = ctypes.POINTER
+_SIGS = {
+    "act_gemm_tune_set": [_i] * 7,
+    "act_gemm_tune_get": [_i] * 5 + [_P(_i), _P(_i)],
+    "act_gemm_tune_clear": [],
+    "act_composite_collect_begin": [],
+    "act_composite_collect_end": [_P(_i), _i],
+    "act_scale_rows_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "act_bn_eval_affine_f32": [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
+    "act_block_saved_floats": [_P(BlockDims)],
+    "act_block_bwd_scratch_floats": [_P(BlockDims)],
+    "act_block_fwd_f32": [_P(BlockDims), _P(BlockParams), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_block_bwd_f32": [_P(BlockDims), _P(BlockParams), _vp, _vp, _vp, _vp, _vp, _P(BlockParams), _vp, _vp, _sz, _vp, _sz, _vp, _vp],
+    "act_prefix_block_saved_floats": [_P(BlockDims), _i],
+    "act_prefix_block_bwd_scratch_floats": [_P(BlockDims), _i],
+    "act_prefix_block_fwd_f32": [_P(BlockDims), _i, _P(BlockParams), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_prefix_block_bwd_f32": [_P(BlockDims), _i, _P(BlockParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "act_prefix_vit_scratch_floats": [_P(PrefixVit)],
+    "act_prefix_vit_fwd_f32": [_P(PrefixVit), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "act_pointnet_saved_floats": [_P(PointnetDims)],
+    "act_pointnet_bwd_scratch_floats": [_P(PointnetDims)],
+    "act_pointnet_fwd_f32": [_P(PointnetDims), _P(PointnetParams), _vp, _i, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_pointnet_bwd_f32": [_P(PointnetDims), _P(PointnetParams), _vp, _vp, _vp, _P(PointnetGrads), _vp, _vp, _sz, _vp],
+    "act_dgcnn_scratch_floats": [_P(Dgcnn)],
+    "act_dgcnn_features_f32": [_P(Dgcnn), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+}
+_C._declare(_SIGS)
+for _n in _SIGS:
+    _C.SIGNATURES.setdefault(_n, getattr(lib, _n).argtypes)
+    if _n.endswith("_floats"):
+        getattr(lib, _n).restype = _sz
+
+
+def _p(t):
+    """device address (int) of a contiguous CUDA tensor, 0 for None -- the cheap form of _C.ptr for struct fields"""
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous():
+        raise _C.ActHipError("act_amd kernels need contiguous CUDA tensors (there is no CPU fallback)")
+    return t.data_ptr()
+
+
+def _ws_of(device, stream_handle):
+    """split-K / reduction scratch of one stream (kernels of different streams run concurrently)"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, stream_handle)
+    w = K._WS.get(key)
+    if w is None:
+        w = K._WS[key] = torch.empty(K._WS_BYTES // 4, dtype=torch.float32, device=device)
+    return w
+
+
+# ---- tuning bridge ------------------------------------------------------------------------------------------------------
+for (_ak, _bk, _M, _N, _K), (_tile, _sp) in K._GEMM_TABLE.items():
+    lib.act_gemm_tune_set(_ak, _bk, _M, _N, _K, _tile, _sp)
+_TUNED = set()
+_SHAPE_BUF = (_i * (5 * 256))()
+
+
+def _tune_shape(ak, bk, M, N, Kd, device):
+    """the decision K._gemm_config would take for this product, registered with the C-side table"""
+    if lib.act_gemm_tune_get(ak, bk, M, N, Kd, None, None) == 0:
+        return
+    if not K.AUTOTUNE or M * N * Kd < (1 << 24) or (not ak and not bk and min(M, N) <= 8):
+        return                                                  # built-in cost model / skinny streaming kernel (tile 0)
+    key = (int(ak), int(bk), M, N, Kd, device.index)
+    cfg = K._GEMM_CACHE.get(key) or K._GEMM_TABLE.get(key[:5])
+    if cfg is None:
+        if torch.cuda.is_current_stream_capturing():
+            return
+        a = torch.randn((M, Kd) if ak else (Kd, M), dtype=torch.float32, device=device)
+        b = torch.randn((N, Kd) if bk else (Kd, N), dtype=torch.float32, device=device)
+        cfg, _ = K.gemm_tune(a, b, ak, bk, M, N, Kd, K.workspace(device))
+        K._NEW_TUNED[key[:5]] = cfg
+    K._GEMM_CACHE[key] = cfg
+    lib.act_gemm_tune_set(ak, bk, M, N, Kd, int(cfg[0]), int(cfg[1]))
+
+
+def ensure_tuned(key, call, device):
+    """first use of a composite with these dimensions: collect the GEMM shapes it launches (dry call), tune + register them"""
+    if key in _TUNED:
+        return
+    check(lib.act_composite_collect_begin(), "act_composite_collect_begin")
+    try:
+        rc = call()
+    finally:
+        n = lib.act_composite_collect_end(_SHAPE_BUF, 256)
+    check(rc, "composite dry call")
+    for i in range(min(n, 256)):
+        _tune_shape(*[int(_SHAPE_BUF[5 * i + j]) for j in range(5)], device)
+    _TUNED.add(key)
+
+
+def register_tuned(ak, bk, M, N, Kd, cfg):
+    """called by the single-GEMM autotuner (kernels._gemm_config) so both host paths launch the same configuration"""
+    lib.act_gemm_tune_set(int(ak), int(bk), M, N, Kd, int(cfg[0]), int(cfg[1]))
+
+
+def reset_tuning():
+    """forget every first-use decision (tests that need identical configurations across processes)"""
+    _TUNED.clear()
+    lib.act_gemm_tune_clear()
+    for (ak, bk, M, N, Kd), (tile, sp) in K._GEMM_TABLE.items():
+        lib.act_gemm_tune_set(ak, bk, M, N, Kd, tile, sp)
+
+
+# ---- Transformer block ------------------------------------------------------------------------------------------------
+_DIMS = {}
+
+
+def _block_dims(B, S, D, heads, hidden, eps):
+    key = (B, S, D, heads, hidden, float(eps))
+    d = _DIMS.get(key)
+    if d is None:
+        d = BlockDims(B, S, D, heads, hidden, float(eps))
+        _DIMS[key] = d = (d, int(lib.act_block_saved_floats(ctypes.byref(d))), int(lib.act_block_bwd_scratch_floats(ctypes.byref(d))))
+    return d
+
+
+def _block_params(n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2):
+    return BlockParams(_p(n1w), _p(n1b), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(n2w), _p(n2b), _p(w1), _p(b1), _p(w2), _p(b2))
+
+
+class BlockFn(torch.autograd.Function):
+    """One pre-LN Transformer block applied to (x + pos) -- models/act.py:72-90 called as blk(x + pos) (:109-112) -- as ONE host call
+    per direction (act_block_fwd_f32 / act_block_bwd_f32: 7 launches forward, 16-20 backward).
+
+    forward : xin = x+pos ; x1 = xin + g1*(proj(attn(LN1(xin)))+b) ; x2 = x1 + g2*(fc2(gelu(fc1(LN2(x1))))+b)
+    g1/g2 are the per-sample DropPath gates (floor(keep+U)/keep) or None.
+    train_w: 0 frozen weights (dX only), 1 weight gradients in line, 2 weight gradients on the auxiliary stream."""
+
+    @staticmethod
+    def forward(ctx, x, pos, gate1, gate2, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, train_w):
+        B, S, D = x.shape
+        dev = x.device
+        dims, n_saved, _ = _block_dims(B, S, D, heads, w1.shape[0], eps)
+        x2d = K._f32c(x).reshape(B * S, D)
+        pos2d = K._f32c(pos).reshape(B * S, D) if pos is not None else None
+        need_grad = any(ctx.needs_input_grad)
+        prm = _block_params(n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2)
+        saved = torch.empty(n_saved, dtype=torch.float32, device=dev)
+        out = torch.empty(B, S, D, dtype=torch.float32, device=dev)
+        ws = K.workspace(dev)
+        args = (ctypes.byref(dims), ctypes.byref(prm), _p(x2d), _p(pos2d), _p(gate1), _p(gate2), int(need_grad), _p(saved), _p(out),
+                _p(ws), ws.numel() * 4)
+        ensure_tuned(("blk_fwd", B, S, D, heads, w1.shape[0]), lambda: lib.act_block_fwd_f32(*args, _C.stream()), dev)
+        check(lib.act_block_fwd_f32(*args, _C.stream()), "act_block_fwd_f32")
+        if need_grad:
+            ctx.save_for_backward(saved, gate1, gate2, n1w, wqkv, bqkv, wproj, n2w, w1, w2)
+            ctx.dims = (B, S, D, heads, w1.shape[0], eps)
+            ctx.has_pos = pos is not None
+            ctx.train_w = int(train_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved, gate1, gate2, n1w, wqkv, bqkv, wproj, n2w, w1, w2 = ctx.saved_tensors
+        B, S, D, heads, hidden, eps = ctx.dims
+        dev = dout.device
+        dims, _, n_scratch = _block_dims(B, S, D, heads, hidden, eps)
+        dout = K._f32c(dout).reshape(B * S, D)
+        tw = ctx.train_w
+        prm = _block_params(n1w, None, wqkv, bqkv, wproj, None, n2w, None, w1, None, w2, None)
+        dx = torch.empty(B, S, D, dtype=torch.float32, device=dev)
+        scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
+        grads, gp = (None,) * 12, None
+        if tw:
+            e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+            grads = (e(D), e(D), e(3 * D, D), e(3 * D) if bqkv is not None else None, e(D, D), e(D), e(D), e(D),
+                     e(hidden, D), e(hidden), e(D, hidden), e(D))
+            gp = ctypes.byref(BlockParams(*[_p(g) for g in grads]))
+        ws = K.workspace(dev)
+        side, sws = None, None
+        if tw == 2 and K.OVERLAP_DW:
+            side = K.side_stream(dev, 1).cuda_stream
+            sws = _ws_of(dev, side)
+        args = (ctypes.byref(dims), ctypes.byref(prm), _p(gate1), _p(gate2), _p(saved), _p(dout), _p(dx), gp, _p(scratch),
+                _p(ws), ws.numel() * 4, _p(sws), (sws.numel() * 4 if sws is not None else 0))
+        ensure_tuned(("blk_bwd", B, S, D, heads, hidden, bool(tw)), lambda: lib.act_block_bwd_f32(*args, _C.stream(), side), dev)
+        check(lib.act_block_bwd_f32(*args, _C.stream(), side), "act_block_bwd_f32")
+        dg1, dbt1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbt2, dw1, db1, dw2, db2 = grads
+        return (dx, dx if ctx.has_pos else None, None, None, dg1, dbt1, dwqkv, dbqkv, dwproj, dbproj, dg2, dbt2,
+                dw1, db1, dw2, db2, None, None, None)
+
+
+# ---- prefix block (prompts = keys / values only) ---------------------------------------------------------------------------
+_PDIMS = {}
+
+
+def _prefix_dims(B, G, D, heads, hidden, eps, P):
+    key = (B, G, D, heads, hidden, float(eps), P)
+    d = _PDIMS.get(key)
+    if d is None:
+        d = BlockDims(B, G, D, heads, hidden, float(eps))
+        _PDIMS[key] = d = (d, int(lib.act_prefix_block_saved_floats(ctypes.byref(d), P)),
+                           int(lib.act_prefix_block_bwd_scratch_floats(ctypes.byref(d), P)))
+    return d
+
+
+class PrefixBlockFn(torch.autograd.Function):
+    """Pre-LN block on G patch tokens per cloud with P prompt tokens acting as keys/values only, WITH backward to the patch
+    tokens, their positions and the prompts (Stage-I prompt tuning of the frozen Transformer, models/dvae.py:536-576: every
+    layer replaces the prompt rows of its input and the output drops them, so prompt rows never need queries / proj / MLP).
+    The block weights are frozen (freeze_visual_embed: True); inputs x2d [B*G,D], pos2d [B*G,D], prm2d [B*P,D] = prompt+pos."""
+
+    @staticmethod
+    def forward(ctx, x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps):
+        D = x2d.shape[1]
+        dev = x2d.device
+        dims, n_saved, _ = _prefix_dims(B, G, D, heads, w1.shape[0], eps, P)
+        x2d, pos2d, prm2d = K._f32c(x2d), K._f32c(pos2d), K._f32c(prm2d)
+        prm = _block_params(n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2)
+        saved = torch.empty(n_saved, dtype=torch.float32, device=dev)
+        out = torch.empty(B * G, D, dtype=torch.float32, device=dev)
+        ws = K.workspace(dev)
+        args = (ctypes.byref(dims), P, ctypes.byref(prm), _p(x2d), _p(pos2d), _p(prm2d), None, 1, _p(saved), _p(out), _p(ws), ws.numel() * 4)
+        ensure_tuned(("pfx_fwd", B, G, D, heads, w1.shape[0], P), lambda: lib.act_prefix_block_fwd_f32(*args, _C.stream()), dev)
+        check(lib.act_prefix_block_fwd_f32(*args, _C.stream()), "act_prefix_block_fwd_f32")
+        ctx.save_for_backward(saved, prm2d, n1w, wqkv, wproj, n2w, w1, w2)
+        ctx.dims = (B, P, G, D, heads, w1.shape[0], eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved, prm2d, n1w, wqkv, wproj, n2w, w1, w2 = ctx.saved_tensors
+        B, P, G, D, heads, hidden, eps = ctx.dims
+        dev = dout.device
+        dims, _, n_scratch = _prefix_dims(B, G, D, heads, hidden, eps, P)
+        dout = K._f32c(dout)
+        prm = _block_params(n1w, None, wqkv, None, wproj, None, n2w, None, w1, None, w2, None)
+        dx = torch.empty(B * G, D, dtype=torch.float32, device=dev)
+        dprm = torch.empty(B * P, D, dtype=torch.float32, device=dev)
+        scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
+        ws = K.workspace(dev)
+        args = (ctypes.byref(dims), P, ctypes.byref(prm), _p(prm2d), _p(saved), _p(dout), _p(dx), _p(dprm), _p(scratch), _p(ws), ws.numel() * 4)
+        ensure_tuned(("pfx_bwd", B, G, D, heads, hidden, P), lambda: lib.act_prefix_block_bwd_f32(*args, _C.stream()), dev)
+        check(lib.act_prefix_block_bwd_f32(*args, _C.stream()), "act_prefix_block_bwd_f32")
+        return (dx, dx, dprm) + (None,) * 17
+
+
+def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, n1p=None):
+    """Inference-only prefix block (one host call): exactly the patch-token rows of
+    blk(cat(prompt, x) + cat(prompt_pos, pos)) of models/dvae.py:549-571.  prm2d [B*P, D] = prompt + prompt_pos, or n1p = its LayerNorm."""
+    D = x2d.shape[1]
+    dev = x2d.device
+    dims, n_saved, _ = _prefix_dims(B, G, D, heads, w1.shape[0], eps, P)
+    x2d, pos2d = K._f32c(x2d), K._f32c(pos2d)
+    prm2d = K._f32c(prm2d) if prm2d is not None else None
+    n1p = K._f32c(n1p) if n1p is not None else None
+    prm = _block_params(n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2)
+    tmp = torch.empty(n_saved, dtype=torch.float32, device=dev)
+    out = torch.empty(B * G, D, dtype=torch.float32, device=dev)
+    ws = K.workspace(dev)
+    args = (ctypes.byref(dims), P, ctypes.byref(prm), _p(x2d), _p(pos2d), _p(prm2d), _p(n1p), 0, _p(tmp), _p(out), _p(ws), ws.numel() * 4)
+    ensure_tuned(("pfx_fwd", B, G, D, heads, w1.shape[0], P), lambda: lib.act_prefix_block_fwd_f32(*args, _C.stream()), dev)
+    check(lib.act_prefix_block_fwd_f32(*args, _C.stream()), "act_prefix_block_fwd_f32")
+    return out
+
+
+# ---- the frozen prompt-tuned Transformer of the teacher, whole stack --------------------------------------------------------
+def prefix_vit_forward(tok, tokens, center, drop_p, seed_base, seed_dev):
+    """``tok`` = ACTPromptedDiscreteVAEwithVIT (frozen); tokens [B,G,tokens_dims], center [B,G,3] -> [B,G,tokens_dims].
+    visual_embedding_deep_prompt (models/dvae.py:536-576), inference form, in one host call (~125 launches)."""
+    B, G, td = tokens.shape
+    dev = tokens.device
+    blocks = tok.visual_embed[0]
+    depth, Pn, D = tok.visual_embed_depth, tok.num_prompt_token, tok.visual_embed_dim
+    vp, nrm = tok.visual_pos_embed, tok.visual_embed[1]
+    b0 = blocks[0]
+    m = PrefixVit()
+    m.B, m.P, m.G, m.D, m.heads, m.hidden, m.depth, m.tokens_dims, m.pos_hidden = (B, Pn, G, D, b0.num_heads, b0.mlp.fc1.weight.shape[0], depth, td,
+                                                                                    vp[0].weight.shape[0])
+    m.eps, m.drop_p, m.seed_base, m.seed_dev = float(b0.eps), float(drop_p), int(seed_base) & (2 ** 64 - 1), _p(seed_dev)
+    m.pos_w0, m.pos_b0, m.pos_w1, m.pos_b1 = _p(vp[0].weight), _p(vp[0].bias), _p(vp[2].weight), _p(vp[2].bias)
+    m.pre_w, m.pre_b, m.post_w, m.post_b = _p(tok.proj_pre.weight), _p(tok.proj_pre.bias), _p(tok.proj_post.weight), _p(tok.proj_post.bias)
+    m.norm_w, m.norm_b = _p(nrm.weight), _p(nrm.bias)
+    toks = (_vp * depth)(*[_p(tok.visual_prompt_token[0] if i == 0 else tok.deep_prompt_tokens[i - 1]) for i in range(depth)])
+    poss = (_vp * depth)(*[_p(tok.visual_prompt_pos[0] if i == 0 else tok.deep_prompt_pos[i - 1]) for i in range(depth)])
+    blks = (BlockParams * depth)()
+    for i, blk in enumerate(blocks):
+        a, ml = blk.attn, blk.mlp
+        blks[i] = _block_params(blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, blk.norm2.weight,
+                                blk.norm2.bias, ml.fc1.weight, ml.fc1.bias, ml.fc2.weight, ml.fc2.bias)
+    m.prompt_tok, m.prompt_pos, m.blocks = toks, poss, blks
+    n_scratch = int(lib.act_prefix_vit_scratch_floats(ctypes.byref(m)))
+    scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
+    out = torch.empty(B, G, td, dtype=torch.float32, device=dev)
+    ws = K.workspace(dev)
+    tokens, center = K._f32c(tokens), K._f32c(center)
+    args = (ctypes.byref(m), _p(tokens), _p(center), _p(out), _p(scratch), _p(ws), ws.numel() * 4)
+    ensure_tuned(("vit", B, Pn, G, D, m.heads, m.hidden, depth, td), lambda: lib.act_prefix_vit_fwd_f32(*args, _C.stream()), dev)
+    check(lib.act_prefix_vit_fwd_f32(*args, _C.stream()), "act_prefix_vit_fwd_f32")
+    return out
+
+
+# ---- mini-PointNet patch embedding ---------------------------------------------------------------------------------------
+def _pointnet_structs(enc, BG, n):
+    c1, bn1, _, c2 = enc.first_conv
+    c3, bn2, _, c4 = enc.second_conv
+    dims = PointnetDims(BG, n, c4.weight.shape[0], float(bn1.eps), float(bn2.eps), float(bn1.momentum), float(bn2.momentum))
+    return dims, (c1, bn1, c2, c3, bn2, c4)
+
+
+class PointnetFn(torch.autograd.Function):
+    """Encoder.forward (models/dvae.py:201-215) on rows [BG*n, 3] -> tokens [BG, C]: act_pointnet_fwd_f32 / act_pointnet_bwd_f32.
+    ``buffers`` = (bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var), updated in place when training."""
+
+    @staticmethod
+    def forward(ctx, x, c1w, c1b, g1, b1, c2w, c2b, c3w, c3b, g2, b2, c4w, c4b, buffers, dims, training):
+        dev = x.device
+        x = K._f32c(x)
+        need_grad = any(ctx.needs_input_grad)
+        prm = PointnetParams(*[_p(t) for t in (c1w, c1b, g1, b1, c2w, c2b, c3w, c3b, g2, b2, c4w, c4b) + tuple(buffers)])
+        saved = torch.empty(int(lib.act_pointnet_saved_floats(ctypes.byref(dims))), dtype=torch.float32, device=dev)
+        out = torch.empty(dims.BG, dims.C, dtype=torch.float32, device=dev)
+        ws = K.workspace(dev)
+        args = (ctypes.byref(dims), ctypes.byref(prm), _p(x), int(training), int(need_grad), _p(saved), _p(out), _p(ws), ws.numel() * 4)
+        ensure_tuned(("pn_fwd", dims.BG, dims.n, dims.C), lambda: lib.act_pointnet_fwd_f32(*args, _C.stream()), dev)
+        check(lib.act_pointnet_fwd_f32(*args, _C.stream()), "act_pointnet_fwd_f32")
+        if need_grad:
+            ctx.save_for_backward(x, saved, c1w, c1b, g1, b1, c2w, c2b, c3w, c3b, g2, b2, c4w, c4b)
+            ctx.dims, ctx.training = dims, bool(training)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise NotImplementedError("mini-PointNet backward in eval mode (running statistics) is off the training path")
+        x, saved = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        dims = ctx.dims
+        dev = dout.device
+        dout = K._f32c(dout)
+        prm = PointnetParams(*([_p(t) for t in params] + [None] * 4))
+        grads = tuple(torch.empty_like(t) for t in params)
+        gp = PointnetGrads(*[_p(g) for g in grads])
+        scratch = torch.empty(int(lib.act_pointnet_bwd_scratch_floats(ctypes.byref(dims))), dtype=torch.float32, device=dev)
+        ws = K.workspace(dev)
+        args = (ctypes.byref(dims), ctypes.byref(prm), _p(x), _p(saved), _p(dout), ctypes.byref(gp), _p(scratch), _p(ws), ws.numel() * 4)
+        ensure_tuned(("pn_bwd", dims.BG, dims.n, dims.C), lambda: lib.act_pointnet_bwd_f32(*args, _C.stream()), dev)
+        check(lib.act_pointnet_bwd_f32(*args, _C.stream()), "act_pointnet_bwd_f32")
+        return (None,) + grads + (None, None, None)
+
+
+def pointnet_forward(enc, point_groups):
+    """``enc`` = models.dvae.Encoder; point_groups [bs, g, n, 3] -> [bs, g, C]"""
+    bs, g, n, _ = point_groups.shape
+    dims, (c1, bn1, c2, c3, bn2, c4) = _pointnet_structs(enc, bs * g, n)
+    training = enc.training
+    if training:
+        for bn in (bn1, bn2):
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+    w2 = lambda c: c.weight.view(c.weight.shape[0], c.weight.shape[1])
+    out = PointnetFn.apply(point_groups.reshape(bs * g * n, 3), w2(c1), c1.bias, bn1.weight, bn1.bias, w2(c2), c2.bias, w2(c3), c3.bias,
+                           bn2.weight, bn2.bias, w2(c4), c4.bias,
+                           (bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var), dims, training)
+    return out.reshape(bs, g, dims.C)
+
+
+# ---- DGCNN, inference form -------------------------------------------------------------------------------------------------
+def dgcnn_features(dg, f, idx, stacked):
+    """``dg`` = models.dvae.DGCNN (frozen / no grad); f [B,G,Cin], idx int64 [B,k,G], stacked = the four [Wa ; Wb-Wa] matrices
+    -> pre-norm head rows [B*G, Cout] (everything up to layer5's GroupNorm), one host call (10 launches)."""
+    B, G, Cin = f.shape
+    dev = f.device
+    w5 = dg.layer5[0].weight
+    m = Dgcnn()
+    gn0 = dg.layer1[1]
+    m.B, m.G, m.k, m.Cin, m.Cout, m.groups = B, G, idx.shape[1], Cin, w5.shape[0], gn0.num_groups
+    m.eps, m.slope = float(gn0.eps), 0.2
+    m.w_in, m.b_in, m.w5 = _p(dg.input_trans.weight), _p(dg.input_trans.bias), _p(w5)
+    for l, layer in enumerate((dg.layer1, dg.layer2, dg.layer3, dg.layer4)):
+        m.stacked[l], m.gn_w[l], m.gn_b[l] = _p(stacked[l]), _p(layer[1].weight), _p(layer[1].bias)
+    scratch = torch.empty(int(lib.act_dgcnn_scratch_floats(ctypes.byref(m))), dtype=torch.float32, device=dev)
+    h = torch.empty(B * G, m.Cout, dtype=torch.float32, device=dev)
+    ws = K.workspace(dev)
+    f = K._f32c(f)
+    args = (ctypes.byref(m), _p(f), _p(idx), _p(h), _p(scratch), _p(ws), ws.numel() * 4)
+    ensure_tuned(("dgcnn", B, G, Cin, m.Cout), lambda: lib.act_dgcnn_features_f32(*args, _C.stream()), dev)
+    check(lib.act_dgcnn_features_f32(*args, _C.stream()), "act_dgcnn_features_f32")
+    return h

@@ -1,0 +1,478 @@
+// composite.hip -- host-side launch sequences: one C call enqueues every kernel of a module (include/act_hip.h, "composite
+// entry points").  No device code here: each function is the fixed launch schedule of one module of the path, built from the
+// single-kernel entry points of this library, so results are bit-identical to issuing those calls one by one from the host
+// language -- what changes is the host cost (one FFI crossing + ~4 us per hipLaunchKernel instead of ~35 us of Python per launch).
+//
+// Stream discipline: everything is enqueued on `stream`; weight-gradient GEMMs + bias column sums of a block backward go to
+// `side_stream` when one is given: fork = event recorded on `stream` after the producing kernel, join = event recorded on
+// `side_stream` that `stream` waits for before the function returns.  Buffers handed to the side stream are caller-owned slabs
+// that outlive the call on `stream` order, so the caller's allocator never sees a cross-stream hazard.
+#include "common.h"
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#define CK(expr) do { const int rc__ = (expr); if (rc__ != 0) return rc__; } while (0)
+// every non-GEMM launch goes through RUN: skipped while the calling thread collects the GEMM shapes of a composite (see below)
+#define RUN(expr) do { if (!t_collect) { const int rc__ = (expr); if (rc__ != 0) return rc__; } } while (0)
+
+namespace {
+
+// ---- shape collection: between act_composite_collect_begin / _end (same host thread) the composite entry points launch
+// nothing and only record the (a_kmajor, b_kmajor, M, N, K) of every GEMM they would launch, so the host-side autotuner can
+// time and register configurations for them BEFORE their first real execution (results then never depend on call history)
+struct GemmShape { int ak, bk, M, N, K; };
+thread_local std::vector<GemmShape>* t_collect = nullptr;
+inline bool collecting(int ak, int bk, int M, int N, int K) {
+    if (!t_collect) return false;
+    t_collect->push_back({ak, bk, M, N, K});
+    return true;
+}
+
+// ---- fork / join events: a small ring per side stream (an event may be re-recorded while an earlier wait on it is pending:
+// hipStreamWaitEvent captures the record that is current at call time; the ring only keeps the number of live records small)
+struct EventRing {
+    std::vector<hipEvent_t> ev;
+    size_t next = 0;
+    hipEvent_t get() {
+        if (ev.size() < 32) { hipEvent_t e; hipEventCreateWithFlags(&e, hipEventDisableTiming); ev.push_back(e); return e; }
+        hipEvent_t e = ev[next]; next = (next + 1) % ev.size(); return e;
+    }
+};
+std::mutex g_ring_mu;
+std::unordered_map<hipStream_t, EventRing> g_rings;
+
+int order_after(hipStream_t waiter, hipStream_t producer) {            // work enqueued later on `waiter` runs after everything on `producer`
+    if (t_collect) return 0;
+    hipEvent_t e;
+    { std::lock_guard<std::mutex> g(g_ring_mu); e = g_rings[producer].get(); }
+    hipError_t r = hipEventRecord(e, producer);
+    if (r != hipSuccess) return (int)r;
+    r = hipStreamWaitEvent(waiter, e, 0);
+    return (int)r;
+}
+
+inline float attn_scale(int hd) { return (float)pow((double)hd, -0.5); }      // == Python's float(hd) ** -0.5
+inline act_gemm_epilogue_t epi0() { act_gemm_epilogue_t e{}; e.alpha = 1.0f; return e; }
+
+// C[M,N] = epi(A[M,K] . W[N,K]^T)            forward Linear
+int gemm_nt(int M, int N, int K, const float* A, int lda, const float* W, int ldw, float* C, int ldc, const act_gemm_epilogue_t& e,
+            float* ws, size_t wsb, hipStream_t s) {
+    if (collecting(1, 1, M, N, K)) return 0;
+    return act_sgemm_f32(1, 1, M, N, K, A, lda, W, ldw, C, ldc, &e, ws, wsb, s);
+}
+// dX[M,K'] = epi(dY[M,N'] . W[N',K'])        input gradient: A = dY [M][N'] K-major, B = W stored [N'][K'] = [K][N] N-major
+int gemm_nn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const act_gemm_epilogue_t& e,
+            float* ws, size_t wsb, hipStream_t s) {
+    if (collecting(1, 0, M, N, K)) return 0;
+    return act_sgemm_f32(1, 0, M, N, K, A, lda, B, ldb, C, ldc, &e, ws, wsb, s);
+}
+// dW[M,N] = dY[K,M]^T . X[K,N]               weight gradient: both operands stored [K][*]
+int gemm_tn(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* ws, size_t wsb, hipStream_t s) {
+    if (collecting(0, 0, M, N, K)) return 0;
+    const act_gemm_epilogue_t e = epi0();
+    return act_sgemm_f32(0, 0, M, N, K, A, lda, B, ldb, C, ldc, &e, ws, wsb, s);
+}
+int colsum(const float* in, int R, int C, float* out, float* ws, size_t wsb, hipStream_t s) {
+    if (t_collect) return 0;
+    if (wsb < act_colsum_workspace(R, C)) return ACT_E_BADARG;
+    return act_colsum_f32(in, R, C, C, out, 0, ws, wsb, s);
+}
+
+struct Carver {                      // hands out consecutive, 4-float aligned pieces of a slab
+    float* p; size_t used = 0;
+    explicit Carver(float* base) : p(base) {}
+    float* take(size_t n) { float* r = p ? p + used : nullptr; used += (n + 3) & ~(size_t)3; return r; }
+};
+
+// ---- Transformer block ---------------------------------------------------------------------------------------------------
+struct BlockSaved { float *xin, *n1, *qkv, *att, *x1, *n2, *hpre, *a, *mean1, *rstd1, *mean2, *rstd2, *lse; };
+size_t carve_block(float* base, const act_block_dims_t& d, BlockSaved& sv) {
+    const size_t T = (size_t)d.B * d.S, D = d.D, Hd = d.hidden;
+    Carver c(base);
+    sv.xin = c.take(T * D); sv.n1 = c.take(T * D); sv.qkv = c.take(T * 3 * D); sv.att = c.take(T * D); sv.x1 = c.take(T * D);
+    sv.n2 = c.take(T * D); sv.hpre = c.take(T * Hd); sv.a = c.take(T * Hd);
+    sv.mean1 = c.take(T); sv.rstd1 = c.take(T); sv.mean2 = c.take(T); sv.rstd2 = c.take(T); sv.lse = c.take((size_t)d.B * d.heads * d.S);
+    return c.used;
+}
+struct BlockBwdScratch { float *dy2, *dh, *dn2, *dx1, *dy1, *datt, *dqkv, *dn1; };
+size_t carve_block_bwd(float* base, const act_block_dims_t& d, BlockBwdScratch& sc) {
+    const size_t T = (size_t)d.B * d.S, D = d.D, Hd = d.hidden;
+    Carver c(base);
+    sc.dy2 = c.take(T * D); sc.dh = c.take(T * Hd); sc.dn2 = c.take(T * D); sc.dx1 = c.take(T * D); sc.dy1 = c.take(T * D);
+    sc.datt = c.take(T * D); sc.dqkv = c.take(T * 3 * D); sc.dn1 = c.take(T * D);
+    return c.used;
+}
+bool bad_dims(const act_block_dims_t* d) {
+    return !d || d->B <= 0 || d->S <= 0 || d->D <= 0 || d->heads <= 0 || d->D % d->heads || d->hidden <= 0;
+}
+
+// ---- prefix block --------------------------------------------------------------------------------------------------------
+struct PrefixSaved { float *n1p, *meanp, *rstdp, *kvp, *xin, *n1x, *mean1, *rstd1, *qkvx, *att, *lse, *x1, *n2, *mean2, *rstd2, *hpre, *a; };
+size_t carve_prefix(float* base, const act_block_dims_t& d, int P, PrefixSaved& sv) {
+    const size_t TG = (size_t)d.B * d.S, TP = (size_t)d.B * P, D = d.D, Hd = d.hidden;
+    Carver c(base);
+    sv.n1p = c.take(TP * D); sv.kvp = c.take(TP * 2 * D); sv.xin = c.take(TG * D); sv.n1x = c.take(TG * D); sv.qkvx = c.take(TG * 3 * D);
+    sv.att = c.take(TG * D); sv.x1 = c.take(TG * D); sv.n2 = c.take(TG * D); sv.hpre = c.take(TG * Hd); sv.a = c.take(TG * Hd);
+    sv.meanp = c.take(TP); sv.rstdp = c.take(TP); sv.mean1 = c.take(TG); sv.rstd1 = c.take(TG); sv.mean2 = c.take(TG); sv.rstd2 = c.take(TG);
+    sv.lse = c.take((size_t)d.B * d.heads * d.S);
+    return c.used;
+}
+struct PrefixBwdScratch { float *dh, *dn2, *dx1, *datt, *dkvp, *dqkvx, *dn1x, *dn1p; };
+size_t carve_prefix_bwd(float* base, const act_block_dims_t& d, int P, PrefixBwdScratch& sc) {
+    const size_t TG = (size_t)d.B * d.S, TP = (size_t)d.B * P, D = d.D, Hd = d.hidden;
+    Carver c(base);
+    sc.dh = c.take(TG * Hd); sc.dn2 = c.take(TG * D); sc.dx1 = c.take(TG * D); sc.datt = c.take(TG * D); sc.dkvp = c.take(TP * 2 * D);
+    sc.dqkvx = c.take(TG * 3 * D); sc.dn1x = c.take(TG * D); sc.dn1p = c.take(TP * D);
+    return c.used;
+}
+
+// the launch sequence of one prefix block given the LayerNorm'd prompt rows n1p (shared by the inference stack and the
+// differentiable forward)
+int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t& w, const float* x, const float* pos, const float* n1p,
+                      bool keep, PrefixSaved& sv, float* out, float* ws, size_t wsb, hipStream_t s) {
+    const int B = d.B, G = d.S, D = d.D, H = d.heads, hd = D / H, Hd = d.hidden, TG = B * G, TP = B * P;
+    act_gemm_epilogue_t e = epi0();
+    e.bias = w.qkv_b ? w.qkv_b + D : nullptr;                                                   // K,V rows of the qkv Linear
+    CK(gemm_nt(TP, 2 * D, D, n1p, D, w.qkv_w + (size_t)D * D, D, sv.kvp, 2 * D, e, ws, wsb, s));
+    RUN(act_layernorm_fwd_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, sv.n1x, keep ? sv.mean1 : nullptr, keep ? sv.rstd1 : nullptr, TG, D, d.eps, s));
+    e = epi0(); e.bias = w.qkv_b;
+    CK(gemm_nt(TG, 3 * D, D, sv.n1x, D, w.qkv_w, D, sv.qkvx, 3 * D, e, ws, wsb, s));
+    RUN(act_attention_fwd_prefix_f32(sv.kvp, P, sv.qkvx, G, sv.att, keep ? sv.lse : nullptr, B, H, hd, attn_scale(hd), s));
+    e = epi0(); e.bias = w.proj_b; e.res = sv.xin; e.ldr = D;
+    CK(gemm_nt(TG, D, D, sv.att, D, w.proj_w, D, sv.x1, D, e, ws, wsb, s));
+    RUN(act_layernorm_fwd_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, sv.n2, keep ? sv.mean2 : nullptr, keep ? sv.rstd2 : nullptr, TG, D, d.eps, s));
+    e = epi0(); e.bias = w.fc1_b; e.act = ACT_EPI_GELU; e.aux = keep ? sv.hpre : nullptr; e.ldaux = Hd;
+    CK(gemm_nt(TG, Hd, D, sv.n2, D, w.fc1_w, D, sv.a, Hd, e, ws, wsb, s));
+    e = epi0(); e.bias = w.fc2_b; e.res = sv.x1; e.ldr = D;
+    CK(gemm_nt(TG, D, Hd, sv.a, Hd, w.fc2_w, Hd, out, D, e, ws, wsb, s));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int act_composite_collect_begin(void) {
+    if (t_collect) return ACT_E_BADARG;
+    t_collect = new std::vector<GemmShape>();
+    return 0;
+}
+// -> number of recorded GEMMs (the first `max` are written to shapes [max][5] = a_kmajor, b_kmajor, M, N, K)
+int act_composite_collect_end(int* shapes, int max) {
+    if (!t_collect) return ACT_E_BADARG;
+    const int n = (int)t_collect->size();
+    for (int i = 0; i < n && i < max && shapes; ++i) {
+        const GemmShape& g = (*t_collect)[i];
+        shapes[5 * i] = g.ak; shapes[5 * i + 1] = g.bk; shapes[5 * i + 2] = g.M; shapes[5 * i + 3] = g.N; shapes[5 * i + 4] = g.K;
+    }
+    delete t_collect; t_collect = nullptr;
+    return n;
+}
+
+// ============================================================================================== Transformer block
+size_t act_block_saved_floats(const act_block_dims_t* d) {
+    if (bad_dims(d)) return 0;
+    BlockSaved sv; return carve_block(nullptr, *d, sv);
+}
+size_t act_block_bwd_scratch_floats(const act_block_dims_t* d) {
+    if (bad_dims(d)) return 0;
+    BlockBwdScratch sc; return carve_block_bwd(nullptr, *d, sc);
+}
+
+int act_block_fwd_f32(const act_block_dims_t* d, const act_block_params_t* w, const float* x, const float* pos, const float* gate1,
+                      const float* gate2, int keep_for_backward, float* saved, float* out, float* ws, size_t wsb, act_stream_t stream) {
+    if (!w || !x || !saved || !out) return ACT_E_NULLPTR;
+    if (bad_dims(d)) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = d->B, S = d->S, D = d->D, H = d->heads, hd = D / H, Hd = d->hidden, T = B * S;
+    const bool keep = keep_for_backward != 0;
+    BlockSaved sv; carve_block(saved, *d, sv);
+    RUN(act_layernorm_fwd_f32(x, pos, w->norm1_w, w->norm1_b, sv.xin, sv.n1, keep ? sv.mean1 : nullptr, keep ? sv.rstd1 : nullptr, T, D, d->eps, s));
+    act_gemm_epilogue_t e = epi0(); e.bias = w->qkv_b;
+    CK(gemm_nt(T, 3 * D, D, sv.n1, D, w->qkv_w, D, sv.qkv, 3 * D, e, ws, wsb, s));
+    RUN(act_attention_fwd_f32(sv.qkv, sv.att, keep ? sv.lse : nullptr, B, S, H, hd, attn_scale(hd), s));
+    e = epi0(); e.bias = w->proj_b; e.rowscale = gate1; e.rows_per_scale = S; e.res = sv.xin; e.ldr = D;
+    CK(gemm_nt(T, D, D, sv.att, D, w->proj_w, D, sv.x1, D, e, ws, wsb, s));
+    RUN(act_layernorm_fwd_f32(sv.x1, nullptr, w->norm2_w, w->norm2_b, nullptr, sv.n2, keep ? sv.mean2 : nullptr, keep ? sv.rstd2 : nullptr, T, D, d->eps, s));
+    e = epi0(); e.bias = w->fc1_b; e.act = ACT_EPI_GELU; e.aux = keep ? sv.hpre : nullptr; e.ldaux = Hd;
+    CK(gemm_nt(T, Hd, D, sv.n2, D, w->fc1_w, D, sv.a, Hd, e, ws, wsb, s));
+    e = epi0(); e.bias = w->fc2_b; e.rowscale = gate2; e.rows_per_scale = S; e.res = sv.x1; e.ldr = D;
+    CK(gemm_nt(T, D, Hd, sv.a, Hd, w->fc2_w, Hd, out, D, e, ws, wsb, s));
+    return 0;
+}
+
+int act_block_bwd_f32(const act_block_dims_t* d, const act_block_params_t* w, const float* gate1, const float* gate2, const float* saved,
+                      const float* dout, float* dx, const act_block_grads_t* g, float* scratch, float* ws, size_t wsb, float* sws,
+                      size_t swsb, act_stream_t stream, act_stream_t side_stream) {
+    if (!w || !saved || !dout || !dx || !scratch) return ACT_E_NULLPTR;
+    if (bad_dims(d)) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fork = g && side_stream && side_stream != stream && sws;
+    hipStream_t ss = fork ? (hipStream_t)side_stream : s;           // stream of the weight-gradient work
+    float* wws = fork ? sws : ws; const size_t wwsb = fork ? swsb : wsb;
+    const int B = d->B, S = d->S, D = d->D, H = d->heads, hd = D / H, Hd = d->hidden, T = B * S;
+    BlockSaved sv; carve_block(const_cast<float*>(saved), *d, sv);
+    BlockBwdScratch sc; carve_block_bwd(scratch, *d, sc);
+
+    // dW = dy^T . x and db = column sums of dy, after everything enqueued so far on `stream`
+    auto wgrad = [&](const float* dy, int N, const float* xop, int K, float* dw, float* db) -> int {
+        if (!g) return 0;
+        if (fork) CK(order_after(ss, s));
+        if (dw) CK(gemm_tn(N, K, T, dy, N, xop, K, dw, K, wws, wwsb, ss));
+        if (db) CK(colsum(dy, T, N, db, wws, wwsb, ss));
+        return 0;
+    };
+
+    const float* dy2 = dout;
+    if (gate2) { RUN(act_scale_rows_f32(dout, gate2, T, D, S, sc.dy2, s)); dy2 = sc.dy2; }
+    CK(wgrad(dy2, D, sv.a, Hd, g ? g->fc2_w : nullptr, g ? g->fc2_b : nullptr));
+    act_gemm_epilogue_t e = epi0(); e.act = ACT_EPI_MUL_GELU_GRAD; e.aux = sv.hpre; e.ldaux = Hd;
+    CK(gemm_nn(T, Hd, D, dy2, D, w->fc2_w, Hd, sc.dh, Hd, e, ws, wsb, s));
+    CK(wgrad(sc.dh, Hd, sv.n2, D, g ? g->fc1_w : nullptr, g ? g->fc1_b : nullptr));
+    CK(gemm_nn(T, D, Hd, sc.dh, Hd, w->fc1_w, D, sc.dn2, D, epi0(), ws, wsb, s));
+    RUN(act_layernorm_bwd_f32(sc.dn2, sv.x1, w->norm2_w, sv.mean2, sv.rstd2, dout, sc.dx1, g ? g->norm2_w : nullptr, g ? g->norm2_b : nullptr, 0,
+                             ws, wsb, T, D, s));
+    const float* dy1 = sc.dx1;
+    if (gate1) { RUN(act_scale_rows_f32(sc.dx1, gate1, T, D, S, sc.dy1, s)); dy1 = sc.dy1; }
+    CK(wgrad(dy1, D, sv.att, D, g ? g->proj_w : nullptr, g ? g->proj_b : nullptr));
+    CK(gemm_nn(T, D, D, dy1, D, w->proj_w, D, sc.datt, D, epi0(), ws, wsb, s));
+    RUN(act_attention_bwd_f32(sv.qkv, sv.att, sc.datt, sv.lse, sc.dqkv, B, S, H, hd, attn_scale(hd), s));
+    CK(wgrad(sc.dqkv, 3 * D, sv.n1, D, g ? g->qkv_w : nullptr, (g && w->qkv_b) ? g->qkv_b : nullptr));
+    CK(gemm_nn(T, D, 3 * D, sc.dqkv, 3 * D, w->qkv_w, D, sc.dn1, D, epi0(), ws, wsb, s));
+    RUN(act_layernorm_bwd_f32(sc.dn1, sv.xin, w->norm1_w, sv.mean1, sv.rstd1, sc.dx1, dx, g ? g->norm1_w : nullptr, g ? g->norm1_b : nullptr, 0,
+                             ws, wsb, T, D, s));
+    if (fork) CK(order_after(s, ss));
+    return 0;
+}
+
+// ============================================================================================== prefix block (prompts = keys / values only)
+size_t act_prefix_block_saved_floats(const act_block_dims_t* d, int P) {
+    if (bad_dims(d) || P < 0) return 0;
+    PrefixSaved sv; return carve_prefix(nullptr, *d, P, sv);
+}
+size_t act_prefix_block_bwd_scratch_floats(const act_block_dims_t* d, int P) {
+    if (bad_dims(d) || P < 0) return 0;
+    PrefixBwdScratch sc; return carve_prefix_bwd(nullptr, *d, P, sc);
+}
+
+int act_prefix_block_fwd_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const float* x, const float* pos, const float* prm,
+                             const float* n1p_in, int keep_for_backward, float* saved, float* out, float* ws, size_t wsb, act_stream_t stream) {
+    if (!w || !x || !saved || !out || (!prm && !n1p_in)) return ACT_E_NULLPTR;
+    if (bad_dims(d) || P <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool keep = keep_for_backward != 0;
+    PrefixSaved sv; carve_prefix(saved, *d, P, sv);
+    const float* n1p = n1p_in;
+    if (!n1p) {
+        RUN(act_layernorm_fwd_f32(prm, nullptr, w->norm1_w, w->norm1_b, nullptr, sv.n1p, keep ? sv.meanp : nullptr, keep ? sv.rstdp : nullptr,
+                                 d->B * P, d->D, d->eps, s));
+        n1p = sv.n1p;
+    }
+    return prefix_block_core(*d, P, *w, x, pos, n1p, keep, sv, out, ws, wsb, s);
+}
+
+int act_prefix_block_bwd_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const float* prm, const float* saved,
+                             const float* dout, float* dx, float* dprm, float* scratch, float* ws, size_t wsb, act_stream_t stream) {
+    if (!w || !prm || !saved || !dout || !dx || !dprm || !scratch) return ACT_E_NULLPTR;
+    if (bad_dims(d) || P <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = d->B, G = d->S, D = d->D, H = d->heads, hd = D / H, Hd = d->hidden, TG = B * G, TP = B * P;
+    PrefixSaved sv; carve_prefix(const_cast<float*>(saved), *d, P, sv);
+    PrefixBwdScratch sc; carve_prefix_bwd(scratch, *d, P, sc);
+    act_gemm_epilogue_t e = epi0(); e.act = ACT_EPI_MUL_GELU_GRAD; e.aux = sv.hpre; e.ldaux = Hd;
+    CK(gemm_nn(TG, Hd, D, dout, D, w->fc2_w, Hd, sc.dh, Hd, e, ws, wsb, s));
+    CK(gemm_nn(TG, D, Hd, sc.dh, Hd, w->fc1_w, D, sc.dn2, D, epi0(), ws, wsb, s));
+    RUN(act_layernorm_bwd_f32(sc.dn2, sv.x1, w->norm2_w, sv.mean2, sv.rstd2, dout, sc.dx1, nullptr, nullptr, 0, nullptr, 0, TG, D, s));
+    CK(gemm_nn(TG, D, D, sc.dx1, D, w->proj_w, D, sc.datt, D, epi0(), ws, wsb, s));
+    RUN(act_attention_bwd_prefix_f32(sv.kvp, P, sv.qkvx, G, sv.att, sc.datt, sv.lse, sc.dkvp, sc.dqkvx, B, H, hd, attn_scale(hd), s));
+    CK(gemm_nn(TG, D, 3 * D, sc.dqkvx, 3 * D, w->qkv_w, D, sc.dn1x, D, epi0(), ws, wsb, s));
+    RUN(act_layernorm_bwd_f32(sc.dn1x, sv.xin, w->norm1_w, sv.mean1, sv.rstd1, sc.dx1, dx, nullptr, nullptr, 0, nullptr, 0, TG, D, s));
+    CK(gemm_nn(TP, D, 2 * D, sc.dkvp, 2 * D, w->qkv_w + (size_t)D * D, D, sc.dn1p, D, epi0(), ws, wsb, s));
+    RUN(act_layernorm_bwd_f32(sc.dn1p, prm, w->norm1_w, sv.meanp, sv.rstdp, nullptr, dprm, nullptr, nullptr, 0, nullptr, 0, TP, D, s));
+    return 0;
+}
+
+// ============================================================================================== frozen prompt-tuned Transformer (teacher)
+static size_t carve_vit(float* base, const act_prefix_vit_t& m, float*& pos_h, float*& pos, float*& xa, float*& xb, float*& n1p, float*& blk,
+                        float*& feat) {
+    const size_t TG = (size_t)m.B * m.G, TP = (size_t)m.B * m.P, D = m.D;
+    act_block_dims_t d{m.B, m.G, m.D, m.heads, m.hidden, m.eps};
+    PrefixSaved sv;
+    Carver c(base);
+    pos_h = c.take(TG * m.pos_hidden); pos = c.take(TG * D); xa = c.take(TG * D); xb = c.take(TG * D); n1p = c.take(TP * D); feat = c.take(TG * D);
+    blk = c.take(carve_prefix(nullptr, d, m.P, sv));
+    return c.used;
+}
+static bool bad_vit(const act_prefix_vit_t* m) {
+    return !m || m->B <= 0 || m->P <= 0 || m->G <= 0 || m->D <= 0 || m->heads <= 0 || m->D % m->heads || m->hidden <= 0 || m->depth <= 0 ||
+           m->tokens_dims <= 0 || m->pos_hidden <= 0;
+}
+size_t act_prefix_vit_scratch_floats(const act_prefix_vit_t* m) {
+    if (bad_vit(m)) return 0;
+    float *a, *b, *c, *d, *e, *f, *g;
+    return carve_vit(nullptr, *m, a, b, c, d, e, f, g);
+}
+
+int act_prefix_vit_fwd_f32(const act_prefix_vit_t* m, const float* tokens, const float* center, float* out, float* scratch, float* ws,
+                           size_t wsb, act_stream_t stream) {
+    if (bad_vit(m)) return ACT_E_BADARG;
+    if (!tokens || !center || !out || !scratch || !m->blocks || !m->prompt_tok || !m->prompt_pos) return ACT_E_NULLPTR;
+    hipStream_t s = (hipStream_t)stream;
+    const int TG = m->B * m->G, D = m->D;
+    float *pos_h, *pos, *xa, *xb, *n1p, *blk, *feat;
+    carve_vit(scratch, *m, pos_h, pos, xa, xb, n1p, blk, feat);
+    const act_block_dims_t d{m->B, m->G, m->D, m->heads, m->hidden, m->eps};
+    PrefixSaved sv; carve_prefix(blk, d, m->P, sv);
+    // pos = visual_pos_embed(center): Linear(3, pos_hidden) - GELU - Linear(pos_hidden, D)   (models/dvae.py:413-417)
+    act_gemm_epilogue_t e = epi0(); e.bias = m->pos_b0; e.act = ACT_EPI_GELU;
+    CK(gemm_nt(TG, m->pos_hidden, 3, center, 3, m->pos_w0, 3, pos_h, m->pos_hidden, e, ws, wsb, s));
+    e = epi0(); e.bias = m->pos_b1;
+    CK(gemm_nt(TG, D, m->pos_hidden, pos_h, m->pos_hidden, m->pos_w1, m->pos_hidden, pos, D, e, ws, wsb, s));
+    e = epi0(); e.bias = m->pre_b;
+    CK(gemm_nt(TG, D, m->tokens_dims, tokens, m->tokens_dims, m->pre_w, m->tokens_dims, xa, D, e, ws, wsb, s));
+    float* cur = xa; float* nxt = xb;
+    for (int i = 0; i < m->depth; ++i) {
+        const act_block_params_t& w = m->blocks[i];
+        const uint64_t seed = (m->seed_base + 7919ull * (uint64_t)(i + 1)) & ((1ull << 62) - 1);
+        RUN(act_prompt_layernorm_fwd_f32(m->prompt_tok[i], m->prompt_pos[i], m->B, m->P, D, m->drop_p, seed, m->seed_dev, w.norm1_w, w.norm1_b,
+                                        m->eps, n1p, s));
+        CK(prefix_block_core(d, m->P, w, cur, pos, n1p, false, sv, nxt, ws, wsb, s));
+        float* t = cur; cur = nxt; nxt = t;
+    }
+    RUN(act_layernorm_fwd_f32(cur, nullptr, m->norm_w, m->norm_b, nullptr, feat, nullptr, nullptr, TG, D, m->eps, s));
+    e = epi0(); e.bias = m->post_b;
+    CK(gemm_nt(TG, m->tokens_dims, D, feat, D, m->post_w, D, out, m->tokens_dims, e, ws, wsb, s));
+    return 0;
+}
+
+// ============================================================================================== mini-PointNet (Encoder)
+namespace {
+struct PnSaved { float *h1, *a1, *h2, *fg, *gw, *h3, *a3, *h4, *st1, *st2; int32_t *arg1, *arg2; };   // st* = mean | rstd | scale | shift
+size_t carve_pn(float* base, const act_pointnet_dims_t& d, PnSaved& sv) {
+    const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
+    Carver c(base);
+    sv.h1 = c.take(R * 128); sv.a1 = c.take(R * 128); sv.h2 = c.take(R * 256); sv.fg = c.take(BG * 256); sv.gw = c.take(BG * 512);
+    sv.h3 = c.take(R * 512); sv.a3 = c.take(R * 512); sv.h4 = c.take(R * C); sv.st1 = c.take(4 * 128); sv.st2 = c.take(4 * 512);
+    sv.arg1 = reinterpret_cast<int32_t*>(c.take(BG * 256)); sv.arg2 = reinterpret_cast<int32_t*>(c.take(BG * C));
+    return c.used;
+}
+struct PnBwdScratch { float *dh4, *da3, *dh3, *dgw, *dh2, *dfg, *da1, *dh1; };
+size_t carve_pn_bwd(float* base, const act_pointnet_dims_t& d, PnBwdScratch& sc) {
+    const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
+    Carver c(base);
+    sc.dh4 = c.take(R * C); sc.da3 = c.take(R * 512); sc.dh3 = c.take(R * 512); sc.dgw = c.take(BG * 512); sc.dh2 = c.take(R * 256);
+    sc.dfg = c.take(BG * 256); sc.da1 = c.take(R * 128); sc.dh1 = c.take(R * 128);
+    return c.used;
+}
+bool bad_pn(const act_pointnet_dims_t* d) { return !d || d->BG <= 0 || d->n <= 0 || d->C <= 0 || (d->C & 3); }
+}  // namespace
+
+size_t act_pointnet_saved_floats(const act_pointnet_dims_t* d) { if (bad_pn(d)) return 0; PnSaved sv; return carve_pn(nullptr, *d, sv); }
+size_t act_pointnet_bwd_scratch_floats(const act_pointnet_dims_t* d) { if (bad_pn(d)) return 0; PnBwdScratch sc; return carve_pn_bwd(nullptr, *d, sc); }
+
+int act_pointnet_fwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, int training, int keep_for_backward,
+                         float* saved, float* out, float* ws, size_t wsb, act_stream_t stream) {
+    if (!w || !x || !saved || !out) return ACT_E_NULLPTR;
+    if (bad_pn(d)) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int BG = d->BG, n = d->n, C = d->C, R = BG * n;
+    PnSaved sv; carve_pn(saved, *d, sv);
+    auto bn = [&](const float* h, int Cc, const float* gw_, const float* gb_, float* rm, float* rv, float eps, float mom, float* st, float* a) -> int {
+        float *mean = st, *rstd = st + Cc, *scale = st + 2 * Cc, *shift = st + 3 * Cc;
+        if (training) {
+            if (wsb < act_colstats_workspace(R, Cc)) return ACT_E_BADARG;
+            RUN(act_bn_stats_f32(h, R, Cc, gw_, gb_, eps, mom, rm, rv, mean, rstd, scale, shift, ws, wsb, s));
+        } else {
+            RUN(act_bn_eval_affine_f32(gw_, gb_, rm, rv, eps, Cc, scale, shift, s));
+        }
+        RUN(act_affine_act_f32(h, scale, shift, 1, R, Cc, a, s));
+        return 0;
+    };
+    act_gemm_epilogue_t e = epi0(); e.bias = w->c1_b;
+    CK(gemm_nt(R, 128, 3, x, 3, w->c1_w, 3, sv.h1, 128, e, ws, wsb, s));
+    CK(bn(sv.h1, 128, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, d->eps1, d->momentum1, sv.st1, sv.a1));
+    e = epi0(); e.bias = w->c2_b;
+    CK(gemm_nt(R, 256, 128, sv.a1, 128, w->c2_w, 128, sv.h2, 256, e, ws, wsb, s));
+    RUN(act_group_max_f32(sv.h2, BG, n, 256, sv.fg, sv.arg1, s));
+    // conv 512->512 on cat(global, local): the global half once per group, broadcast-added in the epilogue of the local half
+    e = epi0(); e.bias = w->c3_b;
+    CK(gemm_nt(BG, 512, 256, sv.fg, 256, w->c3_w, 512, sv.gw, 512, e, ws, wsb, s));
+    e = epi0(); e.res = sv.gw; e.ldr = 512; e.res_row_div = n;
+    CK(gemm_nt(R, 512, 256, sv.h2, 256, w->c3_w + 256, 512, sv.h3, 512, e, ws, wsb, s));
+    CK(bn(sv.h3, 512, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, d->eps2, d->momentum2, sv.st2, sv.a3));
+    e = epi0(); e.bias = w->c4_b;
+    CK(gemm_nt(R, C, 512, sv.a3, 512, w->c4_w, 512, sv.h4, C, e, ws, wsb, s));
+    RUN(act_group_max_f32(sv.h4, BG, n, C, out, keep_for_backward ? sv.arg2 : nullptr, s));
+    return 0;
+}
+
+int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, const float* saved, const float* dout,
+                         const act_pointnet_grads_t* g, float* scratch, float* ws, size_t wsb, act_stream_t stream) {
+    if (!w || !x || !saved || !dout || !g || !scratch) return ACT_E_NULLPTR;
+    if (bad_pn(d)) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int BG = d->BG, n = d->n, C = d->C, R = BG * n;
+    PnSaved sv; carve_pn(const_cast<float*>(saved), *d, sv);
+    PnBwdScratch sc; carve_pn_bwd(scratch, *d, sc);
+    auto st = [](float* base, int Cc, int which) { return base + which * Cc; };               // 0 mean, 1 rstd, 2 scale, 3 shift
+    RUN(act_group_max_bwd_f32(dout, sv.arg2, BG, n, C, 0, sc.dh4, s));
+    CK(gemm_tn(C, 512, R, sc.dh4, C, sv.a3, 512, g->c4_w, 512, ws, wsb, s));
+    CK(colsum(sc.dh4, R, C, g->c4_b, ws, wsb, s));
+    CK(gemm_nn(R, 512, C, sc.dh4, C, w->c4_w, 512, sc.da3, 512, epi0(), ws, wsb, s));
+    RUN(act_bn_bwd_f32(sv.h3, sc.da3, st(sv.st2, 512, 2), st(sv.st2, 512, 3), st(sv.st2, 512, 0), st(sv.st2, 512, 1), 1, R, 512, sc.dh3, g->bn2_w, g->bn2_b,
+                      ws, wsb, s));
+    // the two column halves of dW3 [512, 512]: [:, :256] from the per-group path, [:, 256:] from the per-point path
+    CK(gemm_tn(512, 256, R, sc.dh3, 512, sv.h2, 256, g->c3_w + 256, 512, ws, wsb, s));
+    RUN(act_group_sum_f32(sc.dh3, BG, n, 512, sc.dgw, s));
+    CK(gemm_nn(R, 256, 512, sc.dh3, 512, w->c3_w + 256, 512, sc.dh2, 256, epi0(), ws, wsb, s));
+    CK(gemm_tn(512, 256, BG, sc.dgw, 512, sv.fg, 256, g->c3_w, 512, ws, wsb, s));
+    CK(colsum(sc.dgw, BG, 512, g->c3_b, ws, wsb, s));
+    CK(gemm_nn(BG, 256, 512, sc.dgw, 512, w->c3_w, 512, sc.dfg, 256, epi0(), ws, wsb, s));
+    RUN(act_group_max_bwd_f32(sc.dfg, sv.arg1, BG, n, 256, 1, sc.dh2, s));
+    CK(gemm_tn(256, 128, R, sc.dh2, 256, sv.a1, 128, g->c2_w, 128, ws, wsb, s));
+    CK(colsum(sc.dh2, R, 256, g->c2_b, ws, wsb, s));
+    CK(gemm_nn(R, 128, 256, sc.dh2, 256, w->c2_w, 128, sc.da1, 128, epi0(), ws, wsb, s));
+    RUN(act_bn_bwd_f32(sv.h1, sc.da1, st(sv.st1, 128, 2), st(sv.st1, 128, 3), st(sv.st1, 128, 0), st(sv.st1, 128, 1), 1, R, 128, sc.dh1, g->bn1_w, g->bn1_b,
+                      ws, wsb, s));
+    CK(gemm_tn(128, 3, R, sc.dh1, 128, x, 3, g->c1_w, 3, ws, wsb, s));
+    CK(colsum(sc.dh1, R, 128, g->c1_b, ws, wsb, s));
+    return 0;
+}
+
+// ============================================================================================== DGCNN (inference form)
+static const int kDgcnnCin[4] = {128, 256, 512, 512}, kDgcnnCout[4] = {256, 512, 512, 1024};
+static size_t carve_dgcnn(float* base, const act_dgcnn_t& m, float*& x0, float*& yz, float*& cat, float*& stats) {
+    const size_t T = (size_t)m.B * m.G;
+    Carver c(base);
+    x0 = c.take(T * 128); yz = c.take(T * 2048); cat = c.take(T * 2304); stats = c.take((size_t)18 * m.B * m.groups);
+    return c.used;
+}
+size_t act_dgcnn_scratch_floats(const act_dgcnn_t* m) {
+    if (!m || m->B <= 0 || m->G <= 0 || m->groups <= 0) return 0;
+    float *a, *b, *c, *d; return carve_dgcnn(nullptr, *m, a, b, c, d);
+}
+int act_dgcnn_features_f32(const act_dgcnn_t* m, const float* f, const int64_t* idx, float* h, float* scratch, float* ws, size_t wsb,
+                           act_stream_t stream) {
+    if (!m || !f || !idx || !h || !scratch) return ACT_E_NULLPTR;
+    if (m->B <= 0 || m->G <= 0 || m->k <= 0 || m->Cin <= 0 || m->Cout <= 0 || m->groups <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = m->B * m->G;
+    float *x0, *yz, *cat, *stats;
+    carve_dgcnn(scratch, *m, x0, yz, cat, stats);
+    act_gemm_epilogue_t e = epi0(); e.bias = m->b_in;
+    CK(gemm_nt(T, 128, m->Cin, f, m->Cin, m->w_in, m->Cin, x0, 128, e, ws, wsb, s));
+    const float* xin = x0; int ldx = 128, off = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int cin = kDgcnnCin[l], cout = kDgcnnCout[l];
+        // W.cat(x_j - x_i, x_i) = Wa x_j + (Wb - Wa) x_i: one GEMM over the B*G points -> [Y | Z], then gather + GroupNorm + LeakyReLU + max_k
+        CK(gemm_nt(T, 2 * cout, cin, xin, ldx, m->stacked[l], cin, yz, 2 * cout, epi0(), ws, wsb, s));
+        RUN(act_edge_gn_lrelu_max_f32(yz, 2 * cout, cout, idx, m->B, m->G, m->k, cout, m->groups, m->gn_w[l], m->gn_b[l], m->eps, m->slope, stats,
+                                     cat, 2304, off, s));
+        xin = cat + off; ldx = 2304; off += cout;
+    }
+    CK(gemm_nt(T, m->Cout, 2304, cat, 2304, m->w5, 2304, h, m->Cout, epi0(), ws, wsb, s));
+    return 0;
+}
+
+}  // extern "C"

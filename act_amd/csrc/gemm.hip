@@ -315,6 +315,34 @@ static void launch_variant(const GemmParams& p, int ak, int bk, bool vec, bool f
 #undef L
 }
 
+// ---- launch-configuration table: (a_kmajor, b_kmajor, M, N, K) -> (tile id, split-K), filled by the host-side autotuner ----------
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct TuneKey { int ak, bk, M, N, K; bool operator==(const TuneKey& o) const { return ak == o.ak && bk == o.bk && M == o.M && N == o.N && K == o.K; } };
+struct TuneHash { size_t operator()(const TuneKey& k) const {
+    uint64_t h = 1469598103934665603ull;
+    for (int v : {k.ak, k.bk, k.M, k.N, k.K}) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
+    return (size_t)h; } };
+std::mutex g_tune_mu;
+std::unordered_map<TuneKey, std::pair<int, int>, TuneHash> g_tune;
+}  // namespace
+extern "C" int act_gemm_tune_set(int ak, int bk, int M, int N, int K, int tile, int splits) {
+    if (tile < 0 || tile > 12 || splits < 0) return ACT_E_BADARG;
+    std::lock_guard<std::mutex> g(g_tune_mu);
+    g_tune[TuneKey{ak != 0, bk != 0, M, N, K}] = {tile, splits};
+    return 0;
+}
+extern "C" int act_gemm_tune_get(int ak, int bk, int M, int N, int K, int* tile, int* splits) {
+    std::lock_guard<std::mutex> g(g_tune_mu);
+    auto it = g_tune.find(TuneKey{ak != 0, bk != 0, M, N, K});
+    if (it == g_tune.end()) return 1;
+    if (tile) *tile = it->second.first;
+    if (splits) *splits = it->second.second;
+    return 0;
+}
+extern "C" int act_gemm_tune_clear(void) { std::lock_guard<std::mutex> g(g_tune_mu); g_tune.clear(); return 0; }
+
 static int g_gemm_bk = 0;      // 0 = not read yet; ACT_GEMM_BK={16,32} selects the K-tile depth (tuning knob)
 static int gemm_bk() {
     if (!g_gemm_bk) { const char* e = getenv("ACT_GEMM_BK"); g_gemm_bk = (e && atoi(e) == 32) ? 32 : GEMM_BK_DEFAULT; }
@@ -432,5 +460,7 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
 extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                              float* C, int ldc, const act_gemm_epilogue_t* epi_in, float* workspace, size_t workspace_bytes,
                              act_stream_t stream) {
-    return act_sgemm_ex_f32(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epi_in, workspace, workspace_bytes, 0, 0, stream);
+    int tile = 0, splits = 0;
+    if (act_gemm_tune_get(a_kmajor, b_kmajor, M, N, K, &tile, &splits) != 0) { tile = 0; splits = 0; }
+    return act_sgemm_ex_f32(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epi_in, workspace, workspace_bytes, tile, splits, stream);
 }

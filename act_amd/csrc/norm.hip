@@ -504,3 +504,26 @@ extern "C" int act_cosine_loss_bwd_f32(const float* student, const float* teache
                        1.0f / (float)R, grad_student);
     ACT_LAUNCH_CHECK(); return 0;
 }
+
+// y[r,:] = x[r,:] * gate[r / rows_per_scale]   (DropPath gate on a gradient; float4 stream)
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ x, const float* __restrict__ gate, long long total4, int D4,
+                                                         int rows_per_scale, float* __restrict__ y) {
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    float4* __restrict__ y4 = reinterpret_cast<float4*>(y);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const float g = gate[(i / D4) / rows_per_scale];
+        float4 v = x4[i];
+        v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+        y4[i] = v;
+    }
+}
+extern "C" int act_scale_rows_f32(const float* x, const float* gate, int T, int D, int rows_per_scale, float* y, act_stream_t stream) {
+    if (!x || !gate || !y) return ACT_E_NULLPTR;
+    if (T < 0 || D <= 0 || (D & 3) || rows_per_scale <= 0) return ACT_E_BADARG;
+    const long long total4 = (long long)T * D / 4; if (total4 == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_ELTWISE, s, 0.0, 8.0 * T * (double)D);
+    long long g = (total4 + 255) / 256; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)g), dim3(256), 0, s, x, gate, total4, D / 4, rows_per_scale, y);
+    ACT_LAUNCH_CHECK(); return 0;
+}

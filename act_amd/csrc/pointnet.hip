@@ -251,3 +251,20 @@ extern "C" int act_group_sum_f32(const float* in, int G, int n, int C, float* ou
     hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, in, n, C, total, out);
     ACT_LAUNCH_CHECK(); return 0;
 }
+
+// eval-mode BatchNorm as an affine map (nn.BatchNorm1d.eval(): running statistics)
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                      const float* __restrict__ rv, float eps, int C, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(rv[c] + eps);
+    scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
+}
+extern "C" int act_bn_eval_affine_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                                      int C, float* scale, float* shift, act_stream_t stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return ACT_E_NULLPTR;
+    if (C <= 0) return ACT_E_BADARG;
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var, eps, C,
+                       scale, shift);
+    ACT_LAUNCH_CHECK(); return 0;
+}

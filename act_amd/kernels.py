@@ -235,6 +235,7 @@ def _gemm_config(a, b, ak, bk, M, N, K, ws):
     best, _ = gemm_tune(a, b, ak, bk, M, N, K, ws)
     _GEMM_CACHE[key] = best
     _NEW_TUNED[key[:5]] = best
+    lib.act_gemm_tune_set(int(ak), int(bk), M, N, K, int(best[0]), int(best[1]))      # the composite entry points launch the same configuration
     return best
 
 
@@ -368,8 +369,10 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
-class BlockFn(torch.autograd.Function):
-    """One pre-LN Transformer block applied to (x + pos)  -- models/act.py:72-90 called as blk(x + pos) (:109-112).
+class BlockFnPerKernel(torch.autograd.Function):
+    """One pre-LN Transformer block applied to (x + pos)  -- models/act.py:72-90 called as blk(x + pos) (:109-112), issued from the
+    host one kernel at a time.  The product path is composite.BlockFn (one host call per direction, same kernels, bit-identical
+    results); this form stays for ACT_COMPOSITE=0 A/B measurements and the bit-identity test.
 
     forward : xin = x+pos ; x1 = xin + g1*(proj(attn(LN1(xin)))+b) ; x2 = x1 + g2*(fc2(gelu(fc1(LN2(x1))))+b)
     g1/g2 are the per-sample DropPath gates (floor(keep+U)/keep) or None.  7 launches forward.
@@ -834,7 +837,7 @@ def attention_bwd_prefix(kv0, S0, qkv1, Sq, out, dout, lse, B, H, hd):
     return dkv0, dqkv1
 
 
-class PrefixBlockFn(torch.autograd.Function):
+class PrefixBlockFnPerKernel(torch.autograd.Function):
     """Pre-LN block on G patch tokens per cloud with P prompt tokens acting as keys/values only, WITH backward to the patch
     tokens, their positions and the prompts (Stage-I prompt tuning of the frozen Transformer, models/dvae.py:536-576: every
     layer replaces the prompt rows of its input and the output drops them, so prompt rows never need queries / proj / MLP).
@@ -890,7 +893,7 @@ def prompt_layernorm(tok, ppos, B, drop_p, seed, gamma, beta, eps, seed_dev=None
     return y
 
 
-def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, n1p=None):
+def block_forward_prefix_perkernel(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2, heads, eps, n1p=None):
     """Inference-only pre-LN block on G 'patch' tokens per cloud with P extra 'prompt' tokens that act as keys/values only
     (their outputs are discarded by the caller): x2d [B*G, D] (+ pos2d), prm2d [B*P, D] = prompt + prompt_pos (or n1p = its
     LayerNorm, already computed by prompt_layernorm).
@@ -907,3 +910,14 @@ def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj
     n2, _, _, _ = layernorm_fwd(x1, None, n2w, n2b, eps, want_stats=False)
     a = gemm(n2, w1, True, True, bias=b1, act=EPI_GELU)
     return gemm(a, w2, True, True, bias=b2, res=x1)
+
+
+# ---- the product forms of the block-level Functions live in act_amd.composite (one host call per module); resolved lazily so that
+# either module may be imported first.  ACT_COMPOSITE=0 selects the per-kernel host path above.
+def __getattr__(name):
+    if name in ("BlockFn", "PrefixBlockFn", "block_forward_prefix"):
+        from . import composite
+        if composite.ENABLED:
+            return getattr(composite, name)
+        return {"BlockFn": BlockFnPerKernel, "PrefixBlockFn": PrefixBlockFnPerKernel, "block_forward_prefix": block_forward_prefix_perkernel}[name]
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -10,6 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import kernels as K
+from .. import composite as CP
 from ..knn_cuda import KNN, knn_group
 from ..pointnet2_ops import pointnet2_utils
 from ..extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2
@@ -62,6 +63,8 @@ class Encoder(nn.Module):
                                          nn.Conv1d(512, self.encoder_channel, 1))
 
     def forward(self, point_groups):
+        if CP.ENABLED and not any(isinstance(m, nn.SyncBatchNorm) for m in (self.first_conv[1], self.second_conv[1])):
+            return CP.pointnet_forward(self, point_groups)              # one host call per direction (csrc/composite.hip)
         bs, g, n, _ = point_groups.shape
         x = point_groups.reshape(bs * g * n, 3)
         c1, bn1, _, c2 = self.first_conv
@@ -132,11 +135,14 @@ class DGCNN(nn.Module):
 
     def features(self, f, coor, idx=None):
         """everything up to (not including) layer5's GroupNorm: -> pre-norm head output rows [B*G, C']"""
-        B, G, C = f.shape
+        B, G, Cin = f.shape
         if idx is None:
             with torch.no_grad():
                 idx = self.graph_index(coor)
-        x = K.linear(f.reshape(B * G, C), _w2d(self.input_trans), self.input_trans.bias)
+        if CP.ENABLED and not torch.is_grad_enabled():                     # frozen teacher: the whole stack in one host call
+            stacked = [self._stacked_weight(l[0]) for l in (self.layer1, self.layer2, self.layer3, self.layer4)]
+            return CP.dgcnn_features(self, f, idx, stacked)
+        x = K.linear(f.reshape(B * G, Cin), _w2d(self.input_trans), self.input_trans.bias)
         fused = not torch.is_grad_enabled()
         cat = torch.empty(B * G, 2304, dtype=torch.float32, device=f.device) if fused else None
         feats, off = [], 0
@@ -339,13 +345,15 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         queries, projection and MLP are evaluated for the G patch tokens only (58 % of the FLOPs, identical outputs)."""
         B, G, _ = input.shape
         Pn, D = self.num_prompt_token, self.visual_embed_dim
+        drop_p = self.prompt_dropout.p if self.training else 0.0
+        fused = draws is None or not (draws.record or any(draws.has(f"prompt.{i}") for i in range(self.visual_embed_depth)))
+        base, ctr = rng if rng is not None else self._rng(input.device)
+        if fused and CP.ENABLED:                                         # the whole 12-layer stack in one host call (~125 launches)
+            return CP.prefix_vit_forward(self, input, center, drop_p, base, ctr)
         vp = self.visual_pos_embed
         pos = K.mlp(center, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias).reshape(B * G, D)
         x = K.linear(input, self.proj_pre.weight, self.proj_pre.bias).reshape(B * G, D)
         blocks = self.visual_embed[0]
-        drop_p = self.prompt_dropout.p if self.training else 0.0
-        fused = draws is None or not (draws.record or any(draws.has(f"prompt.{i}") for i in range(self.visual_embed_depth)))
-        base, ctr = rng if rng is not None else self._rng(input.device)
         for i in range(self.visual_embed_depth):
             tok = self.visual_prompt_token[0] if i == 0 else self.deep_prompt_tokens[i - 1]
             ppos = self.visual_prompt_pos[0] if i == 0 else self.deep_prompt_pos[i - 1]

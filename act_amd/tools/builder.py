@@ -12,19 +12,16 @@ from ..utils.misc import worker_init_fn
 
 
 def dataset_builder(args, config):
+    """(sampler, DataLoader) of one dataset section of the YAML (tools/builder.py:14-33): the train subset is shuffled and drops its
+    ragged last batch; under DDP every rank gets a DistributedSampler shard.  Host batches are pinned so the H2D copy of the next
+    batch overlaps the current step."""
     dataset = build_dataset_from_cfg(config._base_, config.others)
-    shuffle = config.others.subset == 'train'
-    if args.distributed:
-        sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=shuffle)
-        dataloader = torch.utils.data.DataLoader(dataset, batch_size=config.others.bs, num_workers=int(args.num_workers),
-                                                 drop_last=config.others.subset == 'train', worker_init_fn=worker_init_fn,
-                                                 sampler=sampler, pin_memory=True)
-    else:
-        sampler = None
-        dataloader = torch.utils.data.DataLoader(dataset, batch_size=config.others.bs, shuffle=shuffle,
-                                                 drop_last=config.others.subset == 'train', num_workers=int(args.num_workers),
-                                                 worker_init_fn=worker_init_fn, pin_memory=True)
-    return sampler, dataloader
+    is_train = config.others.subset == 'train'
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, shuffle=is_train) if args.distributed else None
+    loader = torch.utils.data.DataLoader(
+        dataset, batch_size=config.others.bs, sampler=sampler, shuffle=(is_train and sampler is None), drop_last=is_train,
+        num_workers=int(args.num_workers), worker_init_fn=worker_init_fn, pin_memory=True)
+    return sampler, loader
 
 
 def model_builder(config):
@@ -108,57 +105,83 @@ def build_opti_sche(base_model, config):
     return optimizer, scheduler
 
 
-def _strip(sd):
-    return {k.replace("module.", ""): v for k, v in sd.items()}
+# ---- checkpoints: the reference's container {'base_model', 'optimizer', 'epoch', 'metrics', 'best_metrics'} (tools/builder.py:138-144),
+# keys optionally prefixed with 'module.' when the file was written from a DDP / DataParallel wrapper ---------------------------------
+_LAST = 'ckpt-last.pth'
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def _weights(blob, *slots):
+    """state_dict stored under the first present slot, DDP prefixes removed"""
+    for slot in slots:
+        sd = blob.get(slot)
+        if sd is not None:
+            return {k.replace("module.", ""): v for k, v in sd.items()}
+    raise RuntimeError('mismatch of ckpt weight')
+
+
+def _as_dict(metric):
+    return metric if isinstance(metric, dict) else metric.state_dict()
+
+
+def _read_last(args, what, logger):
+    path = os.path.join(args.experiment_path, _LAST)
+    if not os.path.exists(path):
+        print_log(f'[RESUME INFO] no checkpoint file from path {path}...', logger=logger)
+        return None
+    print_log(f'[RESUME INFO] Loading {what} from {path}...', logger=logger)
+    return torch.load(path, map_location='cpu')
 
 
 def resume_model(base_model, args, logger=None):
-    ckpt_path = os.path.join(args.experiment_path, 'ckpt-last.pth')
-    if not os.path.exists(ckpt_path):
-        print_log(f'[RESUME INFO] no checkpoint file from path {ckpt_path}...', logger=logger)
+    """-> (first epoch to run, best metrics dict); (0, 0) when there is nothing to resume (tools/builder.py:97-121)"""
+    blob = _read_last(args, 'model weights', logger)
+    if blob is None:
         return 0, 0
-    print_log(f'[RESUME INFO] Loading model weights from {ckpt_path}...', logger=logger)
-    state_dict = torch.load(ckpt_path, map_location='cpu')
-    base_model.load_state_dict(_strip(state_dict['base_model']), strict=True)
-    start_epoch = state_dict['epoch'] + 1
-    best_metrics = state_dict['best_metrics']
-    if not isinstance(best_metrics, dict):
-        best_metrics = best_metrics.state_dict()
-    print_log(f'[RESUME INFO] resume ckpts @ {start_epoch - 1} epoch( best_metrics = {str(best_metrics):s})', logger=logger)
-    return start_epoch, best_metrics
+    _unwrap(base_model).load_state_dict(_weights(blob, 'base_model'), strict=True)
+    best = _as_dict(blob['best_metrics'])
+    print_log(f"[RESUME INFO] resume ckpts @ {blob['epoch']} epoch( best_metrics = {best})", logger=logger)
+    return blob['epoch'] + 1, best
 
 
 def resume_optimizer(optimizer, args, logger=None):
-    ckpt_path = os.path.join(args.experiment_path, 'ckpt-last.pth')
-    if not os.path.exists(ckpt_path):
-        print_log(f'[RESUME INFO] no checkpoint file from path {ckpt_path}...', logger=logger)
+    """restore the optimizer state of ckpt-last.pth (tools/builder.py:123-132).  A checkpoint written by the reference lists the
+    never-trained lm_head / cls_head parameters in its AdamW groups (they are frozen here, see runner_pretrain.freeze_unused_heads):
+    such a state cannot be mapped onto this optimizer, which then starts from fresh moments -- said loudly, not silently."""
+    blob = _read_last(args, 'optimizer', logger)
+    if blob is None:
         return 0, 0, 0
-    print_log(f'[RESUME INFO] Loading optimizer from {ckpt_path}...', logger=logger)
-    optimizer.load_state_dict(torch.load(ckpt_path, map_location='cpu')['optimizer'])
+    saved = blob['optimizer']
+    have = [len(g['params']) for g in optimizer.param_groups]
+    want = [len(g['params']) for g in saved['param_groups']]
+    if have != want:
+        print_log(f'[RESUME WARNING] optimizer state of the checkpoint has parameter groups of sizes {want}, this run has {have} '
+                  '(frozen unused heads): AdamW moments are NOT restored', logger=logger)
+        return None
+    optimizer.load_state_dict(saved)
 
 
 def save_checkpoint(base_model, optimizer, epoch, metrics, best_metrics, prefix, args, skip=False, logger=None):
     path = os.path.join(args.experiment_path, prefix + '.pth')
     if skip:
         print_log(f"Skipped saving checkpoint at {path}", logger=logger)
-        return
-    if args.local_rank == 0:
-        module = base_model.module if hasattr(base_model, "module") else base_model
-        torch.save({'base_model': module.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch,
-                    'metrics': metrics.state_dict() if metrics is not None else dict(),
-                    'best_metrics': best_metrics.state_dict() if best_metrics is not None else dict()}, path)
+    elif args.local_rank == 0:
+        blob = dict(base_model=_unwrap(base_model).state_dict(), optimizer=optimizer.state_dict(), epoch=epoch,
+                    metrics=_as_dict(metrics) if metrics is not None else {},
+                    best_metrics=_as_dict(best_metrics) if best_metrics is not None else {})
+        torch.save(blob, path)
         print_log(f"Save checkpoint at {path}", logger=logger)
 
 
 def load_model(base_model, ckpt_path, logger=None):
+    """strict load of a released / saved checkpoint ('model' or 'base_model' slot; tools/builder.py:147-173)"""
     if not os.path.exists(ckpt_path):
         raise NotImplementedError('no checkpoint file from path %s...' % ckpt_path)
     print_log(f'Loading weights from {ckpt_path}...', logger=logger)
-    state_dict = torch.load(ckpt_path, map_location='cpu')
-    if state_dict.get('model') is not None:
-        base_ckpt = _strip(state_dict['model'])
-    elif state_dict.get('base_model') is not None:
-        base_ckpt = _strip(state_dict['base_model'])
-    else:
-        raise RuntimeError('mismatch of ckpt weight')
-    base_model.load_state_dict(base_ckpt, strict=True)
+    blob = torch.load(ckpt_path, map_location='cpu')
+    _unwrap(base_model).load_state_dict(_weights(blob, 'model', 'base_model'), strict=True)
+    perf = _as_dict(blob['metrics']) if blob.get('metrics') is not None else 'No Metrics'
+    print_log(f"ckpts @ {blob.get('epoch', -1)} epoch( performance = {perf})", logger=logger)

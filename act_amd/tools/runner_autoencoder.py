@@ -22,7 +22,8 @@ class Metrics:
 
     def __init__(self, name="CDL1", values=None):
         self.name = name
-        self._values = values if isinstance(values, dict) else {"CDL1": float("inf"), "CDL2": float("inf")}
+        # a checkpoint written before the first validation stores an empty dict: that means "no best yet"
+        self._values = dict(values) if isinstance(values, dict) and name in values else {"CDL1": float("inf"), "CDL2": float("inf")}
 
     def better_than(self, other):
         return other is None or self._values[self.name] < other._values[other.name]

@@ -1,40 +1,54 @@
-"""running averages of scalars (reference: utils/AverageMeter.py:2-41)."""
+"""Running statistics of the logged scalars (interface of the reference's utils/AverageMeter.py: ``update`` / ``val`` /
+``count`` / ``avg``; a meter built with a list of names tracks one channel per name and answers with lists)."""
 
 
-class AverageMeter(object):
+class _Channel:
+    __slots__ = ("last", "total", "n")
+
+    def __init__(self):
+        self.last, self.total, self.n = 0, 0, 0
+
+    def push(self, v):
+        self.last = v
+        self.total += v
+        self.n += 1
+
+    @property
+    def mean(self):
+        return self.total / self.n
+
+
+class AverageMeter:
     def __init__(self, items=None):
         self.items = items
-        self.n_items = 1 if items is None else len(items)
         self.reset()
 
+    @property
+    def n_items(self):
+        return len(self._ch)
+
     def reset(self):
-        self._val = [0] * self.n_items
-        self._sum = [0] * self.n_items
-        self._count = [0] * self.n_items
+        self._ch = [_Channel() for _ in (self.items if self.items is not None else (None,))]
 
     def update(self, values):
-        if type(values).__name__ == "list":
-            for idx, v in enumerate(values):
-                self._val[idx] = v
-                self._sum[idx] += v
-                self._count[idx] += 1
+        """a list feeds the channels in order; a bare scalar feeds channel 0"""
+        if isinstance(values, list):
+            for ch, v in zip(self._ch, values):
+                ch.push(v)
         else:
-            self._val[0] = values
-            self._sum[0] += values
-            self._count[0] += 1
+            self._ch[0].push(values)
+
+    def _read(self, attr, idx):
+        if idx is not None:
+            return getattr(self._ch[idx], attr)
+        out = [getattr(ch, attr) for ch in self._ch]
+        return out[0] if self.items is None else out
 
     def val(self, idx=None):
-        if idx is None:
-            return self._val[0] if self.items is None else [self._val[i] for i in range(self.n_items)]
-        return self._val[idx]
+        return self._read("last", idx)
 
     def count(self, idx=None):
-        if idx is None:
-            return self._count[0] if self.items is None else [self._count[i] for i in range(self.n_items)]
-        return self._count[idx]
+        return self._read("n", idx)
 
     def avg(self, idx=None):
-        if idx is None:
-            return self._sum[0] / self._count[0] if self.items is None else \
-                [self._sum[i] / self._count[i] for i in range(self.n_items)]
-        return self._sum[idx] / self._count[idx]
+        return self._read("mean", idx)

@@ -221,6 +221,120 @@ int act_kl_uniform_fwd_f32(const float* logits, int B, int G, int C, float* lse,
 int act_kl_uniform_bwd_f32(const float* logits, const float* lse, const float* qbar, const float* grad_klv, int B, int G, int C,
                            float* dlogits, act_stream_t stream);
 
+/* ---- GEMM launch-configuration table (host side) ------------------------------------------------------------------------
+ * act_sgemm_f32 (no explicit configuration) first consults this table keyed by (a_kmajor, b_kmajor, M, N, K), then its built-in
+ * cost model.  The Python host fills it from the shipped tune file and from first-use timing (act_amd/kernels.py); the composite
+ * entry points below therefore launch exactly the configurations the single-GEMM path uses. */
+int act_gemm_tune_set(int a_kmajor, int b_kmajor, int M, int N, int K, int tile, int splits);
+int act_gemm_tune_get(int a_kmajor, int b_kmajor, int M, int N, int K, int* tile, int* splits);   /* 0 = found, 1 = absent */
+int act_gemm_tune_clear(void);
+
+/* x[r,:] * gate[r / rows_per_scale] -> y   (DropPath gate applied to a gradient, utils/transformer_layers.py:105-120) */
+int act_scale_rows_f32(const float* x, const float* gate, int T, int D, int rows_per_scale, float* y, act_stream_t stream);
+/* eval-mode BatchNorm folded to an affine map: scale = gamma * rsqrt(running_var + eps), shift = beta - running_mean * scale */
+int act_bn_eval_affine_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                           int C, float* scale, float* shift, act_stream_t stream);
+
+/* ---- composite entry points: one host call enqueues every kernel of a module -------------------------------------------
+ * A Stage-II step is ~500 kernel launches; issued one ctypes call at a time the host needs ~16 ms per step, which is what
+ * bounds an 8-rank node sharing one host.  These functions run the launch sequence of a whole module in C: same kernels, same
+ * order, same results (bit-identical to calling the single-kernel entry points above one by one).  All buffers are caller-owned;
+ * `saved` / `scratch` are single slabs whose sizes the *_floats helpers return; nothing is allocated, nothing synchronises.
+ * `side_stream` (nullable): weight-gradient GEMMs and bias column sums are enqueued there (forked after the producing kernel on
+ * `stream`, joined back before the function returns) so they share the chip with the latency-bound dX chain. */
+/* GEMM-shape collection (host-side autotuning of composites): between begin and end, on the same host thread, the composite
+ * entry points launch nothing and record the (a_kmajor, b_kmajor, M, N, K) of each GEMM they would launch.
+ * end -> number recorded (the first `max` written to shapes [max][5]). */
+int act_composite_collect_begin(void);
+int act_composite_collect_end(int* shapes, int max);
+
+typedef struct {                     /* parameters of one pre-LN Transformer block (models/act.py:72-90; timm ViT block) */
+    const float *norm1_w, *norm1_b, *qkv_w, *qkv_b /* nullable */, *proj_w, *proj_b, *norm2_w, *norm2_b,
+                *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} act_block_params_t;
+typedef struct {                     /* where the gradients go; NULL struct pointer = frozen block (dX only) */
+    float *norm1_w, *norm1_b, *qkv_w, *qkv_b /* nullable */, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} act_block_grads_t;
+typedef struct { int B, S, D, heads, hidden; float eps; } act_block_dims_t;
+
+/* forward of blk(x + pos) (models/act.py:87-90 called as :109-112): 7 launches.  x, pos (nullable), out: [B*S, D];
+ * gate1 / gate2 (nullable) [B] = DropPath floor(keep+U)/keep of the two residual branches; keep_for_backward = 0 skips the
+ * statistics / pre-activation stores.  saved: act_block_saved_floats(dims) floats (activations kept for the backward). */
+size_t act_block_saved_floats(const act_block_dims_t* d);
+int act_block_fwd_f32(const act_block_dims_t* d, const act_block_params_t* w, const float* x, const float* pos,
+                      const float* gate1, const float* gate2, int keep_for_backward, float* saved, float* out,
+                      float* workspace, size_t workspace_bytes, act_stream_t stream);
+/* backward: dout [B*S, D] -> dx [B*S, D] (gradient of x and of pos) + parameter gradients.  scratch: act_block_bwd_scratch_floats. */
+size_t act_block_bwd_scratch_floats(const act_block_dims_t* d);
+int act_block_bwd_f32(const act_block_dims_t* d, const act_block_params_t* w, const float* gate1, const float* gate2,
+                      const float* saved, const float* dout, float* dx, const act_block_grads_t* grads, float* scratch,
+                      float* workspace, size_t workspace_bytes, float* side_workspace, size_t side_workspace_bytes,
+                      act_stream_t stream, act_stream_t side_stream);
+
+/* Block on G patch tokens per cloud with P prompt tokens acting as keys / values only (prompt-tuned frozen Transformer,
+ * models/dvae.py:536-576: every layer replaces the prompt rows of its input and the output drops them).  dims: S = G.
+ * x, pos [B*G, D]; prompt rows either prm [B*P, D] (= dropout(prompt) + prompt_pos, differentiable path) or n1p [B*P, D]
+ * (their LayerNorm, already computed by act_prompt_layernorm_fwd_f32).  Weights are frozen: the backward produces dx (= dpos) and
+ * dprm only.  saved: act_prefix_block_saved_floats; scratch: act_prefix_block_bwd_scratch_floats. */
+size_t act_prefix_block_saved_floats(const act_block_dims_t* d, int P);
+int act_prefix_block_fwd_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const float* x, const float* pos,
+                             const float* prm, const float* n1p, int keep_for_backward, float* saved, float* out,
+                             float* workspace, size_t workspace_bytes, act_stream_t stream);
+size_t act_prefix_block_bwd_scratch_floats(const act_block_dims_t* d, int P);
+int act_prefix_block_bwd_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const float* prm, const float* saved,
+                             const float* dout, float* dx, float* dprm, float* scratch, float* workspace, size_t workspace_bytes,
+                             act_stream_t stream);
+
+/* Whole frozen prompt-tuned Transformer of the Stage-II teacher in ONE call (visual_embedding_deep_prompt, models/dvae.py:536-576,
+ * inference form): pos = visual_pos_embed(center); x = proj_pre(tokens); depth x { LN(dropout(prompt_i) + prompt_pos_i) (in-kernel
+ * Philox keyed by seed_base + 7919 (i+1) and the device-resident step counter), prefix block }; LN; proj_post.  ~125 launches. */
+typedef struct {
+    int B, P, G, D, heads, hidden, depth, tokens_dims, pos_hidden;
+    float eps, drop_p;
+    uint64_t seed_base;
+    const uint64_t* seed_dev;
+    const float *pos_w0, *pos_b0, *pos_w1, *pos_b1, *pre_w, *pre_b, *post_w, *post_b, *norm_w, *norm_b;
+    const float* const* prompt_tok;           /* [depth] -> [P, D] */
+    const float* const* prompt_pos;           /* [depth] -> [P, D] */
+    const act_block_params_t* blocks;         /* [depth] */
+} act_prefix_vit_t;
+size_t act_prefix_vit_scratch_floats(const act_prefix_vit_t* m);
+int act_prefix_vit_fwd_f32(const act_prefix_vit_t* m, const float* tokens, const float* center, float* out, float* scratch,
+                           float* workspace, size_t workspace_bytes, act_stream_t stream);
+
+/* mini-PointNet patch embedding (Encoder, models/dvae.py:185-215) on rows = points: x [BG*n, 3] -> tokens [BG, C].
+ * conv 3->128, BN, ReLU, conv 128->256, max over the n points of a group, conv 512->512 on cat(global, local) (the global half
+ * evaluated once per group), BN, ReLU, conv 512->C, max.  training: batch statistics + running-stat update, else running stats. */
+typedef struct {
+    const float *c1_w, *c1_b, *bn1_w, *bn1_b, *c2_w, *c2_b, *c3_w, *c3_b, *bn2_w, *bn2_b, *c4_w, *c4_b;
+    float *bn1_mean, *bn1_var, *bn2_mean, *bn2_var;      /* running statistics (updated in place when training) */
+} act_pointnet_params_t;
+typedef struct { float *c1_w, *c1_b, *bn1_w, *bn1_b, *c2_w, *c2_b, *c3_w, *c3_b, *bn2_w, *bn2_b, *c4_w, *c4_b; } act_pointnet_grads_t;
+typedef struct { int BG, n, C; float eps1, eps2, momentum1, momentum2; } act_pointnet_dims_t;
+size_t act_pointnet_saved_floats(const act_pointnet_dims_t* d);
+int act_pointnet_fwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, int training,
+                         int keep_for_backward, float* saved, float* out, float* workspace, size_t workspace_bytes,
+                         act_stream_t stream);
+size_t act_pointnet_bwd_scratch_floats(const act_pointnet_dims_t* d);
+int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, const float* saved,
+                         const float* dout, const act_pointnet_grads_t* grads, float* scratch, float* workspace,
+                         size_t workspace_bytes, act_stream_t stream);
+
+/* DGCNN (models/dvae.py:26-117), inference form, everything up to (not including) layer5's GroupNorm: f [B*G, Cin], graph idx
+ * int64 [B,k,G] -> h [B*G, Cout].  w_in/b_in = input_trans; stacked[l] = [Wa ; Wb - Wa] of edge-conv layer l ([2*cout_l, cin_l]);
+ * gn_w/gn_b[l] = its GroupNorm(4) affine; w5 = layer5 conv [Cout, 2304]. */
+typedef struct {
+    int B, G, k, Cin, Cout, groups;
+    float eps, slope;
+    const float *w_in, *b_in, *w5;
+    const float* stacked[4];
+    const float* gn_w[4];
+    const float* gn_b[4];
+} act_dgcnn_t;
+size_t act_dgcnn_scratch_floats(const act_dgcnn_t* m);
+int act_dgcnn_features_f32(const act_dgcnn_t* m, const float* f, const int64_t* idx, float* h, float* scratch, float* workspace,
+                           size_t workspace_bytes, act_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

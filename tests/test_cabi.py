@@ -27,6 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_declares_every_symbol():
     import act_amd._C as C
     import act_amd.kernels  # noqa: F401  (declares the dense-kernel signatures)
+    import act_amd.composite  # noqa: F401  (declares the composite entry points)
     assert set(_declared()) <= set(C.SIGNATURES), sorted(set(_declared()) - set(C.SIGNATURES))
 
 

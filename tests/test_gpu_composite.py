@@ -1,0 +1,156 @@
+"""The composite entry points (csrc/composite.hip: one host call per module) must be BIT-identical to issuing the same kernels
+one ctypes call at a time (act_amd.kernels *PerKernel forms, ACT_COMPOSITE=0): same kernels, same order, same launch
+configurations.  Checked for the Transformer block (with DropPath gates, position add, weight gradients in line and on the
+auxiliary stream), the prompt-prefix block (train + inference), the mini-PointNet Encoder (train fwd/bwd, eval), the DGCNN
+inference stack and the whole frozen prompt-tuned Transformer of the teacher (in-kernel Philox dropout active)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _params(dev, D, hidden, qkv_bias, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, off=0.0: (off + torch.randn(*s, generator=g) * 0.05).to(dev).requires_grad_(True)
+    return [r(D, off=1.0), r(D), r(3 * D, D), (r(3 * D) if qkv_bias else None), r(D, D), r(D), r(D, off=1.0), r(D), r(hidden, D), r(hidden),
+            r(D, hidden), r(D)]
+
+
+@pytest.mark.parametrize("B,S,D,H,qkv_bias,train_w", [(4, 14, 384, 6, False, 1), (4, 14, 384, 6, False, 2), (3, 64, 128, 2, True, 2),
+                                                      (2, 33, 64, 2, True, 0)])
+def test_block_composite_is_bit_identical(dev, B, S, D, H, qkv_bias, train_w):
+    import act_amd.kernels as K
+    import act_amd.composite as CP
+    torch.manual_seed(0)
+    x0 = torch.randn(B, S, D, device=dev); pos0 = 0.1 * torch.randn(B, S, D, device=dev)
+    g1 = torch.floor(0.8 + torch.rand(B, device=dev)) / 0.8; g2 = torch.floor(0.8 + torch.rand(B, device=dev)) / 0.8
+    dout = torch.randn(B, S, D, device=dev)
+    res = []
+    for fn in (K.BlockFnPerKernel, CP.BlockFn):
+        ps = _params(dev, D, 4 * D, qkv_bias, 1)
+        x, pos = x0.clone().requires_grad_(True), pos0.clone().requires_grad_(True)
+        y = fn.apply(x, pos, g1, g2, *ps, H, 1e-5, train_w)
+        y.backward(dout)
+        torch.cuda.synchronize()
+        res.append([y.detach(), x.grad, pos.grad] + [p.grad for p in ps if p is not None])
+    for a, b in zip(*res):
+        if train_w == 0 and a is None:
+            assert b is None
+            continue
+        assert torch.equal(a, b)
+    assert res[0][1].abs().max() > 0
+
+
+def test_prefix_block_composite_is_bit_identical(dev):
+    import act_amd.kernels as K
+    import act_amd.composite as CP
+    B, P, G, D, H = 3, 16, 32, 128, 2
+    torch.manual_seed(1)
+    x0 = torch.randn(B * G, D, device=dev); pos0 = 0.1 * torch.randn(B * G, D, device=dev); prm0 = 0.3 * torch.randn(B * P, D, device=dev)
+    dout = torch.randn(B * G, D, device=dev)
+    res = []
+    for fn, inf in ((K.PrefixBlockFnPerKernel, K.block_forward_prefix_perkernel), (CP.PrefixBlockFn, CP.block_forward_prefix)):
+        ps = [p.detach() if p is not None else None for p in _params(dev, D, 4 * D, True, 2)]
+        x, pos, prm = (t.clone().requires_grad_(True) for t in (x0, pos0, prm0))
+        y = fn.apply(x, pos, prm, B, P, G, *ps, H, 1e-6)
+        y.backward(dout)
+        with torch.no_grad():
+            yi = inf(x0, pos0, prm0, B, P, G, *ps, H, 1e-6)
+            n1p, _, _, _ = K.layernorm_fwd(prm0, None, ps[0], ps[1], 1e-6, want_stats=False)
+            yj = inf(x0, pos0, None, B, P, G, *ps, H, 1e-6, n1p=n1p)
+        torch.cuda.synchronize()
+        res.append([y.detach(), x.grad, pos.grad, prm.grad, yi, yj])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert torch.equal(res[1][0], res[1][4]) and torch.equal(res[1][4], res[1][5])
+
+
+def test_encoder_composite_is_bit_identical(dev):
+    import act_amd.composite as CP
+    from act_amd.models.dvae import Encoder
+    from tests.golden.fill import fill_module
+    torch.manual_seed(2)
+    nb = 0.2 * torch.randn(6, 16, 32, 3, device=dev)
+    dout = torch.randn(6, 16, 96, device=dev)
+    res = []
+    for enabled in (False, True):
+        enc = fill_module(Encoder(96), "cmp.enc.").to(dev).train()
+        saved, CP.ENABLED = CP.ENABLED, enabled
+        try:
+            y = enc(nb); y.backward(dout)
+            enc.eval()
+            with torch.no_grad():
+                ye = enc(nb)
+        finally:
+            CP.ENABLED = saved
+        torch.cuda.synchronize()
+        assert int(enc.first_conv[1].num_batches_tracked) == 1 and int(enc.second_conv[1].num_batches_tracked) == 1
+        res.append([y.detach(), ye] + [p.grad for p in enc.parameters()] + [b.clone() for b in enc.buffers()])
+    for i, (a, b) in enumerate(zip(*res)):
+        if i == 1:                  # eval mode: scale/shift from running stats by torch ops vs one HIP launch (rsqrt rounding)
+            assert (a - b).abs().max() <= 1e-5 * max(1.0, a.abs().max().item())
+        else:
+            assert torch.equal(a, b), i
+
+
+def test_teacher_stack_composite_is_bit_identical(dev):
+    """DGCNN inference stack + the whole prompt-tuned Transformer (prompt dropout from the in-kernel Philox, same seeds)."""
+    import act_amd.composite as CP
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from tests.golden.fill import fill_module, clouds, TINY_STAGE2
+    cfg = copy.deepcopy(TINY_STAGE2["dvae_config"]); cfg["NAME"] = "ACTPromptedDiscreteVAEwithVIT"
+    torch.manual_seed(3)
+    vae = fill_module(build_model_from_cfg(EasyDict(cfg)), "cmp.vae.").to(dev).train()
+    for p in vae.parameters():
+        p.requires_grad = False
+    pts = torch.from_numpy(clouds(31, 3, 128)).to(dev)
+    res = []
+    for enabled in (False, True):
+        saved, CP.ENABLED = CP.ENABLED, enabled
+        vae.__dict__.pop("_rng_state", None)
+        torch.manual_seed(77)                      # base seed of the Philox stream is drawn from the host RNG
+        try:
+            with torch.no_grad():
+                nb, c = vae.group_divider(pts)
+                f1 = vae.forward_tokenizer_features(nb, c)
+                f2 = vae.forward_tokenizer_features(nb, c)      # second call: the device-resident counter advanced
+        finally:
+            CP.ENABLED = saved
+        torch.cuda.synchronize()
+        res.append((f1, f2))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert not torch.equal(res[0][0], res[0][1])    # dropout / gumbel noise differ between the two steps
+
+
+def test_composite_gemm_shape_collection(dev):
+    """act_composite_collect_begin/_end: a dry call launches nothing and reports the GEMMs of the module."""
+    import ctypes
+    import act_amd.composite as CP
+    d = CP.BlockDims(2, 14, 64, 2, 256, 1e-5)
+    n_saved = CP.lib.act_block_saved_floats(ctypes.byref(d))
+    assert n_saved >= 2 * 14 * (8 * 64 + 2 * 256)
+    x = torch.zeros(28, 64, device=dev); out = torch.full((28, 64), 7.0, device=dev)
+    saved = torch.empty(n_saved, device=dev)
+    ws = torch.empty(1 << 20, device=dev)
+    w = [torch.zeros(s, device=dev) for s in ((64,), (64,), (192, 64), (192,), (64, 64), (64,), (64,), (64,), (256, 64), (256,), (64, 256), (64,))]
+    prm = CP.BlockParams(*[t.data_ptr() for t in w])
+    buf = (ctypes.c_int * 50)()
+    assert CP.lib.act_composite_collect_begin() == 0
+    rc = CP.lib.act_block_fwd_f32(ctypes.byref(d), ctypes.byref(prm), x.data_ptr(), None, None, None, 1, saved.data_ptr(), out.data_ptr(),
+                                  ws.data_ptr(), ws.numel() * 4, None)
+    n = CP.lib.act_composite_collect_end(buf, 10)
+    torch.cuda.synchronize()
+    assert rc == 0 and n == 4
+    shapes = [tuple(buf[5 * i:5 * i + 5]) for i in range(4)]
+    assert shapes == [(1, 1, 28, 192, 64), (1, 1, 28, 64, 64), (1, 1, 28, 256, 64), (1, 1, 28, 64, 256)]
+    assert (out == 7.0).all()                       # nothing was launched
+    assert CP.lib.act_composite_collect_end(buf, 10) < 0      # not collecting any more

@@ -1,0 +1,158 @@
+"""The PRODUCT model under DistributedDataParallel with world_size 2 on one GPU (gloo transporting CUDA tensors, both ranks on
+cuda:0): runner_pretrain.wrap_ddp + train_step(next_points=...) with the cross-step teacher prefetch on auxiliary stream 0, the
+weight-gradient GEMMs on auxiliary stream 1 and gradient_as_bucket_view buckets, i.e. DDP's bucket hooks racing against both
+side streams (reference: tools/runner_pretrain.py:84-93,145-167).
+
+  * trajectory: 4 pipelined AdamW steps with identical shards / seeds on both ranks are bit-identical to the single-process run
+    (the all-reduce mean of two equal fp32 values is exact);
+  * averaging: with different shards and seeds per rank, the gradients DDP leaves in .grad equal the mean of the single-rank
+    gradients (same seeds, no DDP), and are identical on both ranks.
+"""
+import argparse
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS = 4
+
+
+def _cfg(step_per_update=1):
+    from act_amd.utils.config import EasyDict
+    return EasyDict(optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3, weight_decay=0.05)),
+                    scheduler=dict(type="CosLR", kwargs=dict(epochs=300, initial_epochs=10)), step_per_update=step_per_update)
+
+
+def _model(dev):
+    import copy
+    from act_amd.models import build_model_from_cfg
+    from act_amd.tools.runner_pretrain import freeze_unused_heads
+    from act_amd.utils.config import EasyDict
+    from tests.golden.fill import fill_module, TINY_STAGE2
+    cfg = copy.deepcopy(TINY_STAGE2)
+    cfg["transformer_config"]["drop_path_rate"] = 0.2            # DropPath draws active
+    torch.manual_seed(0)
+    model = fill_module(build_model_from_cfg(EasyDict(cfg)), "ddp.").to(dev).train()
+    freeze_unused_heads(model)
+    return model
+
+
+def _batches(seed0, dev):
+    from tests.golden.fill import clouds
+    return [torch.from_numpy(clouds(seed0 + i, 4, 128)).to(dev) for i in range(STEPS)]
+
+
+def _trajectory(wrapped, model, seed, data_seed, dev):
+    """STEPS pipelined steps -> (losses, parameters)"""
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import train_step
+    cfg = _cfg()
+    opt, _ = builder.build_opti_sche(wrapped, cfg)
+    torch.manual_seed(seed)
+    pts = _batches(data_seed, dev)
+    losses = []
+    for i in range(STEPS):
+        nxt = pts[i + 1] if i + 1 < STEPS else None
+        losses.append(train_step(wrapped, opt, pts[i], cfg, next_points=nxt))
+        if nxt is not None:
+            assert model._prefetched is not None and model._prefetched[0] is nxt      # the pipelined path really ran
+    torch.cuda.synchronize()
+    return torch.stack(losses).cpu(), {n: p.detach().clone().cpu() for n, p in model.named_parameters()}
+
+
+def _one_step_grads(wrapped, model, seed, data_seed, dev):
+    """forward + backward of one pipelined step without the optimizer step -> gradients left in .grad"""
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import train_step
+    cfg = _cfg(step_per_update=2)                                   # num_iter=1 != 2: train_step does not step / zero the grads
+    opt, _ = builder.build_opti_sche(wrapped, cfg)
+    torch.manual_seed(seed)
+    pts = _batches(data_seed, dev)
+    loss = train_step(wrapped, opt, pts[0], cfg, num_iter=1, next_points=pts[1])
+    torch.cuda.synchronize()
+    return loss.item(), {n: p.grad.detach().clone().cpu() for n, p in model.named_parameters() if p.grad is not None}
+
+
+class _fixed_gemm_configs:
+    """Bitwise comparisons ACROSS processes need the same GEMM launch configuration (tile / split-K = fp32 summation order) in each
+    of them: switch the timing-based first-use autotuner off (built-in cost model + shipped table only) and drop cached winners."""
+
+    def __enter__(self):
+        import act_amd.kernels as K
+        import act_amd.composite as CP
+        self.K, self.CP, self.saved = K, CP, (K.AUTOTUNE, dict(K._GEMM_CACHE))
+        K.AUTOTUNE = False
+        K._GEMM_CACHE.clear()
+        CP.reset_tuning()                      # C-side table back to the shipped entries only
+
+    def __exit__(self, *exc):
+        self.K.AUTOTUNE = self.saved[0]
+        self.K._GEMM_CACHE.clear()
+        self.K._GEMM_CACHE.update(self.saved[1])
+        self.CP.reset_tuning()                 # composites re-collect (and re-register the cached winners) on next use
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["ACT_GEMM_AUTOTUNE"] = "0"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from act_amd.tools.runner_pretrain import wrap_ddp
+    ns = argparse.Namespace(local_rank=rank, use_gpu=True)
+    # (1) same data and seeds on both ranks: trajectory must equal the single-process one bit for bit
+    model = _model(dev)
+    ddp = wrap_ddp(model, ns)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and ddp.gradient_as_bucket_view
+    losses, params = _trajectory(ddp, model, seed=123, data_seed=20, dev=dev)
+    # (2) different shards and seeds: gradients are the mean over ranks
+    model2 = _model(dev)
+    ddp2 = wrap_ddp(model2, ns)
+    loss2, grads2 = _one_step_grads(ddp2, model2, seed=500 + rank, data_seed=40 + 10 * rank, dev=dev)
+    torch.save({"losses": losses, "params": params, "loss2": loss2, "grads2": grads2}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_product_model_under_ddp_two_ranks_one_gpu(tmp_path):
+    assert torch.cuda.is_available()
+    from act_amd.tools.runner_pretrain import _Single
+    dev = torch.device("cuda:0")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"r{i}.pt") for i in range(2)]
+
+    # ---- (1) 4-step pipelined trajectory: DDP(2 ranks, equal shards) == single process, bitwise -----------------------
+    with _fixed_gemm_configs():
+        model = _model(dev)
+        losses, params = _trajectory(_Single(model), model, seed=123, data_seed=20, dev=dev)
+        single = []
+        for rank in range(2):
+            m = _model(dev)
+            single.append(_one_step_grads(_Single(m), m, seed=500 + rank, data_seed=40 + 10 * rank, dev=dev))
+    for rank in range(2):
+        assert torch.equal(r[rank]["losses"], losses), (rank, r[rank]["losses"], losses)
+        for n, p in params.items():
+            assert torch.equal(r[rank]["params"][n], p), (rank, n)
+    assert len(set(losses.tolist())) == STEPS                       # the model actually moved
+
+    # ---- (2) gradient averaging across different shards ---------------------------------------------------------------
+    assert set(r[0]["grads2"]) == set(single[0][1])
+    assert not any("lm_head" in n or "cls_head" in n for n in r[0]["grads2"])
+    for rank in range(2):
+        assert abs(r[rank]["loss2"] - single[rank][0]) <= 1e-6      # the local loss is not averaged
+    assert abs(single[0][0] - single[1][0]) > 1e-4                   # the shards really differ
+    for n, g0 in single[0][1].items():
+        want = 0.5 * (g0.double() + single[1][1][n].double())
+        scale = max(1e-6, want.abs().max().item())
+        for rank in range(2):
+            err = (r[rank]["grads2"][n].double() - want).abs().max().item()
+            assert err <= 2e-6 * scale + 1e-9, (n, rank, err, scale)
+        assert torch.equal(r[0]["grads2"][n], r[1]["grads2"][n]), n  # identical on both ranks after the all-reduce

@@ -114,7 +114,7 @@ def test_stage2_tiny_vs_oracle_all_draws_active(dev):
     od = dict(oracle.named_parameters())
     for n, p in model.named_parameters():
         if p.requires_grad and od[n].grad is not None and p.grad is not None:
-            assert _rel(p.grad, od[n].grad) <= 2e-4, n
+            assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
 
 
 def test_stage2_full_geometry_vs_oracle(dev):
@@ -138,7 +138,7 @@ def test_stage2_full_geometry_vs_oracle(dev):
     od = dict(oracle.named_parameters())
     for n in ["ACT_encoder.blocks.blocks.11.mlp.fc1.weight", "ACT_encoder.encoder.first_conv.0.weight", "mask_token",
               "ACT_decoder.blocks.0.attn.qkv.weight", "proj_head.bias", "ACT_encoder.pos_embed.2.weight"]:
-        assert _rel(dict(model.named_parameters())[n].grad, od[n].grad) <= 2e-4, n
+        assert _rel(dict(model.named_parameters())[n].grad, od[n].grad) <= TOL, (n, _rel(dict(model.named_parameters())[n].grad, od[n].grad))
 
 
 def test_stage1_tiny_golden(dev):
@@ -152,17 +152,30 @@ def test_stage1_tiny_golden(dev):
     vae.prompt_dropout.p = 0.0
     pts = torch.from_numpy(clouds(4, TINY_B, TINY_N)).to(dev)
     ret = vae(pts, temperature=0.7, hard=False, draws=Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}, device=dev))
-    assert _rel(ret[2], g["coarse"]) <= TOL and _rel(ret[3], g["fine"]) <= TOL and _rel(ret[5], g["logits"]) <= 2e-4
+    assert _rel(ret[2], g["coarse"]) <= TOL and _rel(ret[3], g["fine"]) <= TOL and _rel(ret[5], g["logits"]) <= TOL
     assert _rel(ret[1], g["whole_fine"]) <= TOL
     lr, lk = vae.get_loss(ret, pts)
     assert abs(lr.item() - g["loss"][0]) <= TOL and abs(lk.item() - g["loss"][1]) <= TOL
     (lr + 0.1 * lk).backward()
     pd = dict(vae.named_parameters())
     for n, v in zip(g["grad_names"], g["grad_norms"]):
-        # 5e-4: the graph has discrete selections (LeakyReLU kink of the 64-logit head, max over neighbours, Chamfer arg-min); one
-        # element within rounding distance of a switch point moves a gradient norm by ~1e-4 between summation orders
-        # (the kernels themselves are checked against float64 autograd at 5e-5 in test_gpu_dense.py)
+        # gradient NORMS of the reference golden at 5e-4: this graph is ill-conditioned in fp32 -- the reference's own math (the CPU
+        # oracle) run with 1 vs 8 threads, i.e. nothing but another fp32 summation order, moves these gradients by 1.5e-4 .. 3.5e-4
+        # in ||e||/||r|| (tests/test_oracle_golden.py::test_stage1_tiny_gradient_conditioning; ReLU / LeakyReLU / max / arg-min
+        # switch points within rounding distance).  Element-wise the HIP gradients are within 1e-4 of the oracle's (below).
         assert abs(pd[str(n)].grad.norm().item() - v) <= 5e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)
+    from oracle import models as OM, layers as OL
+    torch.manual_seed(0)
+    ora = fill_module(OM.ACTPromptedDiscreteVAEwithVIT(OM.edict(cfg)), "g7.").train(); ora.prompt_p = 0.0
+    ro = ora(pts.cpu(), OL.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}), temperature=0.7, hard=False)
+    lo = ora.get_loss(ro); (lo[0] + 0.1 * lo[1]).backward()
+    od = dict(ora.named_parameters())
+    checked = 0
+    for n, p in pd.items():
+        if p.grad is not None and od[n].grad is not None:
+            assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
+            checked += 1
+    assert checked >= 60
 
 
 def test_no_host_sync_in_training_step(dev):
@@ -241,7 +254,7 @@ def test_stress_geometry_vs_oracle(dev):
     od = dict(oracle.named_parameters())
     for n in ["ACT_encoder.blocks.blocks.23.mlp.fc1.weight", "ACT_encoder.encoder.second_conv.0.weight", "mask_token",
               "ACT_decoder.blocks.1.attn.qkv.weight", "ACT_encoder.pos_embed.0.weight"]:
-        assert _rel(dict(model.named_parameters())[n].grad, od[n].grad) <= 3e-4, n
+        assert _rel(dict(model.named_parameters())[n].grad, od[n].grad) <= TOL, (n, _rel(dict(model.named_parameters())[n].grad, od[n].grad))
 
 
 def test_forward_eval_cls_feature_vs_oracle(dev):
@@ -332,3 +345,50 @@ def test_block_mask_type_matches_reference_and_trains(dev):
     lo = oracle(pts, rec)
     lg = model(pts.to(dev), draws=Draws(rec.table, device=dev))
     assert abs(lg.item() - lo.item()) <= TOL, (lg.item(), lo.item())
+
+
+def test_stage1_full_geometry_vs_oracle(dev):
+    """BASELINE configs[2] geometry from the shipped YAML (N=1024, G=64, M=32, 8192-token codebook, 12-layer ViT-B with 64 deep
+    prompts through PrefixBlockFn, 64x32 FoldingNet, Chamfer-L1 + KL) at B=2 against the CPU oracle: both losses + gradients."""
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import cfg_from_yaml_file
+    from act_amd.utils.draws import Draws
+    cfg = cfg_from_yaml_file("cfgs/autoencoder/act_dvae_with_pretrained_transformer.yaml").model
+    torch.manual_seed(5)
+    oracle = OM.ACTPromptedDiscreteVAEwithVIT(OM.edict(cfg)).train()
+    vae = build_model_from_cfg(cfg)
+    vae.load_state_dict(oracle.state_dict(), strict=True)
+    vae.to(dev).train()
+    pts = torch.from_numpy(clouds(11, 2, 1024))
+    rec = OL.Draws(record=True)
+    ro = oracle(pts, rec, temperature=0.6, hard=False)
+    lro, lko = oracle.get_loss(ro)
+    (lro + 0.05 * lko).backward()
+    assert "gumbel" in rec.table and any(k.startswith("prompt.") for k in rec.table)
+    rg = vae(pts.to(dev), temperature=0.6, hard=False, draws=Draws(rec.table, device=dev))
+    lrg, lkg = vae.get_loss(rg, pts.to(dev))
+    (lrg + 0.05 * lkg).backward()
+    assert tuple(rg[0].shape) == (2, 512, 3) and tuple(rg[1].shape) == (2, 2048, 3) and tuple(rg[5].shape) == (2, 64, 8192)
+    assert abs(lrg.item() - lro.item()) <= TOL and abs(lkg.item() - lko.item()) <= TOL, (lrg.item(), lro.item(), lkg.item(), lko.item())
+    assert _rel(rg[3], ro[3]) <= TOL and _rel(rg[5], ro[5]) <= TOL
+    od, pd = dict(oracle.named_parameters()), dict(vae.named_parameters())
+    for n in ["encoder.first_conv.0.weight", "dgcnn_1.layer5.0.weight", "codebook", "deep_prompt_tokens", "visual_prompt_pos",
+              "proj_pre.weight", "dgcnn_2.layer3.0.weight", "decoder.mlp.2.weight", "decoder.final_conv.3.weight", "proj_post.bias"]:
+        assert od[n].grad is not None and pd[n].grad is not None, n
+        assert _rel(pd[n].grad, od[n].grad) <= TOL, (n, _rel(pd[n].grad, od[n].grad))
+    assert all(p.grad is None for n, p in pd.items() if n.startswith("visual_embed."))     # frozen Transformer: no dW
+
+
+def test_rand_mask_has_exact_count_per_row(dev):
+    """_mask_center_rand (models/act.py:244-267): exactly int(mask_ratio * G) ones per cloud, different per cloud, on the device."""
+    from act_amd.models.act import random_mask
+    m = random_mask(128, 64, int(0.8 * 64), dev)
+    assert m.dtype == torch.bool and tuple(m.shape) == (128, 64)
+    assert (m.sum(1) == 51).all()
+    assert len({tuple(r.tolist()) for r in m.cpu()}) > 100
+    model = _tiny(dev)
+    center = torch.from_numpy(golden("g1_group")["center"]).to(dev)[:, :16].contiguous()
+    mk = model.ACT_encoder._mask_center_rand(center)
+    assert (mk.sum(1) == int(0.75 * 16)).all()
+    assert not model.ACT_encoder._mask_center_rand(center, noaug=True).any()

@@ -227,3 +227,38 @@ def test_g12_block_mask_matches_reference():
     center = torch.from_numpy(golden("g1_group")["center"])
     m = M.block_mask(center, int(0.8 * 64), g["seed_index"])
     assert np.array_equal(m.numpy(), g["mask"]) and (m.sum(1) == 51).all()
+
+
+def test_stage1_tiny_gradient_conditioning():
+    """Why the Stage-I gradient-NORM goldens are compared at 5e-4 and not 1e-4 (tests/test_gpu_model.py::test_stage1_tiny_golden):
+    the same fp32 math (this oracle == the reference's modules, goldens above) evaluated with a different summation order -- 1 CPU
+    thread vs 8 -- already moves the upstream gradients by more than 1e-4 in ||e|| / ||r||.  ReLU / LeakyReLU / max-pool / Chamfer
+    arg-min switch points sit within rounding distance; no fp32 implementation can be closer to another than that."""
+    import torch
+    from tests.golden.fill import fill_module, clouds, TINY_STAGE2, TINY_B, TINY_N
+    from oracle import models as OM, layers as OL
+    cfg = dict(TINY_STAGE2["dvae_config"]); cfg["NAME"] = "ACTPromptedDiscreteVAEwithVIT"
+    saved = torch.get_num_threads()
+
+    def grads(threads):
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        ora = fill_module(OM.ACTPromptedDiscreteVAEwithVIT(OM.edict(cfg)), "g7.").train(); ora.prompt_p = 0.0
+        torch.manual_seed(777)
+        noise = -torch.empty((TINY_B, 16, 64)).exponential_().log()
+        ret = ora(torch.from_numpy(clouds(4, TINY_B, TINY_N)), OL.Draws({"gumbel": noise}), temperature=0.7, hard=False)
+        lr, lk = ora.get_loss(ret)
+        (lr + 0.1 * lk).backward()
+        return {n: p.grad.double() for n, p in ora.named_parameters() if p.grad is not None}
+    try:
+        a, b = grads(8), grads(1)
+    finally:
+        torch.set_num_threads(saved)
+    if all(torch.equal(a[n], b[n]) for n in a):
+        import pytest
+        pytest.skip("this host evaluates both thread counts in the same order")
+    dev = {n: ((a[n] - b[n]).norm() / b[n].norm()).item() for n in ("encoder.first_conv.0.weight", "dgcnn_1.layer5.0.weight", "proj_pre.weight")}
+    assert max(dev.values()) > 1e-4, dev
+    # ... while element-wise (relative to the largest element, the metric of the GPU parity tests) the two runs agree to 1e-4
+    for n in a:
+        assert ((a[n] - b[n]).abs().max() / max(1.0, b[n].abs().max().item())).item() <= 1e-4, n
