@@ -35,7 +35,8 @@ SIGNATURES = {
     "act_prof_num_kernels": [],
     "act_prof_kernel_name": [_i],
     "act_prof_read": [_i, _vp, _vp, _vp, _vp],
-    "act_fps_f32": [_vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "act_fps_scratch_floats": [_i, _i],
+    "act_fps_f32": [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
     "act_knn_group_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "act_gather_points_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "act_gather_points_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
@@ -44,7 +45,7 @@ SIGNATURES = {
     "act_chamfer_fwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "act_chamfer_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
 }
-_RESTYPE = {"act_arch": ctypes.c_char_p, "act_prof_kernel_name": ctypes.c_char_p}
+_RESTYPE = {"act_arch": ctypes.c_char_p, "act_prof_kernel_name": ctypes.c_char_p, "act_fps_scratch_floats": ctypes.c_size_t}
 
 
 def _declare(extra=None):
@@ -77,7 +78,15 @@ def ptr(t):
         raise ActHipError("act_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
     if not t.is_contiguous():
         raise ActHipError("act_amd kernels need contiguous tensors")
+    _same_device(t)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _same_device(t):
+    """launches go to the CURRENT device's current stream: a tensor living on another GPU would be dereferenced there"""
+    if t.device.index != torch.cuda.current_device():
+        raise ActHipError(f"tensor on cuda:{t.device.index} but the current device is cuda:{torch.cuda.current_device()} "
+                          "(call torch.cuda.set_device(local_rank) first; kernels are launched on the current device's stream)")
 
 
 def ptr_rows(t):
@@ -88,6 +97,7 @@ def ptr_rows(t):
         raise ActHipError("act_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback")
     if not (t.is_contiguous() or (t.dim() == 2 and t.stride(1) == 1)):
         raise ActHipError("act_amd GEMM operands need unit inner stride")
+    _same_device(t)
     return ctypes.c_void_p(t.data_ptr())
 
 

@@ -97,6 +97,7 @@ def _p(t):
         return None
     if not t.is_cuda or not t.is_contiguous():
         raise _C.ActHipError("act_amd kernels need contiguous CUDA tensors (there is no CPU fallback)")
+    _C._same_device(t)
     return t.data_ptr()
 
 

@@ -163,10 +163,10 @@ static int launch_fps(const float* xyz, int B, int N, int G, int32_t* idx, float
     return 0;
 }
 
-static float* g_fps_temp = nullptr; static size_t g_fps_temp_n = 0;
+extern "C" size_t act_fps_scratch_floats(int B, int N) { return N > 16384 ? (size_t)B * N : 0; }
 
 extern "C" int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_out, float* centers_out,
-                           int skip_near_origin, act_stream_t stream) {
+                           int skip_near_origin, float* scratch, act_stream_t stream) {
     if (B == 0 || G == 0) return 0;                        // empty batch: nothing to do (empty tensors have NULL storage)
     if (!xyz || !idx_out) return ACT_E_NULLPTR;
     if (B < 0 || N <= 0 || G < 0) return ACT_E_BADARG;
@@ -182,15 +182,9 @@ extern "C" int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_o
     if (N <= 4096)  return launch_fps<8, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
     if (N <= 8192)  return launch_fps<16, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
     if (N <= 16384) return launch_fps<16, 16>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
-    // very large clouds: running distances in a library-owned global buffer (grown on demand, outside capture)
-    const size_t need = (size_t)B * N;
-    if (need > g_fps_temp_n) {
-        if (g_fps_temp) hipFree(g_fps_temp);
-        hipError_t e = hipMalloc(&g_fps_temp, need * sizeof(float));
-        if (e != hipSuccess) { g_fps_temp = nullptr; g_fps_temp_n = 0; return (int)e; }
-        g_fps_temp_n = need;
-    }
-    hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, s, xyz, N, G, idx_out, centers_out, g_fps_temp, skip_near_origin);
+    // very large clouds: the running distances live in the caller's scratch (act_fps_scratch_floats floats)
+    if (!scratch) return ACT_E_NULLPTR;
+    hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, s, xyz, N, G, idx_out, centers_out, scratch, skip_near_origin);
     ACT_LAUNCH_CHECK();
     return 0;
 }
@@ -306,13 +300,12 @@ extern "C" int act_knn_group_f32(const float* ref, const float* query, int B, in
     if (B == 0 || Q == 0) return 0;                        // empty batch: nothing to do (empty tensors have NULL storage)
     if (!ref || !query || !idx_out) return ACT_E_NULLPTR;
     if (B < 0 || N <= 0 || Q < 0 || K <= 0 || K > N) return ACT_E_BADARG;
-    if (K > 64 && N <= 64 * 128) return ACT_E_BADARG;      // register path keeps the K winners one per lane
-    if (B == 0 || Q == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     // algorithmic bytes per cloud: 12N + 12Q + 8QK (+12QK neighbourhood) (+4QK dist)   [SURVEY 8d]
     ActProfScope ps(KID_KNN_GROUP, s, 0.0,
                     (double)B * (12.0 * N + 12.0 * Q + 8.0 * Q * K + (nbr_out ? 12.0 * Q * K : 0.0) + (dist_out ? 4.0 * Q * K : 0.0)));
-#define KNN_CASE(P) if (N <= 64 * P) return launch_knn<P>(ref, query, B, N, Q, K, idx_out, idx_kq, nbr_out, dist_out, s)
+    // the register path keeps the K winners one per lane (K <= 64); larger K (any N) and N > 8192 take the rescan kernel
+#define KNN_CASE(P) if (K <= 64 && N <= 64 * P) return launch_knn<P>(ref, query, B, N, Q, K, idx_out, idx_kq, nbr_out, dist_out, s)
     KNN_CASE(1); KNN_CASE(2); KNN_CASE(4); KNN_CASE(8); KNN_CASE(16); KNN_CASE(32); KNN_CASE(64); KNN_CASE(128);
 #undef KNN_CASE
     {

@@ -268,3 +268,61 @@ extern "C" int act_bn_eval_affine_f32(const float* gamma, const float* beta, con
                        scale, shift);
     ACT_LAUNCH_CHECK(); return 0;
 }
+
+// ---- pieces of the BatchNorm reductions as separate entry points: SyncBatchNorm (statistics all-reduced across ranks between them) ----
+__global__ __launch_bounds__(256) void meanvar_finalize_kernel(const float* __restrict__ x, const float* __restrict__ partial, int nparts, int C, int R,
+                                                               float* __restrict__ mean_out, float* __restrict__ var_out) {
+    __shared__ float red[2][3][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    float s, q;
+    fold_partials(partial, nparts, C, c, lane, red, s, q);
+    if (lane != 0 || c >= C) return;
+    const float dm = s / (float)R;
+    mean_out[c] = x[c] + dm;
+    var_out[c] = fmaxf(q / (float)R - dm * dm, 0.f);           // biased variance of this rank's rows
+}
+// per-column mean and biased variance of x [R,C] (pivoted sums, deterministic)
+extern "C" int act_col_mean_var_f32(const float* x, int R, int C, float* mean, float* var, float* workspace, size_t workspace_bytes,
+                                    act_stream_t stream) {
+    if (!x || !mean || !var || !workspace) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0) return ACT_E_BADARG;
+    const int parts = stats_parts(R, C);
+    if (workspace_bytes < (size_t)parts * 2 * C * sizeof(float)) return ACT_E_BADARG;
+    int rpb = (R + parts - 1) / parts; rpb = (rpb + 3) / 4 * 4;
+    const int nparts = (R + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_BN_STATS, s, 0.0, 4.0 * R * (double)C);
+    hipLaunchKernelGGL(colstats_stage1<0>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                       R, C, rpb, workspace);
+    hipLaunchKernelGGL(meanvar_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, x, workspace, nparts, C, R, mean, var);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+// backward sums of this rank's rows: sum_dy[c] = sum_r dyh, sum_dy_xhat[c] = sum_r dyh * xhat   (dyh = relu ? dy * (x*scale+shift > 0) : dy)
+extern "C" int act_bn_bwd_sums_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
+                                   int relu, int R, int C, float* sum_dy, float* sum_dy_xhat, float* workspace, size_t workspace_bytes,
+                                   act_stream_t stream) {
+    if (!x || !dy || !scale || !shift || !mean || !rstd || !sum_dy || !sum_dy_xhat || !workspace) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0) return ACT_E_BADARG;
+    const int parts = stats_parts(R, C);
+    if (workspace_bytes < (size_t)parts * 2 * C * sizeof(float)) return ACT_E_BADARG;
+    int rpb = (R + parts - 1) / parts; rpb = (rpb + 3) / 4 * 4;
+    const int nparts = (R + rpb - 1) / rpb;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_BN_BWD, s, 0.0, 8.0 * R * (double)C);
+    hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace);
+    hipLaunchKernelGGL(colstats_stage2, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nparts, C, sum_dy, sum_dy_xhat);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+// dx = scale * (dyh - sum_dy / count - xhat * sum_dy_xhat / count) with the (all-reduced) sums over `count` rows of all ranks
+extern "C" int act_bn_bwd_apply_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
+                                    const float* sum_dy, const float* sum_dy_xhat, float count, int relu, int R, int C, float* dx,
+                                    act_stream_t stream) {
+    if (!x || !dy || !scale || !shift || !mean || !rstd || !sum_dy || !sum_dy_xhat || !dx) return ACT_E_NULLPTR;
+    if (R <= 0 || C <= 0 || !(count > 0.f)) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_BN_BWD, s, 0.0, 12.0 * R * (double)C);
+    const long long total = (long long)R * C;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, sum_dy, sum_dy_xhat, relu,
+                       1.0f / count, total, C, dx);
+    ACT_LAUNCH_CHECK(); return 0;
+}

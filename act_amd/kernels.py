@@ -346,6 +346,37 @@ def mlp(x, w1, b1, w2, b2):
     return MlpFn.apply(x, w1, b1, w2, b2)
 
 
+class MlpRelu3Fn(torch.autograd.Function):
+    """Linear-ReLU-Linear-ReLU-Linear (the FoldingNet coarse MLP, models/dvae.py:226-232): ReLU fused in the producing GEMM's epilogue,
+    the ReLU mask of the backward fused in the input-gradient GEMM of the following layer (ACT_EPI_MUL_RELU_MASK)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, w2, b2):
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        h1 = gemm(x2, w0, True, True, bias=b0, act=EPI_RELU)
+        h2 = gemm(h1, w1, True, True, bias=b1, act=EPI_RELU)
+        y = gemm(h2, w2, True, True, bias=b2)
+        ctx.save_for_backward(x2, h1, h2, w0, w1, w2)
+        ctx.shp = x.shape
+        return y.reshape(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, h1, h2, w0, w1, w2 = ctx.saved_tensors
+        dy = _f32c(dy).reshape(-1, w2.shape[0])
+        dw2, db2 = gemm(dy, h2, False, False), colsum(dy)
+        d2 = gemm(dy, w2, True, False, act=EPI_MUL_RELU_MASK, aux=h2)        # gradient before the second ReLU
+        dw1, db1 = gemm(d2, h1, False, False), colsum(d2)
+        d1 = gemm(d2, w1, True, False, act=EPI_MUL_RELU_MASK, aux=h1)
+        dw0, db0 = gemm(d1, x2, False, False), colsum(d1)
+        dx = gemm(d1, w0, True, False).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
+        return dx, dw0, db0, dw1, db1, dw2, db2
+
+
+def mlp_relu3(x, w0, b0, w1, b1, w2, b2):
+    return MlpRelu3Fn.apply(x, w0, b0, w1, b1, w2, b2)
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -553,12 +584,15 @@ _C._declare({
     "act_group_max_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "act_group_max_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "act_group_sum_f32": [_vp, _i, _i, _i, _vp, _vp],
+    "act_col_mean_var_f32": [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_bn_bwd_sums_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_bn_bwd_apply_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp],
 })
 _C.lib.act_layernorm_bwd_workspace.restype = _sz
 _C.lib.act_colsum_workspace.restype = _sz
 _C.lib.act_colstats_workspace.restype = _sz
 for _n in ("act_colstats_workspace", "act_bn_stats_f32", "act_affine_act_f32", "act_bn_bwd_f32", "act_group_max_f32",
-           "act_group_max_bwd_f32", "act_group_sum_f32"):
+           "act_group_max_bwd_f32", "act_group_sum_f32", "act_col_mean_var_f32", "act_bn_bwd_sums_f32", "act_bn_bwd_apply_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
 
 
@@ -604,10 +638,81 @@ class BNActFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None, None
 
 
+class SyncBNActFn(torch.autograd.Function):
+    """nn.SyncBatchNorm (+ReLU) on rows [R,C] in train mode: batch statistics over the rows of ALL ranks of ``group`` (the reference's
+    --sync_bn path, tools/runner_pretrain.py:86-88).  Per rank: one statistics pass (mean, biased variance, row count), an all-gather of
+    3 x C floats, Chan's combination of the per-rank moments, the affine apply; backward: the two local column sums are all-reduced
+    before dx is formed (dgamma / dbeta stay local sums, DDP averages them like every other gradient -- torch's SyncBatchNorm does the same)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, group):
+        import torch.distributed as dist
+        x = _f32c(x)
+        R, C = x.shape
+        dev = x.device
+        local = torch.empty(3, C, dtype=torch.float32, device=dev)         # mean | var | count
+        ws = workspace(dev, lib.act_colstats_workspace(R, C))
+        check(lib.act_col_mean_var_f32(ptr(x), R, C, ptr(local[0]), ptr(local[1]), ptr(ws), ws.numel() * 4, stream()), "act_col_mean_var_f32")
+        local[2].fill_(float(R))
+        world = dist.get_world_size(group)
+        gathered = torch.empty(world, 3, C, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(gathered, local, group=group) if dist.get_backend(group) == "nccl" else \
+            dist.all_gather(list(gathered.unbind(0)), local, group=group)
+        n = gathered[:, 2]                                                  # [world, C]
+        total = n.sum(0)
+        mean = (gathered[:, 0] * n).sum(0) / total
+        var = ((gathered[:, 1] + (gathered[:, 0] - mean) ** 2) * n).sum(0) / total          # biased variance over all rows
+        rstd = torch.rsqrt(var + eps)
+        scale = (gamma * rstd).contiguous()
+        shift = (beta - mean * scale).contiguous()
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(var * (total / (total - 1).clamp_min(1)), alpha=momentum)
+        y = torch.empty_like(x)
+        check(lib.act_affine_act_f32(ptr(x), ptr(scale), ptr(shift), int(relu), R, C, ptr(y), stream()), "act_affine_act_f32")
+        ctx.save_for_backward(x, scale, shift, mean.contiguous(), rstd.contiguous(), total[:1].contiguous())
+        ctx.relu, ctx.group = relu, group
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, scale, shift, mean, rstd, total = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, C = x.shape
+        dev = x.device
+        sums = torch.empty(2, C, dtype=torch.float32, device=dev)           # sum dy | sum dy * xhat  (this rank)
+        ws = workspace(dev, lib.act_colstats_workspace(R, C))
+        check(lib.act_bn_bwd_sums_f32(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), int(ctx.relu), R, C, ptr(sums[0]), ptr(sums[1]),
+                                      ptr(ws), ws.numel() * 4, stream()), "act_bn_bwd_sums_f32")
+        db, dg = sums[0].clone(), sums[1].clone()
+        dist.all_reduce(sums, group=ctx.group)
+        dx = torch.empty_like(x)
+        count = float(R * dist.get_world_size(ctx.group))                   # equal shards (DistributedSampler with drop_last): no host sync
+        check(lib.act_bn_bwd_apply_f32(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(sums[0]), ptr(sums[1]), count, int(ctx.relu),
+                                       R, C, ptr(dx), stream()), "act_bn_bwd_apply_f32")
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def _sync_group(bn):
+    """process group of a SyncBatchNorm module when its statistics must be synchronised right now, else None"""
+    if not isinstance(bn, torch.nn.SyncBatchNorm):
+        return None
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
+
+
 def batch_norm_act(x, bn, training, relu=True):
-    """functional nn.BatchNorm1d (+ReLU) on rows [R,C] with the module's parameters and buffers."""
+    """functional nn.BatchNorm1d / nn.SyncBatchNorm (+ReLU) on rows [R,C] with the module's parameters and buffers."""
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
+    group = _sync_group(bn) if training else None
+    if group is not None:
+        return SyncBNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, relu, group)
     return BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps, relu)
 
 

@@ -243,11 +243,23 @@ class VisableOnlyMaskTransformer(nn.Module):
         pos = K.mlp(take_rows(center, vis_idx), pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias)
         x_vis = torch.cat((self.cls_token.expand(B, -1, -1), x_vis), dim=1)
         pos = torch.cat((self.cls_pos.expand(B, -1, -1), pos), dim=1)
-        x_vis = self.blocks(x_vis, pos, draws)
+        x_vis_shallow = None
+        if register_shallow_hook > 0:          # models/act.py:293-297: the output of block `hook` (before the final norm) is kept
+            gates = stack_gates(self.blocks.blocks, B, x_vis.device, draws, self.blocks.__dict__.setdefault("_keep_cache", {}))
+            for idx, blk in enumerate(self.blocks.blocks):
+                x_vis = blk(x_vis, pos, draws, f"enc.{idx}", gates[idx])
+                if idx == register_shallow_hook:
+                    x_vis_shallow = x_vis
+        else:
+            x_vis = self.blocks(x_vis, pos, draws)
         x_vis = K.layer_norm(x_vis, self.norm.weight, self.norm.bias, self.norm.eps)
         if only_cls_tokens:
             ch = self.cls_head
             return K.mlp(x_vis[:, 0].contiguous(), ch[0].weight, ch[0].bias, ch[2].weight, ch[2].bias)
+        if register_shallow_hook > 0:
+            if x_vis_shallow is None:
+                raise ValueError(f"register_shallow_hook={register_shallow_hook} is not a block index of a depth-{self.depth} encoder")
+            return x_vis[:, 1:], x_vis[:, 0], x_vis_shallow[:, 1:], bool_masked_pos
         return x_vis[:, 1:], bool_masked_pos
 
 
@@ -269,7 +281,7 @@ class PointTransformer(nn.Module):
         self.group_size = config.group_size
         self.num_group = config.num_group
         self.encoder_dims = config.encoder_dims
-        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size, skip_near_origin=config.get("fps_skip_near_origin", None))
         self.encoder = Encoder(encoder_channel=self.encoder_dims)
         self.reduce_dim = nn.Linear(self.encoder_dims, self.embed_dim) if self.encoder_dims != self.embed_dim else nn.Identity()
         self.cls_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
@@ -411,11 +423,16 @@ class ACT_PointDistillation(nn.Module):
         self.decoder_depth = tc.decoder_depth
         self.decoder_num_heads = tc.decoder_num_heads
         self.cls_loss = tc.cls_loss
-        if self.cls_loss:
-            raise NotImplementedError("cls_loss=False in cfgs/pretrain/pretrain_act_distill.yaml; the shallow-hook branch is off this path")
+        self.register_shallow_hook = tc.get("register_shallow_hook", -1)
+        if self.cls_loss and not self.register_shallow_hook > 0:
+            raise ValueError("cls_loss: True needs register_shallow_hook > 0 (models/act.py:1208-1210 unpacks four encoder outputs)")
+        if self.cls_loss:                      # models/act.py:1120-1122: the model's own cls position for the shallow decoder pass
+            self.cls_pos = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+            trunc_normal_(self.cls_pos, std=.02)
         self.build_tokenizer(config.dvae_config)
         print_log(f'[ACT] divide point cloud into G{self.num_group} x S{self.group_size} points ...', logger='ACT')
-        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size,
+                                   skip_near_origin=config.dvae_config.get("fps_skip_near_origin", None))
         if self.proj_type == 'linear':
             self.proj_head = nn.Linear(self.embed_dim, config.dvae_config.tokens_dims)
         elif self.proj_type == 'conv':
@@ -442,6 +459,10 @@ class ACT_PointDistillation(nn.Module):
             self.dvae_tokenizer.load_state_dict(base_ckpt, strict=True)
             print_log(f'[dVAE] Successful Loading the ckpt for dvae from {dvae_ckpt}', logger='ACT')
         else:
+            import warnings
+            warnings.warn("ACT_PointDistillation: dvae_config.ckpt is 'none' -- the frozen teacher is RANDOMLY INITIALISED. That is what the "
+                          "synthetic benchmark and the parity tests want; real pretraining must point ckpt at a Stage-I checkpoint "
+                          "(reference default: model_zoo/ckpt_act_dvae.pth).", stacklevel=2)
             print_log('[dVAE] ckpt: none -> randomly initialised teacher (synthetic benchmark / tests)', logger='ACT')
         for param in self.dvae_tokenizer.parameters():
             param.requires_grad = False
@@ -527,7 +548,11 @@ class ACT_PointDistillation(nn.Module):
                 side.wait_stream(main)
                 with torch.cuda.stream(side), torch.no_grad():
                     teacher_feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
-        x_vis, mask = self.ACT_encoder(neighborhood, center, draws=draws)
+        if self.cls_loss:                      # models/act.py:1208-1213
+            x_vis, x_vis_cls, x_vis_shallow, mask = self.ACT_encoder(neighborhood, center, register_shallow_hook=self.register_shallow_hook,
+                                                                     draws=draws)
+        else:
+            x_vis, mask = self.ACT_encoder(neighborhood, center, draws=draws)
         B, _, C = x_vis.shape
         if not overlap:
             with torch.no_grad():
@@ -538,19 +563,27 @@ class ACT_PointDistillation(nn.Module):
         # decoder_pos_embed of [visible (ascending), masked (ascending)] centres in one launch pair
         pos_full = K.mlp(take_rows(center, torch.cat((vis_idx, msk_idx), dim=1)), dp[0].weight, dp[0].bias, dp[2].weight, dp[2].bias)
         x_full = torch.cat([x_vis, self.mask_token.expand(B, num_mask, -1)], dim=1)
-        x_rec = self.ACT_decoder(x_full, pos_full, num_mask, draws=draws)
-        if self.proj_type == 'linear':
-            student_feat = K.linear(x_rec, self.proj_head.weight, self.proj_head.bias)
-        elif self.proj_type == 'conv':
-            c = self.proj_head[0]
-            student_feat = K.linear(x_rec, c.weight.view(c.weight.shape[0], -1), c.bias)
-        else:
-            student_feat = x_rec
+        def project(x_rec):
+            if self.proj_type == 'linear':
+                return K.linear(x_rec, self.proj_head.weight, self.proj_head.bias)
+            if self.proj_type == 'conv':
+                c = self.proj_head[0]
+                return K.linear(x_rec, c.weight.view(c.weight.shape[0], -1), c.bias)
+            return x_rec
+        student_feat = project(self.ACT_decoder(x_full, pos_full, num_mask, draws=draws))
+        student_feat_global = None
+        if self.cls_loss:                      # second decoder pass on [cls, shallow visible tokens, mask tokens] (models/act.py:1231-1236)
+            x_sh = torch.cat([x_vis_cls.unsqueeze(1), x_vis_shallow, self.mask_token.expand(B, num_mask, -1)], dim=1)
+            pos_sh = torch.cat([self.cls_pos.expand(B, -1, -1), pos_full], dim=1)
+            student_feat_global = project(self.ACT_decoder(x_sh, pos_sh, num_mask, draws=draws, tag="dec_shallow"))
         if overlap:
             main.wait_stream(side)
             teacher_feat.record_stream(main)
         teacher_feat = take_rows(teacher_feat, msk_idx)
         assert teacher_feat.shape == student_feat.shape
         if self.loss_type == 'cosine':
-            return K.cosine_distill_loss(student_feat, teacher_feat)
-        return K.regression_distill_loss(student_feat, teacher_feat, self.loss_type)
+            loss = K.cosine_distill_loss(student_feat, teacher_feat)
+            if student_feat_global is not None:                          # models/act.py:1248-1249
+                loss = loss + K.cosine_distill_loss(student_feat_global, teacher_feat)
+            return loss
+        return K.regression_distill_loss(student_feat, teacher_feat, self.loss_type)   # 'l2' / 'smoothl1': the global term is not used (:1255)

@@ -27,17 +27,20 @@ def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
 class Group(nn.Module):
     """FPS centres -> kNN neighbourhoods -> centred patches (models/dvae.py:154-183), two launches."""
 
-    def __init__(self, num_group, group_size):
+    def __init__(self, num_group, group_size, skip_near_origin=None):
         super().__init__()
         self.num_group = num_group
         self.group_size = group_size
+        # None: process default (ACT_FPS_SKIP_NEAR_ORIGIN); True reproduces upstream pointnet2_ops, which never selects a point with
+        # |p|^2 <= 1e-3 (config key ``fps_skip_near_origin`` of the model / dvae_config sections, absent from the reference YAML)
+        self.skip_near_origin = skip_near_origin
         self.knn = KNN(k=self.group_size, transpose_mode=True)
 
     def forward(self, xyz):
         """xyz [B,N,3] -> neighborhood [B,G,M,3] (centred), center [B,G,3]"""
         xyz = xyz.contiguous()
         with torch.no_grad():
-            _, center = pointnet2_utils.furthest_point_sample_with_centers(xyz, self.num_group)
+            _, center = pointnet2_utils.furthest_point_sample_with_centers(xyz, self.num_group, self.skip_near_origin)
             _, neighborhood, _ = knn_group(xyz, center, self.group_size, want_nbr=True)
         return neighborhood, center
 
@@ -190,9 +193,7 @@ class Decoder(nn.Module):
         bs, g, c = feature_global.shape
         fgl = feature_global.reshape(bs * g, c)
         m = self.mlp
-        h = F.relu(K.linear(fgl, m[0].weight, m[0].bias))
-        h = F.relu(K.linear(h, m[2].weight, m[2].bias))
-        coarse = K.linear(h, m[4].weight, m[4].bias).reshape(bs * g, self.num_coarse, 3)
+        coarse = K.mlp_relu3(fgl, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias).reshape(bs * g, self.num_coarse, 3)
         S = self.grid_size ** 2
         rep = coarse.unsqueeze(2).expand(-1, -1, S, -1).reshape(bs * g * self.num_fine, 3)      # rows (group, point)
         seed = self.folding_seed.to(fgl.device).view(2, S).t()                                   # [S,2]
@@ -261,7 +262,7 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         if not self.use_deep_prompt or self.num_prompt_token <= 0:
             raise NotImplementedError("only the deep-prompt configuration of the ACT recipe is on this path")
 
-        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size, skip_near_origin=config.get("fps_skip_near_origin", None))
         self.encoder = Encoder(encoder_channel=self.encoder_dims)
         self.dgcnn_1 = DGCNN(encoder_channel=self.encoder_dims, output_channel=self.num_tokens)
         self.codebook = nn.Parameter(torch.randn(self.num_tokens, self.tokens_dims))
@@ -428,7 +429,14 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
             if g is None:
                 g = -torch.empty_like(logits).exponential_().log()
             index = ((logits + g) / tau).argmax(dim=-1)    # one-hot x codebook == row gather (models/dvae.py:587-588)
-            return F.embedding(index, self.codebook)
+            codes = F.embedding(index, self.codebook)
+            if torch.is_grad_enabled() and logits.requires_grad:
+                # straight-through estimator of F.gumbel_softmax(hard=True): y = y_hard - y_soft.detach() + y_soft, so the value is the
+                # codebook row while the gradient reaches the logits through y_soft (and the codebook only through the selected rows)
+                soft = K.gumbel_softmax(logits, tau, noise=g)
+                through = K.linear(soft, self.codebook.detach().t().contiguous(), None)
+                codes = codes + (through - through.detach())
+            return codes
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if g is None else 0       # host RNG (no device sync)
         y = K.gumbel_softmax(logits, tau, noise=g, seed=seed)                       # soft one-hot [B,G,N], noise from Philox in-kernel
         return K.linear(y, self.codebook.t().contiguous(), None)

@@ -97,6 +97,7 @@ def run_net(args, config, train_writer=None, val_writer=None, max_steps=None, lo
     base_model = builder.model_builder(config.model)
     device = torch.device("cuda", args.local_rank % max(1, torch.cuda.device_count()))
     if args.use_gpu:
+        torch.cuda.set_device(device)          # every launch goes to the current device's current stream
         base_model.to(device)
     start_epoch, best_metrics, metrics = 0, None, None
     if args.resume:

@@ -146,6 +146,7 @@ def run_net(args, config, train_writer=None, val_writer=None, max_steps=None, lo
         print_log('Training from scratch', logger=logger)
     device = torch.device("cuda", args.local_rank % max(1, torch.cuda.device_count()))
     if args.use_gpu:
+        torch.cuda.set_device(device)          # every launch goes to the current device's current stream
         base_model.to(device)
     if args.distributed:
         if args.sync_bn:

@@ -9,6 +9,7 @@ Differences forced by the hardware-first design, none of them visible in the con
   * the logged loss is all-reduced every step but read back only every ``log_every`` steps.
 """
 import time
+import weakref
 
 import torch
 import torch.nn as nn
@@ -60,19 +61,33 @@ class _Single(nn.Module):
         return self.module(*a, **k)
 
 
+class _Announced:
+    """the batch that the previous train_step already augmented (in place) and announced to the teacher prefetch: a weak reference
+    plus the tensor version right after the augmentation, so the same tensor handed back as ``points`` is not augmented twice"""
+    ref, version = None, -1
+
+    @classmethod
+    def mark(cls, t):
+        cls.ref, cls.version = weakref.ref(t), t._version
+
+    @classmethod
+    def is_marked(cls, t):
+        return cls.ref is not None and cls.ref() is t and cls.version == t._version
+
+
 def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, draws=None, next_points=None):
     """one optimisation step on a device batch [B,N,3]; returns the detached loss tensor (no host sync).
 
     ``next_points`` (optional): the NEXT batch.  It is augmented here and announced to the model, which starts its grouping and
     frozen-teacher forward on the auxiliary stream while this batch's backward runs; pass that same tensor as ``points`` of the
     next call (it is not augmented twice)."""
-    if augment and not getattr(points, "_act_augmented", False):
+    if augment and not _Announced.is_marked(points):
         points = train_transforms(points)
     loss = base_model(points, draws=draws) if draws is not None else base_model(points)
     if next_points is not None:
         if augment:
             next_points = train_transforms(next_points)
-            next_points._act_augmented = True
+            _Announced.mark(next_points)
         inner = base_model.module if hasattr(base_model, "module") else base_model
         if hasattr(inner, "prefetch_teacher"):
             inner.prefetch_teacher(next_points)
@@ -91,6 +106,7 @@ def run_net(args, config, train_writer=None, val_writer=None, max_steps=None, lo
     freeze_unused_heads(base_model)
     device = torch.device("cuda", args.local_rank % max(1, torch.cuda.device_count()))
     if args.use_gpu:
+        torch.cuda.set_device(device)          # every launch goes to the current device's current stream
         base_model.to(device)
     start_epoch, best_metrics, metrics = 0, Acc_Metric(0.), Acc_Metric(0.)
     if args.resume:

@@ -58,8 +58,36 @@ def cpu_baseline(cfg_model, seconds_budget=25.0, B=8):
     while n < 2 or (time.time() - t0 < seconds_budget and n < 8):
         step(); n += 1
     dt = (time.time() - t0) / n
-    return {"value": B / dt, "unit": "clouds/s", "cores": threads, "kind": "port",
-            "sample": f"{n} Stage-II steps (fwd+bwd+AdamW) of the pure-PyTorch CPU oracle at B={B}, N=1024, same geometry"}
+    out = {"value": B / dt, "unit": "clouds/s", "cores": threads, "kind": "port",
+           "sample": f"{n} Stage-II steps (fwd+bwd+AdamW) of the pure-PyTorch CPU oracle at B={B}, N=1024, same geometry"}
+    try:
+        out.update(cpu_group_baseline())
+    except Exception as e:
+        out["group_sample"] = f"failed: {e}"
+    return out
+
+
+def cpu_group_baseline(B=128, N=1024, G=64, M=32, reps=3):
+    """Group (FPS + kNN + gather + centre subtract) of the plain-C oracle (oracle/point_ops_c.c, OpenMP over clouds) on the host cores."""
+    import ctypes
+    import subprocess
+    import numpy as np
+    d = os.path.join(ROOT, "oracle")
+    so = os.path.join(d, "liboracle_point_ops.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", d, "-s"])
+    lib = ctypes.CDLL(so)
+    pts = synthetic_clouds(B, N, 7, "cpu").numpy()
+    c = np.empty((B, G, 3), np.float32); nb = np.empty((B, G, M, 3), np.float32)
+    f = np.empty((B, G), np.int32); k = np.empty((B, G, M), np.int64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.oracle_group_f32(P(pts), B, N, G, M, P(c), P(nb), P(f), P(k))
+    t0 = time.time()
+    for _ in range(reps):
+        lib.oracle_group_f32(P(pts), B, N, G, M, P(c), P(nb), P(f), P(k))
+    dt = (time.time() - t0) / reps
+    return {"group_Mpts_per_s": B * N / dt / 1e6, "group_ms": 1e3 * dt,
+            "group_sample": f"Group(FPS {G} + kNN {M}) on {B} x {N} clouds, plain-C oracle, OpenMP over clouds ({os.cpu_count()} host cores visible)"}
 
 
 _NEXT = None
@@ -75,6 +103,9 @@ def main():
                     help="2: Stage-II distillation step (BASELINE metric, default); 1: Stage-I autoencoder step (configs[2]); "
                          "3: PointTransformer finetune step (finetune_modelnet.yaml: 8192 raw pts -> FPS 1200 -> 1024, fwd+bwd+AdamW); "
                          "4: PointTransformer inference (eval, FPS 8192 -> 1024 + forward)")
+    ap.add_argument("--config", default="c2", choices=("c2", "c5"),
+                    help="c2: BASELINE configs[1] geometry (default, the driver's line); c5: BASELINE configs[4] stress geometry "
+                         "(N=8192 pts, 512 groups x 64 nbrs, 24-layer d=768 student, B=32/GPU) -- stage 2 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true")
     args = ap.parse_args()
@@ -103,11 +134,19 @@ def main():
     for n in ("ACT", "Transformer"):
         get_logger(n).setLevel(logging.ERROR)
 
+    c5 = args.config == "c5"
+    if c5 and args.stage != 2:
+        raise SystemExit("--config c5 is the Stage-II stress geometry (use --stage 2)")
     if args.batch is None:
-        args.batch = 32 if args.stage == 3 else 128
+        args.batch = 32 if (args.stage == 3 or c5) else 128
     if args.stage == 2:
         config = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml")
         config.model.dvae_config.ckpt = "none"
+        if c5:                                          # BASELINE configs[4]: FPS / kNN in the HBM-bound regime
+            tc, dc = config.model.transformer_config, config.model.dvae_config
+            tc.embed_dim = tc.encoder_dims = 768; tc.depth = 24; tc.num_heads = tc.decoder_num_heads = 12
+            dc.encoder_dims = dc.tokens_dims = dc.decoder_dims = 768
+            dc.num_group, dc.group_size = 512, 64
     elif args.stage == 1:
         config = cfg_from_yaml_file("cfgs/autoencoder/act_dvae_with_pretrained_transformer.yaml")
     else:
@@ -121,7 +160,7 @@ def main():
     optimizer, _ = builder.build_opti_sche(wrapped, config)
     torch.manual_seed(1234 + rank)                      # per-rank draws (main.py:67 seed + local_rank)
 
-    B, N = args.batch, 1024
+    B, N = args.batch, (8192 if c5 else 1024)
     n_raw = 8192 if args.stage >= 3 else N              # the finetune loaders hand over 8192-point clouds (ModelNet40.yaml)
     pool = [synthetic_clouds(B, n_raw, 1234 + rank * 100 + i, device) for i in range(4)]
 
@@ -166,12 +205,28 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    WIN = 50                                             # sustained-clock evidence: GPU time per window of 50 steps (hipEvents)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // WIN + 1)] if args.steps >= 2 * WIN else []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if marks and i % WIN == 0:
+            marks[i // WIN].record()
         loss = step(i)
-    host_issue = time.perf_counter() - t0                # host time to enqueue the K steps (the GPU may still be running)
+    if marks and args.steps % WIN == 0:
+        marks[args.steps // WIN].record()
+    host_issue = time.perf_counter() - t0                # wall time of the enqueue loop (includes back-pressure waits once the GPU queue is full)
     barrier()
     elapsed = time.perf_counter() - t0
+    windows = [marks[j].elapsed_time(marks[j + 1]) / WIN for j in range(len(marks) - 1)] if marks and args.steps % WIN == 0 else []
+    # host cost of ONE step against an idle GPU: nothing to wait for, so this is the pure Python + launch time
+    idle = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step(i)
+        idle.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    host_idle_ms = 1e3 * min(idle)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,7 +238,9 @@ def main():
                    3: "finetune_cls_point_clouds_per_sec", 4: "inference_cls_point_clouds_per_sec"}[args.stage], "value": B * world * args.steps / elapsed, "unit": "clouds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": ("configs[1]: ACT Stage-II pretrain step (pretrain_act_distill.yaml geometry): "
+        "config": {"workload": ("configs[4] stress: ACT Stage-II pretrain step at N=8192 pts, 512 groups x 64 nbrs, 24L d=768 student + 2L decoder, "
+                                "frozen 12L ViT-B teacher on 64 prompts + 512 tokens (random init), B=%d clouds/GPU, aug+fwd+bwd+AdamW" % B) if c5 else
+                               ("configs[1]: ACT Stage-II pretrain step (pretrain_act_distill.yaml geometry): "
                                 "B=128 clouds/GPU x 1024 pts, 64 groups x 32 nbrs, 12L d=384 student + 2L decoder, "
                                 "frozen 12L ViT-B teacher (random init), aug+fwd+bwd+AdamW") if args.stage == 2 else
                                ("PointTransformer finetune step (finetune_modelnet.yaml): B=%d clouds/GPU x 8192 raw pts -> FPS 1200 -> "
@@ -195,11 +252,18 @@ def main():
                                 "B=%d clouds/GPU x 1024 pts, tokenizer + prompt-tuned frozen ViT-B + FoldingNet, "
                                 "Chamfer-L1 + KL losses, fwd+bwd+AdamW" % B),
                    "clouds_per_gpu": B, "points_per_cloud": N, "parallelism": f"dp{world}", "final_loss": loss_val,
-                   "host_enqueue_ms_per_step": 1e3 * host_issue / args.steps,
+                   "host_enqueue_ms_per_step": host_idle_ms,
+                   "host_enqueue_note": "wall time to enqueue one whole step against an idle GPU (min of 3): pure host cost; "
+                                        "host_loop_ms_per_step is the enqueue loop of the timed region, which includes waiting on a full GPU queue",
+                   "host_loop_ms_per_step": 1e3 * host_issue / args.steps,
                    "schedule": ("every timed step = student fwd+bwd+AdamW of batch i on the main stream + grouping and frozen-teacher forward "
                                 "of batch i+1 on an auxiliary HIP stream (bit-identical to the sequential schedule; DESIGN section 4)")
                                if args.stage == 2 else "sequential; next batch's FPS prepared on an auxiliary stream (stages 3, 4)"},
     }
+
+    if windows:
+        out["sustained"] = {"window_steps": WIN, "ms_per_step_by_window": windows, "first": windows[0], "last": windows[-1],
+                            "note": "hipEvent time of consecutive 50-step windows of the timed region (clock / power drift shows as a slope)"}
 
     if rank == 0 and not args.no_instrument:
         # ---- instrumented pass: hipEvents around every launch of libact_hip.so on the launch stream --------------
@@ -265,11 +329,13 @@ def main():
             grp(gpts)
         ev1.record(); torch.cuda.synchronize()
         gms = ev0.elapsed_time(ev1) / reps
-        fps_b, knn_b = 13312.0 * B, 54016.0 * B                    # algorithmic bytes / cloud
+        G_, M_ = (512, 64) if c5 else (64, 32)
+        fps_b = (12.0 * N + 16.0 * G_) * B                          # algorithmic bytes / cloud: 13,312 (C2) / 106,496 (C5)
+        knn_b = (12.0 * N + 12.0 * G_ + 20.0 * G_ * M_) * B         # 54,016 (C2) / 759,808 (C5)
         out["group_fps_knn"] = {"Mpts_per_s": B * N / (gms * 1e-3) / 1e6, "ms": gms,
                                 "alg_GBs": (fps_b + knn_b) / (gms * 1e-3) / 1e9, "frac_hbm": (fps_b + knn_b) / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.stage == 2:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.stage == 2 and not c5:
         try:
             out["cpu_baseline"] = cpu_baseline(config.model)
         except Exception as e:                           # the baseline is a report, never a reason to lose the bench line

@@ -36,12 +36,13 @@ int         act_prof_read(int id, double* total_ms, long long* launches, double*
 /* pointnet2_ops.furthest_point_sample + gather_operation as used by misc.fps
  * (utils/misc.py:39-46; call site models/dvae.py:170).  xyz [B,N,3] -> idx int32 [B,G]
  * (idx[:,0]==0, lowest-index tie-break) and, if centers_out != NULL, centers [B,G,3]. */
+size_t act_fps_scratch_floats(int B, int N);   /* 0 for N <= 16384 (the cloud lives in registers / LDS), else B*N running distances */
 int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_out, float* centers_out,
-                int skip_near_origin, act_stream_t stream);
+                int skip_near_origin, float* scratch /* act_fps_scratch_floats floats, NULL when that is 0 */, act_stream_t stream);
 
 /* knn_cuda.KNN(k).forward fused with Group's gather + centre subtraction
  * (models/dvae.py:159,172-182; DGCNN graph k=4 models/dvae.py:23,68).
- * ref [B,N,3], query [B,Q,3], K <= 64 (any K when N > 8192) -> idx int64 ([B,Q,K], or [B,K,Q] when idx_kq != 0:
+ * ref [B,N,3], query [B,Q,3], any K <= N (K <= 64 and N <= 8192: register-resident fast path) -> idx int64 ([B,Q,K], or [B,K,Q] when idx_kq != 0:
  * transpose_mode=False layout), ascending (distance, index).
  * nbr_out  (nullable) [B,Q,K,3] = ref[idx] - query      dist_out (nullable) sqrt distance, idx layout. */
 int act_knn_group_f32(const float* ref, const float* query, int B, int N, int Q, int K,
@@ -183,6 +184,14 @@ int act_affine_act_f32(const float* x, const float* scale, const float* shift, i
 int act_bn_bwd_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean,
                    const float* rstd, int relu, int R, int C, float* dx, float* dgamma, float* dbeta,
                    float* workspace, size_t workspace_bytes, act_stream_t stream);
+/* SyncBatchNorm building blocks (the statistics are all-reduced across ranks by the host between the calls, tools/runner_pretrain.py:86-88):
+ * per-column mean / biased variance of this rank's rows; backward sums of this rank's rows; dx from the global sums over `count` rows. */
+int act_col_mean_var_f32(const float* x, int R, int C, float* mean, float* var, float* workspace, size_t workspace_bytes, act_stream_t stream);
+int act_bn_bwd_sums_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
+                        int relu, int R, int C, float* sum_dy, float* sum_dy_xhat, float* workspace, size_t workspace_bytes,
+                        act_stream_t stream);
+int act_bn_bwd_apply_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd,
+                         const float* sum_dy, const float* sum_dy_xhat, float count, int relu, int R, int C, float* dx, act_stream_t stream);
 /* torch.max over the n points of each group: in [G*n, C] -> out [G,C], arg int32 [G,C] (first maximum; nullable) */
 int act_group_max_f32(const float* in, int G, int n, int C, float* out, int32_t* arg, act_stream_t stream);
 int act_group_max_bwd_f32(const float* dout, const int32_t* arg, int G, int n, int C, int accumulate, float* din,

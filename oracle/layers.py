@@ -87,9 +87,10 @@ class Block(nn.Module):
         self.dp = float(drop_path)
         self.tag = tag
 
-    def forward(self, x, draws):
-        x = x + drop_path(self.attn(self.norm1(x)), self.dp, self.training, draws, self.tag + ".attn")
-        x = x + drop_path(self.mlp(self.norm2(x)), self.dp, self.training, draws, self.tag + ".mlp")
+    def forward(self, x, draws, tag=None):
+        tag = self.tag if tag is None else tag
+        x = x + drop_path(self.attn(self.norm1(x)), self.dp, self.training, draws, tag + ".attn")
+        x = x + drop_path(self.mlp(self.norm2(x)), self.dp, self.training, draws, tag + ".mlp")
         return x
 
 
@@ -115,9 +116,9 @@ class TransformerDecoder(BlockList):
         super().__init__(dim, depth, heads, dpr, tag=tag)
         self.norm = nn.LayerNorm(dim)
 
-    def forward(self, x, pos, return_token_num, draws):
-        for blk in self.blocks:
-            x = blk(x + pos, draws)
+    def forward(self, x, pos, return_token_num, draws, tag="dec"):
+        for i, blk in enumerate(self.blocks):
+            x = blk(x + pos, draws, f"{tag}.{i}")
         return self.norm(x[:, -return_token_num:])
 
 

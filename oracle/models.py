@@ -132,7 +132,7 @@ class VisableOnlyMaskTransformer(nn.Module):
         elif isinstance(m, nn.LayerNorm):
             nn.init.constant_(m.bias, 0); nn.init.constant_(m.weight, 1.0)
 
-    def forward(self, neighborhood, center, draws, only_cls_tokens=False, noaug=False):
+    def forward(self, neighborhood, center, draws, only_cls_tokens=False, noaug=False, register_shallow_hook=-1):
         B, G, _ = center.shape
         if noaug or self.mask_ratio == 0:
             mask = torch.zeros(B, G, dtype=torch.bool)
@@ -148,9 +148,19 @@ class VisableOnlyMaskTransformer(nn.Module):
         pos = self.pos_embed(center[~mask].reshape(B, -1, 3))
         x_vis = torch.cat((self.cls_token.expand(B, -1, -1), x_vis), dim=1)
         pos = torch.cat((self.cls_pos.expand(B, -1, -1), pos), dim=1)
-        x_vis = self.norm(self.blocks(x_vis, pos, draws))
+        shallow = None
+        if register_shallow_hook > 0:              # models/act.py:293-297: keep the output of block `hook` (before the final norm)
+            for idx, blk in enumerate(self.blocks.blocks):
+                x_vis = blk(x_vis + pos, draws)
+                if idx == register_shallow_hook:
+                    shallow = x_vis
+        else:
+            x_vis = self.blocks(x_vis, pos, draws)
+        x_vis = self.norm(x_vis)
         if only_cls_tokens:
             return self.cls_head(x_vis[:, 0])
+        if register_shallow_hook > 0:
+            return x_vis[:, 1:], x_vis[:, 0], shallow[:, 1:], mask
         return x_vis[:, 1:], mask
 
 
@@ -263,7 +273,12 @@ class ACT_PointDistillation(nn.Module):
         super().__init__()
         tc = config.transformer_config
         self.mask_ratio, self.embed_dim = tc.mask_ratio, tc.embed_dim
+        self.cls_loss = bool(tc.get("cls_loss", False)) if hasattr(tc, "get") else False
+        self.register_shallow_hook = int(tc.get("register_shallow_hook", -1)) if hasattr(tc, "get") else -1
         self.ACT_encoder = VisableOnlyMaskTransformer(config)
+        if self.cls_loss:                          # models/act.py:1120-1122: the model's own position of the cls token for the shallow pass
+            self.cls_pos = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+            trunc_normal_(self.cls_pos)
         self.dvae_tokenizer = ACTPromptedDiscreteVAEwithVIT(config.dvae_config)
         for p in self.dvae_tokenizer.parameters():
             p.requires_grad = False
@@ -286,7 +301,10 @@ class ACT_PointDistillation(nn.Module):
         if noaug:
             with torch.no_grad():
                 return self.ACT_encoder(neighborhood, center, draws, only_cls_tokens=True, noaug=True)
-        x_vis, mask = self.ACT_encoder(neighborhood, center, draws)
+        if self.cls_loss:                          # models/act.py:1208-1213
+            x_vis, x_cls, x_shallow, mask = self.ACT_encoder(neighborhood, center, draws, register_shallow_hook=self.register_shallow_hook)
+        else:
+            x_vis, mask = self.ACT_encoder(neighborhood, center, draws)
         B, _, C = x_vis.shape
         with torch.no_grad():
             teacher = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, draws)
@@ -297,7 +315,13 @@ class ACT_PointDistillation(nn.Module):
         pos_full = torch.cat([pos_vis, pos_msk], dim=1)
         student = self.proj_head(self.ACT_decoder(x_full, pos_full, num_mask, draws))
         teacher = teacher[mask].reshape(B, -1, student.shape[-1])
-        return cosine_distill_loss(student, teacher)
+        loss = cosine_distill_loss(student, teacher)
+        if self.cls_loss:                          # second decoder pass on [cls, shallow visible tokens, mask tokens] (models/act.py:1231-1236,1248-1249)
+            x_sh = torch.cat([x_cls.unsqueeze(1), x_shallow, self.mask_token.expand(B, num_mask, -1)], dim=1)
+            pos_sh = torch.cat([self.cls_pos.expand(B, -1, -1), pos_full], dim=1)
+            student_g = self.proj_head(self.ACT_decoder(x_sh, pos_sh, num_mask, draws, tag="dec_shallow"))
+            loss = loss + cosine_distill_loss(student_g, teacher)
+        return loss
 
 
 class PointTransformer(nn.Module):

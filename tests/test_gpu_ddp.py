@@ -156,3 +156,50 @@ def test_product_model_under_ddp_two_ranks_one_gpu(tmp_path):
             err = (r[rank]["grads2"][n].double() - want).abs().max().item()
             assert err <= 2e-6 * scale + 1e-9, (n, rank, err, scale)
         assert torch.equal(r[0]["grads2"][n], r[1]["grads2"][n]), n  # identical on both ranks after the all-reduce
+
+
+# ---- --sync_bn: SyncBatchNorm statistics across ranks (tools/runner_pretrain.py:86-88) -----------------------------------------
+def _sync_bn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from act_amd.models.dvae import Encoder
+    from tests.golden.fill import fill_module
+    enc = torch.nn.SyncBatchNorm.convert_sync_batchnorm(fill_module(Encoder(64), "sbn.")).to(dev).train()
+    assert isinstance(enc.first_conv[1], torch.nn.SyncBatchNorm)
+    g = torch.Generator().manual_seed(5)
+    nb_all = 0.3 * torch.randn(8, 16, 8, 3, generator=g); dout_all = torch.randn(8, 16, 64, generator=g)
+    sl = slice(4 * rank, 4 * rank + 4)
+    y = enc(nb_all[sl].to(dev))
+    y.backward(dout_all[sl].to(dev))
+    torch.cuda.synchronize()
+    torch.save({"y": y.detach().cpu(), "grads": {n: p.grad.cpu() for n, p in enc.named_parameters()},
+                "rm": enc.second_conv[1].running_mean.cpu(), "rv": enc.first_conv[1].running_var.cpu()}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equals_full_batch(tmp_path):
+    """2 ranks x 4 clouds under SyncBatchNorm == 1 process x 8 clouds under BatchNorm: outputs, running statistics, and the
+    rank-summed parameter gradients (train-mode statistics over the rows of all ranks, forward and backward)."""
+    from act_amd.models.dvae import Encoder
+    from tests.golden.fill import fill_module
+    dev = torch.device("cuda:0")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_sync_bn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"s{i}.pt") for i in range(2)]
+    enc = fill_module(Encoder(64), "sbn.").to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    nb_all = 0.3 * torch.randn(8, 16, 8, 3, generator=g); dout_all = torch.randn(8, 16, 64, generator=g)
+    y = enc(nb_all.to(dev)); y.backward(dout_all.to(dev))
+    rel = lambda a, b: ((a.double() - b.double()).abs().max() / max(1.0, b.double().abs().max().item())).item()
+    assert rel(torch.cat([r[0]["y"], r[1]["y"]]), y.detach().cpu()) <= 1e-5
+    for n, p in enc.named_parameters():
+        assert rel(r[0]["grads"][n] + r[1]["grads"][n], p.grad.cpu()) <= 2e-5, n
+    for rank in range(2):
+        assert rel(r[rank]["rm"], enc.second_conv[1].running_mean.cpu()) <= 1e-5
+        assert rel(r[rank]["rv"], enc.first_conv[1].running_var.cpu()) <= 1e-5
+    # without synchronisation the two halves would normalise with their own statistics
+    assert rel(r[0]["y"], enc(nb_all[:4].to(dev)).detach().cpu()) > 1e-3

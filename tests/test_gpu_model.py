@@ -392,3 +392,93 @@ def test_rand_mask_has_exact_count_per_row(dev):
     mk = model.ACT_encoder._mask_center_rand(center)
     assert (mk.sum(1) == int(0.75 * 16)).all()
     assert not model.ACT_encoder._mask_center_rand(center, noaug=True).any()
+
+
+def test_cls_loss_branch_golden_and_oracle(dev):
+    """transformer_config.cls_loss: True (models/act.py:1208-1249): golden g13 from the reference's own code (loss + gradient norms), and
+    every gradient element-wise against the oracle with DropPath active (second decoder pass draws its own gates)."""
+    import copy
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    g = golden("g13_cls_loss")
+    cfg = copy.deepcopy(TINY_STAGE2)
+    cfg["transformer_config"].update(depth=3, cls_loss=True, register_shallow_hook=1)
+    torch.manual_seed(0)
+    model = fill_module(build_model_from_cfg(EasyDict(cfg)), "g13.").to(dev).train()
+    model.dvae_tokenizer.prompt_dropout.p = 0.0
+    pts = torch.from_numpy(clouds(13, TINY_B, TINY_N))
+    loss = model(pts.to(dev), draws=Draws({"mask": torch.from_numpy(g["mask"]), "gumbel": _gumbel_noise((TINY_B, 16, 64))}, device=dev))
+    loss.backward()
+    assert abs(loss.item() - g["loss"][0]) <= TOL
+    pd = dict(model.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= TOL * max(1.0, v), n
+    assert _rel(pd["cls_pos"].grad, g["grad_cls_pos"]) <= TOL
+    assert sorted(k for k in model.state_dict() if not k.startswith("dvae_tokenizer.")) == [str(k) for k in g["state_dict_keys"]]
+    # DropPath on: oracle records, HIP path replays
+    cfg["transformer_config"]["drop_path_rate"] = 0.3
+    torch.manual_seed(1)
+    oracle = fill_module(OM.ACT_PointDistillation(OM.edict(cfg)), "g13dp.").train()
+    m2 = build_model_from_cfg(EasyDict(cfg)); m2.load_state_dict(oracle.state_dict(), strict=True); m2.to(dev).train()
+    rec = OL.Draws(record=True)
+    lo = oracle(pts, rec); lo.backward()
+    assert any(k.startswith("dec_shallow.") for k in rec.table)
+    lg = m2(pts.to(dev), draws=Draws(rec.table, device=dev)); lg.backward()
+    assert abs(lg.item() - lo.item()) <= TOL
+    od = dict(oracle.named_parameters())
+    for n, p in m2.named_parameters():
+        if p.requires_grad and od[n].grad is not None and p.grad is not None:
+            assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
+    with pytest.raises(Exception):
+        bad = copy.deepcopy(cfg); bad["transformer_config"]["register_shallow_hook"] = -1
+        build_model_from_cfg(EasyDict(bad))
+
+
+def test_reference_format_checkpoints_load_strictly(dev, tmp_path):
+    """SURVEY 8(f)4 / tools/builder.py:97-173, models/act.py:1153-1156: files in the reference's exact container
+    ({'base_model', 'optimizer', 'epoch', 'metrics', 'best_metrics'}, keys carrying DDP's 'module.' prefix) written from the oracle's
+    state_dict load STRICTLY through (a) dvae_config.ckpt of ACT_PointDistillation (Stage-I -> Stage-II hand-over), (b) builder.load_model,
+    (c) builder.resume_model, and the loaded product models reproduce the oracle's outputs."""
+    import argparse
+    import copy
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.tools import builder
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    torch.manual_seed(11)
+    dcfg = dict(TINY_STAGE2["dvae_config"]); dcfg["NAME"] = "ACTPromptedDiscreteVAEwithVIT"
+    o_vae = fill_module(OM.ACTPromptedDiscreteVAEwithVIT(OM.edict(dcfg)), "ck.vae.")
+    dvae_path = str(tmp_path / "ckpt_act_dvae.pth")
+    torch.save({"base_model": {"module." + k: v for k, v in o_vae.state_dict().items()}, "optimizer": {}, "epoch": 299,
+                "metrics": {"CDL1": 1.0}, "best_metrics": {"CDL1": 0.9}}, dvae_path)
+    # (a) Stage II built with dvae_config.ckpt pointing at the Stage-I file
+    cfg = copy.deepcopy(TINY_STAGE2); cfg["dvae_config"]["ckpt"] = dvae_path
+    student = build_model_from_cfg(EasyDict(cfg))
+    for k, v in o_vae.state_dict().items():
+        assert torch.equal(student.dvae_tokenizer.state_dict()[k].cpu(), v), k
+    assert not any(p.requires_grad for p in student.dvae_tokenizer.parameters())
+    # (b) + (c) a Stage-II ckpt-last.pth in the reference's format
+    o_s2 = fill_module(OM.ACT_PointDistillation(OM.edict(TINY_STAGE2)), "ck.s2.")
+    exp = tmp_path / "exp"; exp.mkdir()
+    torch.save({"base_model": {"module." + k: v for k, v in o_s2.state_dict().items()}, "optimizer": {"state": {}, "param_groups": []},
+                "epoch": 41, "metrics": {"acc": 0.0}, "best_metrics": {"acc": 12.5}}, str(exp / "ckpt-last.pth"))
+    m_load = build_model_from_cfg(EasyDict(TINY_STAGE2))
+    builder.load_model(m_load, str(exp / "ckpt-last.pth"))
+    m_res = build_model_from_cfg(EasyDict(TINY_STAGE2))
+    start, best = builder.resume_model(m_res, argparse.Namespace(experiment_path=str(exp), local_rank=0))
+    assert start == 42 and best == {"acc": 12.5}
+    bad = {"base_model": {k: v for k, v in list(o_s2.state_dict().items())[:-1]}}
+    torch.save(bad, str(tmp_path / "bad.pth"))
+    with pytest.raises(RuntimeError):                       # strict: a missing key is an error, as in the reference
+        builder.load_model(build_model_from_cfg(EasyDict(TINY_STAGE2)), str(tmp_path / "bad.pth"))
+    # the loaded product model computes what the oracle computes
+    o_s2.train(); o_s2.dvae_tokenizer.prompt_p = 0.0
+    pts = torch.from_numpy(clouds(17, TINY_B, TINY_N))
+    rec = OL.Draws(record=True)
+    lo = o_s2(pts, rec)
+    for m in (m_load, m_res):
+        m.to(dev).train(); m.dvae_tokenizer.prompt_dropout.p = 0.0
+        assert abs(m(pts.to(dev), draws=Draws(rec.table, device=dev)).item() - lo.item()) <= TOL

@@ -112,8 +112,12 @@ def test_knn_module_layouts_and_dgcnn_graph(dev):
     assert tuple(i2.shape) == (5, 4, 64) and i2.is_contiguous()
     _, i_o2 = OP.knn_ref(c, c, 4)
     assert np.array_equal(i2.cpu().numpy(), i_o2.transpose(0, 2, 1))
+    # K > 64 (beyond one winner per lane): rescan kernel, still bit-exact; K > N is an error
+    d_o3, i_o3 = OP.knn_ref(pts, q, 100)
+    d3, i3 = KNN(k=100, transpose_mode=True)(torch.from_numpy(pts).to(dev), torch.from_numpy(q).to(dev))
+    assert np.array_equal(i3.cpu().numpy(), i_o3) and np.array_equal(d3.cpu().numpy(), d_o3)
     with pytest.raises(Exception):
-        KNN(k=65, transpose_mode=True)(torch.from_numpy(pts).to(dev), torch.from_numpy(q).to(dev))
+        KNN(k=301, transpose_mode=True)(torch.from_numpy(pts).to(dev), torch.from_numpy(q).to(dev))
 
 
 def test_gather_operation_fwd_bwd(dev):
@@ -255,3 +259,36 @@ def test_maximum_sizes_stress_geometry_bit_exact(dev, oracle_c):
         assert oracle_c.oracle_knn_f32(P(pts), P(center), B, N, G, M, P(kidx), P(kd)) == 0
         _, ki = KNN(k=M, transpose_mode=True)(x, torch.from_numpy(center).to(dev))
         assert np.array_equal(ki.cpu().numpy(), kidx)
+
+
+def test_fps_upstream_compat_mode_reachable_and_quantified(dev, monkeypatch):
+    """pointnet2_ops' FPS never selects a point with |p|^2 <= 1e-3.  The switch is reachable from the config
+    (``fps_skip_near_origin``), from ``Group`` and from the environment (ACT_FPS_SKIP_NEAR_ORIGIN=1); on the benchmark distribution
+    (128 pc_norm'd gaussian clouds x 1024 points, G=64) it is reported how many clouds change at least one centre."""
+    import json
+    import os
+    from act_amd.models.dvae import Group
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    from oracle import point_ops as OP
+    pts = clouds(77, 128, 1024)
+    x = torch.from_numpy(pts).to(dev)
+    plain = pu.furthest_point_sample(x, 64).cpu().numpy()
+    compat = pu.furthest_point_sample(x, 64, skip_near_origin=True).cpu().numpy()
+    assert np.array_equal(compat[:8], OP.fps_ref(pts[:8], 64, skip_near_origin=True))
+    near = (pts ** 2).sum(-1) <= 1e-3
+    changed = int((plain != compat).any(axis=1).sum())
+    picked_near = int(np.take_along_axis(near, plain.astype(np.int64), axis=1).any(axis=1).sum())
+    assert changed == picked_near or changed >= picked_near       # a cloud changes iff the plain FPS picked a near-origin point
+    report = {"clouds": 128, "clouds_with_near_origin_points": int(near.any(axis=1).sum()), "near_origin_points": int(near.sum()),
+              "clouds_whose_centres_change": changed, "centres_changed": int((plain != compat).sum())}
+    print("FPS compat report:", json.dumps(report))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(report, open(os.path.join(out, "fps_compat_report.json"), "w"))
+    # Group / config / environment plumbing
+    _, c_plain = Group(64, 32)(x[:4])
+    _, c_compat = Group(64, 32, skip_near_origin=True)(x[:4])
+    assert np.array_equal(c_compat.cpu().numpy(), np.take_along_axis(pts[:4], compat[:4, :, None].astype(np.int64), axis=1))
+    assert np.array_equal(c_plain.cpu().numpy(), np.take_along_axis(pts[:4], plain[:4, :, None].astype(np.int64), axis=1))
+    monkeypatch.setattr(pu, "SKIP_NEAR_ORIGIN", True)
+    assert np.array_equal(pu.furthest_point_sample(x, 64).cpu().numpy(), compat)

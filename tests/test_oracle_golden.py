@@ -262,3 +262,27 @@ def test_stage1_tiny_gradient_conditioning():
     # ... while element-wise (relative to the largest element, the metric of the GPU parity tests) the two runs agree to 1e-4
     for n in a:
         assert ((a[n] - b[n]).abs().max() / max(1.0, b[n].abs().max().item())).item() <= 1e-4, n
+
+
+def _cls_loss_cfg():
+    import copy
+    cfg = copy.deepcopy(TINY_STAGE2)
+    cfg["transformer_config"].update(depth=3, cls_loss=True, register_shallow_hook=1)
+    return cfg
+
+
+def test_g13_cls_loss_branch_matches_reference():
+    """cls_loss: True (shallow hook + second decoder pass, models/act.py:1208-1249): oracle vs the reference's own forward/backward."""
+    g = golden("g13_cls_loss")
+    torch.manual_seed(0)
+    model = fill_module(M.ACT_PointDistillation(M.edict(_cls_loss_cfg())), "g13.").train()
+    model.dvae_tokenizer.prompt_p = 0.0
+    draws = L.Draws({"mask": torch.from_numpy(g["mask"]), "gumbel": _gumbel_noise((TINY_B, 16, 64))})
+    loss = model(torch.from_numpy(clouds(13, TINY_B, TINY_N)), draws)
+    loss.backward()
+    assert abs(loss.item() - g["loss"][0]) <= 1e-5
+    pd = dict(model.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 1e-4 * max(1.0, v), n
+    _close(pd["cls_pos"].grad, g["grad_cls_pos"])
+    assert sorted(k for k in model.state_dict() if not k.startswith("dvae_tokenizer.")) == [str(k) for k in g["state_dict_keys"]]
