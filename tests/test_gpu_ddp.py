@@ -197,7 +197,10 @@ def test_sync_batchnorm_two_ranks_equals_full_batch(tmp_path):
     rel = lambda a, b: ((a.double() - b.double()).abs().max() / max(1.0, b.double().abs().max().item())).item()
     assert rel(torch.cat([r[0]["y"], r[1]["y"]]), y.detach().cpu()) <= 1e-5
     for n, p in enc.named_parameters():
-        assert rel(r[0]["grads"][n] + r[1]["grads"][n], p.grad.cpu()) <= 2e-5, n
+        # relative to the per-rank summands: a conv bias in front of BatchNorm has an exactly-zero total gradient, +x on one rank, -x on the other
+        scale = max(1.0, r[0]["grads"][n].abs().max().item(), r[1]["grads"][n].abs().max().item())
+        err = (r[0]["grads"][n].double() + r[1]["grads"][n].double() - p.grad.cpu().double()).abs().max().item()
+        assert err <= 2e-5 * scale, (n, err, scale)
     for rank in range(2):
         assert rel(r[rank]["rm"], enc.second_conv[1].running_mean.cpu()) <= 1e-5
         assert rel(r[rank]["rv"], enc.first_conv[1].running_var.cpu()) <= 1e-5
