@@ -256,6 +256,175 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// "Quad-fragment" kernels for the layouts with a ROW-contiguous operand: input gradients dX = dY . W (B stored [K][N]) and weight
+// gradients dW = dY^T . X (A stored [K][M], B stored [K][N]).  No transpose anywhere: the LDS image of a row-contiguous operand
+// keeps the global [k][rows] layout (float4 -> ds_write_b128), and ONE ds_read_b128 along the rows feeds the four 16-wide blocks
+// of a wave's 64 rows for one MFMA k-step: lane (q = lane&15, g = lane>>4) reads rows 4q..4q+3 of k-row 4g+s, and element i of the
+// quad is the operand of block i, whose 16 MFMA rows are therefore the INTERLEAVED rows {4r+i}.  The interleave is undone for free
+// in the epilogue (a lane then owns 4 consecutive columns -> one float4 store instead of four scalar stores).  A K-contiguous
+// operand keeps the scheme of sgemm_nt16_kernel ([row][16 k], swizzled, one b128 = four k-steps); both use k = 4g + s for lane group
+// g at k-step s, so the two fetch schemes combine freely.  Per 16-deep K-tile: 8 ds_read_b128 for 64 MFMAs in every layout.
+// Constraint: a row-contiguous operand needs a 64-wide wave extent, i.e. BM = 128 when A is [K][M], BN = 128 when B is [K][N].
+template <int BM, int BN, bool A_K, bool B_K, bool MG = false>
+__global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
+    static_assert(A_K || BM == 128, "row-contiguous A needs BM = 128");
+    static_assert(B_K || BN == 128, "row-contiguous B needs BN = 128");
+    static_assert(!(A_K && B_K), "NT is sgemm_nt16_kernel");
+    constexpr int BK = 16;
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    int tile_m, tile_n;
+    tile_coords(p, wg, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int ntiles = (kend - kbeg) / BK;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- global -> register -> LDS staging
+    // K-contiguous operand: thread owns float4 (row = tid>>2 (+64), chunk = tid&3), swizzled 16-byte chunks (as sgemm_nt16_kernel)
+    // row-contiguous operand: thread owns float4 #(tid + 256 i) of the [16][rows] tile, stored at the same index
+    const int srow = tid >> 2, sch = tid & 3;
+    const int s_off_k = srow * 16 + 4 * (sch ^ ((4 - ((srow >> 2) & 3)) & 3));
+    const float* ga; size_t ga_step, ga_second;
+    if (A_K) {
+        const int r0 = MG ? min(m0 + srow, p.M - 1) : m0 + srow, r1 = MG ? min(m0 + srow + 64, p.M - 1) : m0 + srow + 64;
+        ga = p.A + (size_t)r0 * p.lda + kbeg + sch * 4; ga_step = BK; ga_second = (size_t)(r1 - r0) * p.lda;
+    } else {                                            // [K][M]: float4 v -> k = v / (BM/4), m4 = v % (BM/4); BM = 128: second load = +8 k-rows
+        ga = p.A + (size_t)(kbeg + tid / (BM / 4)) * p.lda + m0 + (tid % (BM / 4)) * 4; ga_step = (size_t)BK * p.lda; ga_second = (size_t)8 * p.lda;
+    }
+    const float* gb; size_t gb_step, gb_second;
+    if (B_K) {
+        gb = p.B + (size_t)(n0 + srow) * p.ldb + kbeg + sch * 4; gb_step = BK; gb_second = (size_t)64 * p.ldb;
+    } else {
+        gb = p.B + (size_t)(kbeg + tid / (BN / 4)) * p.ldb + n0 + (tid % (BN / 4)) * 4; gb_step = (size_t)BK * p.ldb; gb_second = (size_t)8 * p.ldb;
+    }
+    float4 ra0, ra1, rb0, rb1;
+    ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_g = [&](int t) {
+        ra0 = *reinterpret_cast<const float4*>(ga + t * ga_step);
+        if constexpr (NA > 1) ra1 = *reinterpret_cast<const float4*>(ga + ga_second + t * ga_step);
+        rb0 = *reinterpret_cast<const float4*>(gb + t * gb_step);
+        if constexpr (NB > 1) rb1 = *reinterpret_cast<const float4*>(gb + gb_second + t * gb_step);
+    };
+    const int sa_off = A_K ? s_off_k : tid * 4, sb_off = B_K ? s_off_k : tid * 4;
+    auto store_lds = [&](int buf) {
+        *reinterpret_cast<float4*>(&As[buf][sa_off]) = ra0;
+        if constexpr (NA > 1) *reinterpret_cast<float4*>(&As[buf][sa_off + 1024]) = ra1;
+        *reinterpret_cast<float4*>(&Bs[buf][sb_off]) = rb0;
+        if constexpr (NB > 1) *reinterpret_cast<float4*>(&Bs[buf][sb_off + 1024]) = rb1;
+    };
+
+    if (ntiles > 0) { load_g(0); store_lds(0); __syncthreads(); }
+    const int kl = lane >> 4, ml = lane & 15;
+    const int hsw = (4 - ((ml >> 2) & 3)) & 3;
+    // K-contiguous: fragment i at +i*256 floats; row-contiguous: k-step s at +s*rows floats
+    const int a_off = A_K ? (wm * (BM / 2) + ml) * 16 + 4 * (kl ^ hsw) : (4 * kl) * BM + wm * 64 + 4 * ml;
+    const int b_off = B_K ? (wn * (BN / 2) + ml) * 16 + 4 * (kl ^ hsw) : (4 * kl) * BN + wn * 64 + 4 * ml;
+    auto compute = [&](int buf) {
+        float4 af[4], bf[4];                            // A_K: af[i] = 4 k-steps of block i; else af[s] = 4 blocks of k-step s  (TM, TN <= 4)
+#pragma unroll
+        for (int i = 0; i < (A_K ? TM : 4); ++i) af[i] = *reinterpret_cast<const float4*>(&As[buf][a_off + (A_K ? i * 256 : i * BM)]);
+#pragma unroll
+        for (int j = 0; j < (B_K ? TN : 4); ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_off + (B_K ? j * 256 : j * BN)]);
+        auto el = [](const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); };
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float a = A_K ? el(af[i], s) : el(af[s], i);
+                    const float b = B_K ? el(bf[j], s) : el(bf[s], j);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
+                }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        load_g(t + 1);
+        compute(t & 1);
+        store_lds((t & 1) ^ 1);
+        __syncthreads();
+    }
+    if (ntiles > 0) compute((ntiles - 1) & 1);
+
+    // epilogue.  D layout of one 16x16 block: MFMA col = ml, MFMA row = 4*kl + reg.
+    //   actual row of (block i, MFMA row r) = A_K ? wm*BM/2 + 16 i + r : wm*64 + 4 r + i
+    //   actual col of (block j, MFMA col c) = B_K ? wn*BN/2 + 16 j + c : wn*64 + 4 c + j     (-> 4 consecutive columns per lane)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int r16 = kl * 4 + r;
+            const int row = m0 + (A_K ? wm * (BM / 2) + i * 16 + r16 : wm * 64 + 4 * r16 + i);
+            if (MG && row >= p.M) continue;
+            if constexpr (!B_K) {
+                const int col = n0 + wn * 64 + 4 * ml;
+                float4 v = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+                if (p.partial) {
+                    *reinterpret_cast<float4*>(&p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col]) = v;
+                } else {
+                    v.x = epilogue_apply(p.epi, v.x, row, col); v.y = epilogue_apply(p.epi, v.y, row, col + 1);
+                    v.z = epilogue_apply(p.epi, v.z, row, col + 2); v.w = epilogue_apply(p.epi, v.w, row, col + 3);
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
+                        float4* c4 = reinterpret_cast<float4*>(c);
+                        if (p.epi.accumulate) { const float4 o = *c4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                        *c4 = v;
+                    } else {
+                        if (p.epi.accumulate) { v.x += c[0]; v.y += c[1]; v.z += c[2]; v.w += c[3]; }
+                        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * (BN / 2) + j * 16 + ml;
+                    float v = acc[i][j][r];
+                    if (p.partial) p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                    else {
+                        v = epilogue_apply(p.epi, v, row, col);
+                        float* c = p.C + (size_t)row * p.ldc + col;
+                        if (p.epi.accumulate) v += *c;
+                        *c = v;
+                    }
+                }
+            }
+        }
+}
+
+// tile: 0 = 128x128, 1 = 64x128 (NN only: A K-contiguous).  Returns false when the combination does not exist.
+bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s) {
+    if (a_kmajor && b_kmajor) return false;
+    if (b_kmajor) return false;                                       // (A [K][M], B [N][K]) never occurs on this path
+    if (a_kmajor) {                                                   // NN: dX = dY . W
+        const int bm = tile == 1 ? 64 : 128;
+        if (p.M % bm != 0) {
+            if (tile == 1) hipLaunchKernelGGL((sgemm_q16_kernel<64, 128, true, false, true>), grid, dim3(256), 0, s, p);
+            else           hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, true, false, true>), grid, dim3(256), 0, s, p);
+        } else {
+            if (tile == 1) hipLaunchKernelGGL((sgemm_q16_kernel<64, 128, true, false>), grid, dim3(256), 0, s, p);
+            else           hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, true, false>), grid, dim3(256), 0, s, p);
+        }
+        return true;
+    }
+    if (tile != 0) return false;                                      // TN: dW = dY^T . X, 128x128 only
+    hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, false, false>), grid, dim3(256), 0, s, p);
+    return true;
+}
+
 template <int BM, int BN>
 static void launch16(const GemmParams& p, int ak, int bk, dim3 grid, hipStream_t s) {
     if (p.M % BM != 0) {                                 // M tail: A must be K-major (rows = tokens)

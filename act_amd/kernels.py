@@ -194,6 +194,12 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
             cands += [(tile + 6, s) for s in sp_list if (K // s) % 32 == 0]                  # v_mfma_f32_16x16x4_f32 main loop
             if ak and bk:
                 cands += [(tile + 9, s) for s in sp_list if (K // s) % 32 == 0]              # NT: K-contiguous LDS image, b128 fragments
+        if not bk and N % 128 == 0 and K % 32 == 0 and ((tile == 1 and (ak or M % 128 == 0)) or (tile == 2 and ak)):
+            qsp = [1]
+            nbq = -(-M // (128 if tile == 1 else 64)) * (N // 128)
+            if K >= 1024 and nbq < 2048:
+                qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
+            cands += [(12 + tile, s) for s in qsp if (K // s) % 32 == 0]                     # NN / TN: quad fragments (13: 128x128, 14: 64x128)
     scratch = torch.empty(M, N, dtype=torch.float32, device=a.device)
     e = GemmEpilogue(alpha=1.0)
     best, best_t = (0, 0), float("inf")

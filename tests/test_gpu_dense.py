@@ -578,3 +578,47 @@ def test_gemm_explicit_configs_and_pipelined_loop(K, tile):
     for Kd2 in (32, 64, 96, 160):
         a2 = _rnd(f"cf.a{Kd2}", 256, Kd2); b2 = _rnd(f"cf.b{Kd2}", 128, Kd2)
         assert _rel(K.gemm(a2.cuda(), b2.cuda(), cfg=(tile, 1)), a2.double() @ b2.double().t()) <= 2e-5
+
+
+@pytest.mark.parametrize("tile", [13, 14])
+def test_gemm_quad_fragment_kernels_nn_tn(K, tile):
+    """tiles 13 / 14: the ds_read_b128 kernels of the layouts with a row-contiguous operand (input gradients NN, weight gradients
+    TN): column-/row-interleaved MFMA blocks, float4 epilogue, split-K, M tail (NN), fused epilogues, strided B, accumulate."""
+    M, N, Kd = 512, 384, 1024
+    a = _rnd("q.a", M, Kd); b = _rnd("q.b", N, Kd)
+    ref = a.double() @ b.double().t()
+    for sp in (1, 2, 4):
+        assert _rel(K.gemm(a.cuda(), b.t().contiguous().cuda(), True, False, cfg=(tile, sp)), ref) <= 2e-5, (tile, "nn", sp)
+        if tile == 13:
+            assert _rel(K.gemm(a.t().contiguous().cuda(), b.t().contiguous().cuda(), False, False, cfg=(tile, sp)), ref) <= 2e-5, (tile, "tn", sp)
+    with pytest.raises(Exception):
+        K.gemm(a.cuda(), b.cuda(), True, True, cfg=(tile, 1))                         # NT has its own kernel
+    if tile == 14:
+        with pytest.raises(Exception):
+            K.gemm(a.t().contiguous().cuda(), b.t().contiguous().cuda(), False, False, cfg=(tile, 1))
+    # asymmetric operands, single / odd tile counts along K
+    for Kd2 in (32, 96, 160):
+        a2 = _rnd(f"q.a{Kd2}", 256, Kd2); b2 = _rnd(f"q.b{Kd2}", 128, Kd2)
+        assert _rel(K.gemm(a2.cuda(), b2.t().contiguous().cuda(), True, False, cfg=(tile, 1)), a2.double() @ b2.double().t()) <= 2e-5
+    # M tail on the NN layout (rows = tokens), guarded stores
+    for Mt in (2080, 200, 65):
+        at = _rnd(f"q.at{Mt}", Mt, Kd); reft = at.double() @ b.double().t()
+        bt = b.t().contiguous().cuda()
+        for sp in (1, 3):
+            assert _rel(K.gemm(at.cuda(), bt, True, False, cfg=(tile, sp)), reft) <= 2e-5, (tile, Mt, sp)
+        guard = torch.full((Mt + 4, N), 7.0, device="cuda")
+        K.gemm(at.cuda(), bt, True, False, out=guard[:Mt], cfg=(tile, 1))
+        assert (guard[Mt:] == 7.0).all() and _rel(guard[:Mt], reft) <= 2e-5
+    # fused epilogue of the input-gradient GEMM: x gelu'(aux), row gate, residual; accumulate; strided B (column slice of a weight)
+    aux = _rnd("q.aux", M, N).cuda(); gate = (torch.arange(M // 32) % 3).float().cuda() / 0.9; res = _rnd("q.res", M, N).cuda()
+    c = K.gemm(a.cuda(), b.t().contiguous().cuda(), True, False, act=K.EPI_MUL_GELU_GRAD, aux=aux, rowscale=gate, rows_per_scale=32, res=res,
+               cfg=(tile, 1))
+    x = aux.double().cpu()
+    gp = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
+    want = ref * gp * gate.double().cpu().repeat_interleave(32)[:, None] + res.double().cpu()
+    assert _rel(c, want) <= 2e-5
+    base = _rnd("q.base", M, N).cuda()
+    c2 = K.gemm(a.cuda(), b.t().contiguous().cuda(), True, False, out=base.clone(), accumulate=True, alpha=0.5, cfg=(tile, 1))
+    assert _rel(c2, 0.5 * ref + base.double().cpu()) <= 2e-5
+    wide = _rnd("q.wide", Kd, 512).cuda()                                             # B = wide[:, 128:512] : [K][N] with ldb = 512
+    assert _rel(K.gemm(a.cuda(), wide[:, 128:], True, False, cfg=(tile, 1)), a.double() @ wide[:, 128:].double().cpu()) <= 2e-5
