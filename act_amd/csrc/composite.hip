@@ -11,6 +11,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <vector>
+#include <stdlib.h>
 
 #define CK(expr) do { const int rc__ = (expr); if (rc__ != 0) return rc__; } while (0)
 // every non-GEMM launch goes through RUN: skipped while the calling thread collects the GEMM shapes of a composite (see below)
@@ -347,25 +348,47 @@ int act_prefix_vit_fwd_f32(const act_prefix_vit_t* m, const float* tokens, const
 }
 
 // ============================================================================================== mini-PointNet (Encoder)
+// Two launch schedules, chosen from the dimensions alone (so saved / scratch sizes are a function of the dims):
+//  * fused (n in {32, 64}, rows % 128 == 0, C % 64 == 0; ACT_PN_FUSE=0 disables): BatchNorm + ReLU are applied while the NEXT conv stages
+//    its A operand (a1 / a3 never exist), BatchNorm-2 statistics come out of the epilogue of the conv that produces its input, both
+//    max-pools are epilogues (the 512 -> C conv does not even store its output), and the weight gradients of the convs behind a
+//    BatchNorm recompute the activated operand on load.  Per forward: 2 statistics passes, 2 apply passes, 2 max-pool passes and the
+//    h4 store (1.4 ms of the 35 ms Stage-II step for the two encoders) disappear.
+//  * plain: one kernel per layer (tiny test geometries, odd channel counts).
 namespace {
-struct PnSaved { float *h1, *a1, *h2, *fg, *gw, *h3, *a3, *h4, *st1, *st2; int32_t *arg1, *arg2; };   // st* = mean | rstd | scale | shift
+struct PnSaved { float *h1, *a1, *h2, *fg, *gw, *h3, *a3, *h4, *st1, *st2, *tstats; int32_t *arg1, *arg2; };   // st* = mean | rstd | scale | shift
+bool pn_fused(const act_pointnet_dims_t& d) {
+    static const bool on = [] { const char* e = getenv("ACT_PN_FUSE"); return !(e && e[0] == '0'); }();
+    const long long R = (long long)d.BG * d.n;
+    return on && (d.n == 32 || d.n == 64) && R % 128 == 0 && d.C % 64 == 0;
+}
 size_t carve_pn(float* base, const act_pointnet_dims_t& d, PnSaved& sv) {
     const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
+    const bool fused = pn_fused(d);
     Carver c(base);
-    sv.h1 = c.take(R * 128); sv.a1 = c.take(R * 128); sv.h2 = c.take(R * 256); sv.fg = c.take(BG * 256); sv.gw = c.take(BG * 512);
-    sv.h3 = c.take(R * 512); sv.a3 = c.take(R * 512); sv.h4 = c.take(R * C); sv.st1 = c.take(4 * 128); sv.st2 = c.take(4 * 512);
+    sv.h1 = c.take(R * 128); sv.h2 = c.take(R * 256); sv.fg = c.take(BG * 256); sv.gw = c.take(BG * 512); sv.h3 = c.take(R * 512);
+    sv.st1 = c.take(4 * 128); sv.st2 = c.take(4 * 512);
     sv.arg1 = reinterpret_cast<int32_t*>(c.take(BG * 256)); sv.arg2 = reinterpret_cast<int32_t*>(c.take(BG * C));
+    if (fused) { sv.a1 = sv.a3 = sv.h4 = nullptr; sv.tstats = c.take(act_sgemm_fx_tile_stats_floats((int)R, 512)); }
+    else { sv.a1 = c.take(R * 128); sv.a3 = c.take(R * 512); sv.h4 = c.take(R * C); sv.tstats = nullptr; }
     return c.used;
 }
-struct PnBwdScratch { float *dh4, *da3, *dh3, *dgw, *dh2, *dfg, *da1, *dh1; };
+struct PnBwdScratch { float *dh4, *da3, *dh3, *dgw, *dh2, *dfg, *da1, *dh1, *act; };
 size_t carve_pn_bwd(float* base, const act_pointnet_dims_t& d, PnBwdScratch& sc) {
     const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
     Carver c(base);
     sc.dh4 = c.take(R * C); sc.da3 = c.take(R * 512); sc.dh3 = c.take(R * 512); sc.dgw = c.take(BG * 512); sc.dh2 = c.take(R * 256);
     sc.dfg = c.take(BG * 256); sc.da1 = c.take(R * 128); sc.dh1 = c.take(R * 128);
+    sc.act = (pn_fused(d) && d.C % 128 != 0) ? c.take(R * 512) : nullptr;      // a3 rebuilt for the one weight gradient the fused TN kernel cannot take
     return c.used;
 }
 bool bad_pn(const act_pointnet_dims_t* d) { return !d || d->BG <= 0 || d->n <= 0 || d->C <= 0 || (d->C & 3); }
+
+int gemm_fx(int ak, int bk, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, const act_gemm_epilogue_t& e,
+            const act_gemm_fx_t& fx, float* ws, size_t wsb, hipStream_t s) {
+    if (collecting(ak, bk, M, N, K)) return 0;          // (fused kernels pick their own tile; recorded for completeness)
+    return act_sgemm_fx_f32(ak, bk, M, N, K, A, lda, B, ldb, C, ldc, &e, &fx, ws, wsb, s);
+}
 }  // namespace
 
 size_t act_pointnet_saved_floats(const act_pointnet_dims_t* d) { if (bad_pn(d)) return 0; PnSaved sv; return carve_pn(nullptr, *d, sv); }
@@ -377,33 +400,59 @@ int act_pointnet_fwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params
     if (bad_pn(d)) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const int BG = d->BG, n = d->n, C = d->C, R = BG * n;
+    const bool fused = pn_fused(*d);
     PnSaved sv; carve_pn(saved, *d, sv);
-    auto bn = [&](const float* h, int Cc, const float* gw_, const float* gb_, float* rm, float* rv, float eps, float mom, float* st, float* a) -> int {
-        float *mean = st, *rstd = st + Cc, *scale = st + 2 * Cc, *shift = st + 3 * Cc;
+    float *scale1 = sv.st1 + 2 * 128, *shift1 = sv.st1 + 3 * 128, *scale2 = sv.st2 + 2 * 512, *shift2 = sv.st2 + 3 * 512;
+    // statistics of a tensor that is already in HBM (BatchNorm-1 always: its producer is the K = 3 conv; BatchNorm-2 on the plain schedule)
+    auto stats = [&](const float* h, int Cc, const float* g_, const float* b_, float* rm, float* rv, float eps, float mom, float* st) -> int {
         if (training) {
             if (wsb < act_colstats_workspace(R, Cc)) return ACT_E_BADARG;
-            RUN(act_bn_stats_f32(h, R, Cc, gw_, gb_, eps, mom, rm, rv, mean, rstd, scale, shift, ws, wsb, s));
+            RUN(act_bn_stats_f32(h, R, Cc, g_, b_, eps, mom, rm, rv, st, st + Cc, st + 2 * Cc, st + 3 * Cc, ws, wsb, s));
         } else {
-            RUN(act_bn_eval_affine_f32(gw_, gb_, rm, rv, eps, Cc, scale, shift, s));
+            RUN(act_bn_eval_affine_f32(g_, b_, rm, rv, eps, Cc, st + 2 * Cc, st + 3 * Cc, s));
         }
-        RUN(act_affine_act_f32(h, scale, shift, 1, R, Cc, a, s));
         return 0;
     };
     act_gemm_epilogue_t e = epi0(); e.bias = w->c1_b;
     CK(gemm_nt(R, 128, 3, x, 3, w->c1_w, 3, sv.h1, 128, e, ws, wsb, s));
-    CK(bn(sv.h1, 128, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, d->eps1, d->momentum1, sv.st1, sv.a1));
-    e = epi0(); e.bias = w->c2_b;
-    CK(gemm_nt(R, 256, 128, sv.a1, 128, w->c2_w, 128, sv.h2, 256, e, ws, wsb, s));
-    RUN(act_group_max_f32(sv.h2, BG, n, 256, sv.fg, sv.arg1, s));
+    CK(stats(sv.h1, 128, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, d->eps1, d->momentum1, sv.st1));
+    if (!fused) {
+        RUN(act_affine_act_f32(sv.h1, scale1, shift1, 1, R, 128, sv.a1, s));
+        e = epi0(); e.bias = w->c2_b;
+        CK(gemm_nt(R, 256, 128, sv.a1, 128, w->c2_w, 128, sv.h2, 256, e, ws, wsb, s));
+        RUN(act_group_max_f32(sv.h2, BG, n, 256, sv.fg, sv.arg1, s));
+    } else {                                            // conv 128->256 on relu(bn1(h1)) applied on load; max over the group in the epilogue
+        act_gemm_fx_t fx{}; fx.a_scale = scale1; fx.a_shift = shift1; fx.gmax = sv.fg; fx.garg = sv.arg1; fx.group = n; fx.store_c = 1;
+        e = epi0(); e.bias = w->c2_b;
+        CK(gemm_fx(1, 1, R, 256, 128, sv.h1, 128, w->c2_w, 128, sv.h2, 256, e, fx, ws, wsb, s));
+    }
     // conv 512->512 on cat(global, local): the global half once per group, broadcast-added in the epilogue of the local half
     e = epi0(); e.bias = w->c3_b;
     CK(gemm_nt(BG, 512, 256, sv.fg, 256, w->c3_w, 512, sv.gw, 512, e, ws, wsb, s));
     e = epi0(); e.res = sv.gw; e.ldr = 512; e.res_row_div = n;
-    CK(gemm_nt(R, 512, 256, sv.h2, 256, w->c3_w + 256, 512, sv.h3, 512, e, ws, wsb, s));
-    CK(bn(sv.h3, 512, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, d->eps2, d->momentum2, sv.st2, sv.a3));
-    e = epi0(); e.bias = w->c4_b;
-    CK(gemm_nt(R, C, 512, sv.a3, 512, w->c4_w, 512, sv.h4, C, e, ws, wsb, s));
-    RUN(act_group_max_f32(sv.h4, BG, n, C, out, keep_for_backward ? sv.arg2 : nullptr, s));
+    if (!fused) {
+        CK(gemm_nt(R, 512, 256, sv.h2, 256, w->c3_w + 256, 512, sv.h3, 512, e, ws, wsb, s));
+        CK(stats(sv.h3, 512, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, d->eps2, d->momentum2, sv.st2));
+        RUN(act_affine_act_f32(sv.h3, scale2, shift2, 1, R, 512, sv.a3, s));
+        e = epi0(); e.bias = w->c4_b;
+        CK(gemm_nt(R, C, 512, sv.a3, 512, w->c4_w, 512, sv.h4, C, e, ws, wsb, s));
+        RUN(act_group_max_f32(sv.h4, BG, n, C, out, keep_for_backward ? sv.arg2 : nullptr, s));
+        return 0;
+    }
+    if (training) {                                     // BatchNorm-2 statistics from the epilogue of the conv that produces h3
+        act_gemm_fx_t fx{}; fx.tile_stats = sv.tstats; fx.store_c = 1;
+        CK(gemm_fx(1, 1, R, 512, 256, sv.h2, 256, w->c3_w + 256, 512, sv.h3, 512, e, fx, ws, wsb, s));
+        RUN(act_bn_tiles_finalize_f32(sv.tstats, R / 128, 128, 512, w->bn2_w, w->bn2_b, d->eps2, d->momentum2, w->bn2_mean, w->bn2_var, sv.st2, sv.st2 + 512,
+                                      scale2, shift2, s));
+    } else {
+        CK(gemm_nt(R, 512, 256, sv.h2, 256, w->c3_w + 256, 512, sv.h3, 512, e, ws, wsb, s));
+        RUN(act_bn_eval_affine_f32(w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, d->eps2, 512, scale2, shift2, s));
+    }
+    {   // conv 512->C on relu(bn2(h3)) applied on load; only the max over the group leaves the kernel
+        act_gemm_fx_t fx{}; fx.a_scale = scale2; fx.a_shift = shift2; fx.gmax = out; fx.garg = keep_for_backward ? sv.arg2 : nullptr; fx.group = n; fx.store_c = 0;
+        e = epi0(); e.bias = w->c4_b;
+        CK(gemm_fx(1, 1, R, C, 512, sv.h3, 512, w->c4_w, 512, nullptr, C, e, fx, ws, wsb, s));
+    }
     return 0;
 }
 
@@ -413,15 +462,27 @@ int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params
     if (bad_pn(d)) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     const int BG = d->BG, n = d->n, C = d->C, R = BG * n;
+    const bool fused = pn_fused(*d);
     PnSaved sv; carve_pn(const_cast<float*>(saved), *d, sv);
     PnBwdScratch sc; carve_pn_bwd(scratch, *d, sc);
     auto st = [](float* base, int Cc, int which) { return base + which * Cc; };               // 0 mean, 1 rstd, 2 scale, 3 shift
+    // dW = dY^T . relu(bn(h)) for a conv behind a BatchNorm: the activated operand is kept (plain) or recomputed while it is staged (fused)
+    auto wgrad_act = [&](const float* dy, int N_, const float* h, const float* a, float* stt, int Cc, float* dw) -> int {
+        if (!fused) return gemm_tn(N_, Cc, R, dy, N_, a, Cc, dw, Cc, ws, wsb, s);
+        if (N_ % 128 == 0 && Cc % 128 == 0) {
+            act_gemm_fx_t fx{}; fx.b_scale = st(stt, Cc, 2); fx.b_shift = st(stt, Cc, 3);
+            return gemm_fx(0, 0, N_, Cc, R, dy, N_, h, Cc, dw, Cc, epi0(), fx, ws, wsb, s);
+        }
+        RUN(act_affine_act_f32(h, st(stt, Cc, 2), st(stt, Cc, 3), 1, R, Cc, sc.act, s));
+        return gemm_tn(N_, Cc, R, dy, N_, sc.act, Cc, dw, Cc, ws, wsb, s);
+    };
     RUN(act_group_max_bwd_f32(dout, sv.arg2, BG, n, C, 0, sc.dh4, s));
-    CK(gemm_tn(C, 512, R, sc.dh4, C, sv.a3, 512, g->c4_w, 512, ws, wsb, s));
-    CK(colsum(sc.dh4, R, C, g->c4_b, ws, wsb, s));
+    CK(wgrad_act(sc.dh4, C, sv.h3, sv.a3, sv.st2, 512, g->c4_w));
+    if (fused) CK(colsum(dout, BG, C, g->c4_b, ws, wsb, s));                                  // sum_r dh4[r,c] = sum_g dout[g,c]
+    else       CK(colsum(sc.dh4, R, C, g->c4_b, ws, wsb, s));
     CK(gemm_nn(R, 512, C, sc.dh4, C, w->c4_w, 512, sc.da3, 512, epi0(), ws, wsb, s));
     RUN(act_bn_bwd_f32(sv.h3, sc.da3, st(sv.st2, 512, 2), st(sv.st2, 512, 3), st(sv.st2, 512, 0), st(sv.st2, 512, 1), 1, R, 512, sc.dh3, g->bn2_w, g->bn2_b,
-                      ws, wsb, s));
+                       ws, wsb, s));
     // the two column halves of dW3 [512, 512]: [:, :256] from the per-group path, [:, 256:] from the per-point path
     CK(gemm_tn(512, 256, R, sc.dh3, 512, sv.h2, 256, g->c3_w + 256, 512, ws, wsb, s));
     RUN(act_group_sum_f32(sc.dh3, BG, n, 512, sc.dgw, s));
@@ -430,11 +491,11 @@ int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params
     CK(colsum(sc.dgw, BG, 512, g->c3_b, ws, wsb, s));
     CK(gemm_nn(BG, 256, 512, sc.dgw, 512, w->c3_w, 512, sc.dfg, 256, epi0(), ws, wsb, s));
     RUN(act_group_max_bwd_f32(sc.dfg, sv.arg1, BG, n, 256, 1, sc.dh2, s));
-    CK(gemm_tn(256, 128, R, sc.dh2, 256, sv.a1, 128, g->c2_w, 128, ws, wsb, s));
+    CK(wgrad_act(sc.dh2, 256, sv.h1, sv.a1, sv.st1, 128, g->c2_w));
     CK(colsum(sc.dh2, R, 256, g->c2_b, ws, wsb, s));
     CK(gemm_nn(R, 128, 256, sc.dh2, 256, w->c2_w, 128, sc.da1, 128, epi0(), ws, wsb, s));
     RUN(act_bn_bwd_f32(sv.h1, sc.da1, st(sv.st1, 128, 2), st(sv.st1, 128, 3), st(sv.st1, 128, 0), st(sv.st1, 128, 1), 1, R, 128, sc.dh1, g->bn1_w, g->bn1_b,
-                      ws, wsb, s));
+                       ws, wsb, s));
     CK(gemm_tn(128, 3, R, sc.dh1, 128, x, 3, g->c1_w, 3, ws, wsb, s));
     CK(colsum(sc.dh1, R, 128, g->c1_b, ws, wsb, s));
     return 0;

@@ -356,7 +356,7 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     if (M < 0 || N < 0 || K < 0) return ACT_E_BADARG;
     if (M == 0 || N == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    GemmParams p;
+    GemmParams p{};
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     if (epi_in) p.epi = *epi_in;
     else { p.epi = act_gemm_epilogue_t{}; p.epi.alpha = 1.0f; }
@@ -473,4 +473,62 @@ extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, co
     int tile = 0, splits = 0;
     if (act_gemm_tune_get(a_kmajor, b_kmajor, M, N, K, &tile, &splits) != 0) { tile = 0; splits = 0; }
     return act_sgemm_ex_f32(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, epi_in, workspace, workspace_bytes, tile, splits, stream);
+}
+
+
+// ---- GEMM with fused producer / consumer passes (mini-PointNet, see GemmFx in gemm_common.h) ---------------------------------------
+extern "C" size_t act_sgemm_fx_tile_stats_floats(int M, int N) { return (size_t)((M + 127) / 128) * 2 * N; }
+
+extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                const act_gemm_epilogue_t* epi_in, const act_gemm_fx_t* fx, float* workspace, size_t workspace_bytes,
+                                act_stream_t stream) {
+    if (!A || !B || !fx) return ACT_E_NULLPTR;
+    if (M <= 0 || N <= 0 || K <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    GemmParams p{};
+    p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    if (epi_in) p.epi = *epi_in; else p.epi.alpha = 1.0f;
+    p.fx.a_scale = fx->a_scale; p.fx.a_shift = fx->a_shift; p.fx.b_scale = fx->b_scale; p.fx.b_shift = fx->b_shift;
+    p.fx.tile_stats = fx->tile_stats; p.fx.gmax = fx->gmax; p.fx.garg = fx->garg; p.fx.group = fx->group; p.fx.store_c = fx->store_c;
+    static const int group_m_env = [] { const char* e = getenv("ACT_GEMM_GROUP_M"); return e ? atoi(e) : 8; }();
+    p.group_m = group_m_env;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && (lda & 3) == 0 && (ldb & 3) == 0;
+    if (!aligned) return ACT_E_BADARG;
+    if (a_kmajor && b_kmajor) {                                        // forward conv: A-side affine + ReLU, column statistics, group max
+        int mask = 0;
+        if (fx->a_scale) { if (!fx->a_shift || K > 1024) return ACT_E_BADARG; mask |= FX_AFFINE_A; }
+        if (fx->tile_stats) mask |= FX_COLSTATS;
+        if (fx->gmax) { if (fx->group != 32 && fx->group != 64) return ACT_E_BADARG; mask |= FX_GROUPMAX; if (!fx->store_c) mask |= FX_NOSTORE; }
+        if (mask == 0 || (M % 128) || (K % 16) || (N % 64)) return ACT_E_BADARG;
+        if (!(mask & FX_NOSTORE) && !C) return ACT_E_NULLPTR;
+        const int tile = (N % 128 == 0) ? 0 : 1, BN = tile == 0 ? 128 : 64;
+        p.tiles_m = M / 128; p.tiles_n = N / BN; p.k_per_split = K; p.partial = nullptr;
+        ActProfScope ps(KID_GEMM_NT, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + ((mask & FX_NOSTORE) ? 0.0 : (double)M * N)));
+        if (!launch_sgemm_nt16_fx(p, tile, mask, dim3((unsigned)(p.tiles_m * p.tiles_n)), s)) return ACT_E_BADARG;
+        ACT_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!a_kmajor && !b_kmajor) {                                      // weight gradient with the B operand activated on load
+        if (!fx->b_scale || !fx->b_shift || !C) return ACT_E_NULLPTR;
+        if ((M % 128) || (N % 128) || (K % 32)) return ACT_E_BADARG;
+        p.tiles_m = M / 128; p.tiles_n = N / 128;
+        const long long nt = (long long)p.tiles_m * p.tiles_n;
+        int splits = (int)((768 + nt - 1) / nt);                       // ~3 workgroups per CU; K = rows of the batch, a few hundred thousand
+        if (splits > 64) splits = 64;
+        while (splits > 1 && (K / splits < 256 || (size_t)splits * M * N * sizeof(float) > workspace_bytes)) --splits;
+        int kps = (K + splits - 1) / splits; kps = (kps + 31) / 32 * 32; splits = (K + kps - 1) / kps;
+        if (splits > 1 && !workspace) return ACT_E_NULLPTR;
+        p.k_per_split = kps; p.partial = splits > 1 ? workspace : nullptr;
+        ActProfScope ps(KID_GEMM_TN, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        launch_sgemm_q16_tn_fx(p, dim3((unsigned)nt, 1, (unsigned)splits), s);
+        ACT_LAUNCH_CHECK();
+        if (splits > 1) {
+            const long long total = (long long)M * N;
+            long long g = (total + 255) / 256; if (g > 4096) g = 4096;
+            hipLaunchKernelGGL(sgemm_splitk_reduce, dim3((unsigned)g), dim3(256), 0, s, workspace, splits, M, N, C, ldc, p.epi);
+            ACT_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    return ACT_E_BADARG;
 }

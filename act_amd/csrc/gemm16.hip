@@ -145,13 +145,19 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
 // Bank conflicts of the b128 reads (serviced in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) are removed
 // by XOR-swizzling the 16-byte chunk index with H[(row>>2)&3], H = {0,3,2,1}.  The main loop then contains no VALU address
 // arithmetic at all (row-block strides are ds_read immediates) and 4x fewer LDS instructions than the [k][row] kernels.
-template <int BM, int BN, bool MG = false>
+// FX (mini-PointNet fusions, BM = 128 only): FX_AFFINE_A applies the producer's BatchNorm + ReLU to A while it is staged (the activated
+// tensor never exists in HBM); FX_COLSTATS leaves per-tile column (mean, sum of squared deviations) of the stored values for the
+// following BatchNorm (no statistics pass over the output); FX_GROUPMAX reduces every `group` consecutive rows to their max / first
+// arg-max (the max-pool over the points of a group) in the epilogue; FX_NOSTORE drops the C store when only that max is wanted.
+template <int BM, int BN, bool MG = false, int FX = 0>
 __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) {
     constexpr int BK = 16;
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;
+    static_assert(FX == 0 || (BM == 128 && !MG), "fused variants: 128-row tiles, no M tail");
     __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
+    __shared__ __attribute__((aligned(16))) float Sx[(FX & FX_AFFINE_A) ? 2048 : 4];      // scale[K] | shift[K] of the A-side affine map (K <= 1024)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -187,7 +193,21 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
         rb0 = *reinterpret_cast<const float4*>(gb + t * BK);
         if constexpr (NB > 1) rb1 = *reinterpret_cast<const float4*>(gb + stride_b + t * BK);
     };
-    auto store_lds = [&](int buf) {
+    if constexpr ((FX & FX_AFFINE_A) != 0) {
+        for (int k = tid; k < p.K; k += 256) { Sx[k] = p.fx.a_scale[k]; Sx[1024 + k] = p.fx.a_shift[k]; }
+        __syncthreads();
+    }
+    auto store_lds = [&](int buf, int t) {
+        if constexpr ((FX & FX_AFFINE_A) != 0) {                      // A' = relu(A * scale[k] + shift[k]) for this thread's 4 k of tile t
+            const float4 sc = *reinterpret_cast<const float4*>(&Sx[kbeg + t * BK + sch * 4]);
+            const float4 sh = *reinterpret_cast<const float4*>(&Sx[1024 + kbeg + t * BK + sch * 4]);
+            ra0.x = fmaxf(ra0.x * sc.x + sh.x, 0.f); ra0.y = fmaxf(ra0.y * sc.y + sh.y, 0.f);
+            ra0.z = fmaxf(ra0.z * sc.z + sh.z, 0.f); ra0.w = fmaxf(ra0.w * sc.w + sh.w, 0.f);
+            if constexpr (NA > 1) {
+                ra1.x = fmaxf(ra1.x * sc.x + sh.x, 0.f); ra1.y = fmaxf(ra1.y * sc.y + sh.y, 0.f);
+                ra1.z = fmaxf(ra1.z * sc.z + sh.z, 0.f); ra1.w = fmaxf(ra1.w * sc.w + sh.w, 0.f);
+            }
+        }
         *reinterpret_cast<float4*>(&As[buf][s_off]) = ra0;
         if constexpr (NA > 1) *reinterpret_cast<float4*>(&As[buf][s_off + 1024]) = ra1;
         *reinterpret_cast<float4*>(&Bs[buf][s_off]) = rb0;
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
 
     if (ntiles > 0) {
         load_g(0);
-        store_lds(0);
+        store_lds(0, 0);
         __syncthreads();
     }
     const int kl = lane >> 4, ml = lane & 15;
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
     for (int t = 0; t + 1 < ntiles; ++t) {              // steady state: fetch tile t+1 while computing tile t
         load_g(t + 1);
         compute(t & 1);
-        store_lds((t & 1) ^ 1);
+        store_lds((t & 1) ^ 1, t + 1);
         __syncthreads();
     }
     if (ntiles > 0) compute((ntiles - 1) & 1);
@@ -248,12 +268,118 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
                     p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
                 } else {
                     v = epilogue_apply(p.epi, v, row, col);
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if (p.epi.accumulate) v += *c;
-                    *c = v;
+                    if constexpr (FX != 0) acc[i][j][r] = v;          // the fused reductions below work on the stored values
+                    if constexpr ((FX & FX_NOSTORE) == 0) {
+                        float* c = p.C + (size_t)row * p.ldc + col;
+                        if (p.epi.accumulate) v += *c;
+                        *c = v;
+                    }
                 }
             }
         }
+
+    if constexpr ((FX & FX_GROUPMAX) != 0) {
+        // max + first arg-max over every `group` consecutive rows (torch.max(feature, dim=2) over the points of a group,
+        // models/dvae.py:211,214).  A wave owns 64 rows = two groups of 32 or one of 64: no cross-wave step.
+        const int group = p.fx.group;                                 // 32 or 64
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 16 + ml;
+            float hb[2]; int hi[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                             // half of the wave's rows: blocks 2h, 2h+1
+                float best = acc[2 * h][j][0]; int bi = 4 * kl;       // local row within the half
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[2 * h + ii][j][r]; const int idx = ii * 16 + 4 * kl + r;
+                        if (v > best) { best = v; bi = idx; }         // ascending idx in-lane: strict '>' keeps the first maximum
+                    }
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {            // across the four 16-lane rows (kl): lowest index wins ties
+                    const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                hb[h] = best; hi[h] = bi;
+            }
+            if (kl == 0) {
+                if (group == 32) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const size_t g = (size_t)(m0 + wm * 64 + h * 32) / 32;
+                        p.fx.gmax[g * p.N + col] = hb[h];
+                        if (p.fx.garg) p.fx.garg[g * p.N + col] = hi[h];
+                    }
+                } else {                                              // one group of 64 rows: the first half wins ties
+                    const bool second = hb[1] > hb[0];
+                    const size_t g = (size_t)(m0 + wm * 64) / 64;
+                    p.fx.gmax[g * p.N + col] = second ? hb[1] : hb[0];
+                    if (p.fx.garg) p.fx.garg[g * p.N + col] = second ? hi[1] + 32 : hi[0];
+                }
+            }
+        }
+    }
+    if constexpr ((FX & FX_COLSTATS) != 0) {
+        // per-tile column mean and sum of squared deviations over the tile's 128 rows (two passes over the accumulators, so no
+        // E[x^2] - E[x]^2 cancellation); bn_tiles_finalize merges the tiles_m partials of a column in a fixed order
+        __syncthreads();                                              // As is free now: [2 wm][BN] exchange buffer
+        float* red = &As[0][0];
+        float csum[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            csum[j] = s;
+            if (kl == 0) red[wm * BN + wn * (BN / 2) + j * 16 + ml] = s;
+        }
+        __syncthreads();
+        float mean[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = wn * (BN / 2) + j * 16 + ml;
+            mean[j] = (red[c] + red[BN + c]) * (1.0f / BM);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; q += d * d; }
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            if (kl == 0) red[wm * BN + wn * (BN / 2) + j * 16 + ml] = q;
+        }
+        __syncthreads();
+        if (wm == 0 && kl == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int c = wn * (BN / 2) + j * 16 + ml;
+                float* ts = p.fx.tile_stats + (size_t)tile_m * 2 * p.N + n0 + c;
+                ts[0] = mean[j];
+                ts[p.N] = red[c] + red[BN + c];
+            }
+        }
+        (void)csum;
+    }
+}
+
+bool launch_sgemm_nt16_fx(const GemmParams& p, int tile, int fx, dim3 grid, hipStream_t s) {
+#define FXL(BN_, MASK) hipLaunchKernelGGL((sgemm_nt16_kernel<128, BN_, false, MASK>), grid, dim3(256), 0, s, p); return true
+    if (tile == 0) {
+        if (fx == FX_COLSTATS) { FXL(128, FX_COLSTATS); }
+        if (fx == (FX_AFFINE_A | FX_GROUPMAX)) { FXL(128, FX_AFFINE_A | FX_GROUPMAX); }
+        if (fx == (FX_AFFINE_A | FX_GROUPMAX | FX_NOSTORE)) { FXL(128, FX_AFFINE_A | FX_GROUPMAX | FX_NOSTORE); }
+    } else if (tile == 1) {
+        if (fx == FX_COLSTATS) { FXL(64, FX_COLSTATS); }
+        if (fx == (FX_AFFINE_A | FX_GROUPMAX)) { FXL(64, FX_AFFINE_A | FX_GROUPMAX); }
+        if (fx == (FX_AFFINE_A | FX_GROUPMAX | FX_NOSTORE)) { FXL(64, FX_AFFINE_A | FX_GROUPMAX | FX_NOSTORE); }
+    }
+#undef FXL
+    return false;
 }
 
 
@@ -267,8 +393,11 @@ __global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) 
 // operand keeps the scheme of sgemm_nt16_kernel ([row][16 k], swizzled, one b128 = four k-steps); both use k = 4g + s for lane group
 // g at k-step s, so the two fetch schemes combine freely.  Per 16-deep K-tile: 8 ds_read_b128 for 64 MFMAs in every layout.
 // Constraint: a row-contiguous operand needs a 64-wide wave extent, i.e. BM = 128 when A is [K][M], BN = 128 when B is [K][N].
-template <int BM, int BN, bool A_K, bool B_K, bool MG = false>
+// FXB (weight gradients of the mini-PointNet): B'[k,n] = relu(B[k,n] * b_scale[n] + b_shift[n]) while B is staged -- the activated input of
+// the layer is recomputed from the stored pre-BatchNorm tensor instead of being kept (a thread's float4 always covers the same 4 columns).
+template <int BM, int BN, bool A_K, bool B_K, bool MG = false, bool FXB = false>
 __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
+    static_assert(!FXB || !B_K, "FXB: row-contiguous B");
     static_assert(A_K || BM == 128, "row-contiguous A needs BM = 128");
     static_assert(B_K || BN == 128, "row-contiguous B needs BN = 128");
     static_assert(!(A_K && B_K), "NT is sgemm_nt16_kernel");
@@ -321,7 +450,20 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
         if constexpr (NB > 1) rb1 = *reinterpret_cast<const float4*>(gb + gb_second + t * gb_step);
     };
     const int sa_off = A_K ? s_off_k : tid * 4, sb_off = B_K ? s_off_k : tid * 4;
+    float4 bsc = make_float4(1.f, 1.f, 1.f, 1.f), bsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (FXB) {
+        bsc = *reinterpret_cast<const float4*>(p.fx.b_scale + n0 + (tid % (BN / 4)) * 4);
+        bsh = *reinterpret_cast<const float4*>(p.fx.b_shift + n0 + (tid % (BN / 4)) * 4);
+    }
     auto store_lds = [&](int buf) {
+        if constexpr (FXB) {
+            rb0.x = fmaxf(rb0.x * bsc.x + bsh.x, 0.f); rb0.y = fmaxf(rb0.y * bsc.y + bsh.y, 0.f);
+            rb0.z = fmaxf(rb0.z * bsc.z + bsh.z, 0.f); rb0.w = fmaxf(rb0.w * bsc.w + bsh.w, 0.f);
+            if constexpr (NB > 1) {
+                rb1.x = fmaxf(rb1.x * bsc.x + bsh.x, 0.f); rb1.y = fmaxf(rb1.y * bsc.y + bsh.y, 0.f);
+                rb1.z = fmaxf(rb1.z * bsc.z + bsh.z, 0.f); rb1.w = fmaxf(rb1.w * bsc.w + bsh.w, 0.f);
+            }
+        }
         *reinterpret_cast<float4*>(&As[buf][sa_off]) = ra0;
         if constexpr (NA > 1) *reinterpret_cast<float4*>(&As[buf][sa_off + 1024]) = ra1;
         *reinterpret_cast<float4*>(&Bs[buf][sb_off]) = rb0;
@@ -422,6 +564,11 @@ bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor,
     }
     if (tile != 0) return false;                                      // TN: dW = dY^T . X, 128x128 only
     hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, false, false>), grid, dim3(256), 0, s, p);
+    return true;
+}
+
+bool launch_sgemm_q16_tn_fx(const GemmParams& p, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, false, false, false, true>), grid, dim3(256), 0, s, p);
     return true;
 }
 

@@ -9,7 +9,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GEMM_MIN_WAVES 4          // waves per SIMD the register allocator must leave room for (4 workgroups / CU)
 #endif
 
+// optional fusions of the producer / consumer passes around a GEMM (mini-PointNet: BatchNorm statistics, BatchNorm apply + ReLU, max-pool)
+struct GemmFx {
+    const float* a_scale; const float* a_shift;    // NT: A'[r,k] = max(0, A[r,k] * a_scale[k] + a_shift[k]) applied while staging A (K <= 1024)
+    const float* b_scale; const float* b_shift;    // TN: B'[k,n] = max(0, B[k,n] * b_scale[n] + b_shift[n]) applied while staging B
+    float* tile_stats;                             // NT: [tiles_m][2][N] per-tile column mean and sum of squared deviations of the stored values
+    float* gmax; int32_t* garg; int group;         // NT: max (+ first arg-max) over every `group` (32 | 64) consecutive rows -> [M/group][N]
+    int store_c;                                   // 0: C is not written (only its group max is wanted)
+};
+enum { FX_AFFINE_A = 1, FX_COLSTATS = 2, FX_GROUPMAX = 4, FX_NOSTORE = 8, FX_AFFINE_B = 16 };
+
 struct GemmParams {
+    GemmFx fx;
     const float* A; const float* B; float* C;
     int M, N, K, lda, ldb, ldc;
     int k_per_split;                 // K range per blockIdx.z (== K when no split)
@@ -65,3 +76,6 @@ void launch_sgemm16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, d
 void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s);
 // quad-fragment kernels for the NN / TN layouts (gemm16.hip): tile 0 = 128x128, 1 = 64x128 (NN only); false = no such kernel
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
+// NT kernels with fused producer / consumer passes (gemm16.hip); fx_mask = FX_* bits; tile 0 = 128x128, 1 = 128x64.  false = no such kernel
+bool launch_sgemm_nt16_fx(const GemmParams& p, int tile, int fx_mask, dim3 grid, hipStream_t s);
+bool launch_sgemm_q16_tn_fx(const GemmParams& p, dim3 grid, hipStream_t s);      // TN 128x128 with FX_AFFINE_B

@@ -326,3 +326,59 @@ extern "C" int act_bn_bwd_apply_f32(const float* x, const float* dy, const float
                        1.0f / count, total, C, dx);
     ACT_LAUNCH_CHECK(); return 0;
 }
+
+// BatchNorm statistics from the per-tile column (mean, M2) partials a GEMM epilogue left behind (act_sgemm_fx_f32, tile_stats
+// [tiles][2][C], every tile `rows_per_tile` rows): mean = avg of tile means, M2 = sum M2_t + rows_per_tile * sum (mean_t - mean)^2
+// (Chan's combination for equal counts), folded in a fixed order (deterministic) -- then exactly what bn_finalize_kernel produces.
+__global__ __launch_bounds__(256) void bn_tiles_finalize_kernel(const float* __restrict__ ts, int tiles, int rows_per_tile, int C,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                                float* __restrict__ scale_out, float* __restrict__ shift_out) {
+    __shared__ float red[3][64];
+    __shared__ float bmean[64];
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int t = lane; t < tiles; t += 4) s += ts[((size_t)t * 2) * C + c];
+    }
+    if (lane > 0) red[lane - 1][cl] = s;
+    __syncthreads();
+    if (lane == 0) bmean[cl] = ((s + red[0][cl]) + (red[1][cl] + red[2][cl])) / (float)tiles;
+    __syncthreads();
+    const float mean = bmean[cl];
+    float q = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int t = lane; t < tiles; t += 4) {
+            const float d = ts[((size_t)t * 2) * C + c] - mean;
+            q += ts[((size_t)t * 2 + 1) * C + c] + (float)rows_per_tile * d * d;
+        }
+    }
+    __syncthreads();
+    if (lane > 0) red[lane - 1][cl] = q;
+    __syncthreads();
+    if (lane != 0 || c >= C) return;
+    const float R = (float)tiles * (float)rows_per_tile;
+    const float var = fmaxf(((q + red[0][cl]) + (red[1][cl] + red[2][cl])) / R, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    mean_out[c] = mean; rstd_out[c] = rstd; scale_out[c] = sc; shift_out[c] = beta[c] - mean * sc;
+    if (running_mean) {
+        const float unb = R > 1.f ? var * (R / (R - 1.f)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+}
+extern "C" int act_bn_tiles_finalize_f32(const float* tile_stats, int tiles, int rows_per_tile, int C, const float* gamma, const float* beta, float eps,
+                                         float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale,
+                                         float* shift, act_stream_t stream) {
+    if (!tile_stats || !gamma || !beta || !mean || !rstd || !scale || !shift) return ACT_E_NULLPTR;
+    if (tiles <= 0 || rows_per_tile <= 0 || C <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_BN_STATS, s, 0.0, 8.0 * tiles * (double)C);
+    hipLaunchKernelGGL(bn_tiles_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, tile_stats, tiles, rows_per_tile, C, gamma, beta, eps, momentum,
+                       running_mean, running_var, mean, rstd, scale, shift);
+    ACT_LAUNCH_CHECK(); return 0;
+}

@@ -72,7 +72,8 @@ def side_stream(device, which=0):
     key = (device.index if device.index is not None else torch.cuda.current_device(), which)
     st = _SIDE.get(key)
     if st is None:
-        st = _SIDE[key] = torch.cuda.Stream(device=device)
+        prio = int(os.environ.get("ACT_SIDE_PRIO%d" % which, "0"))      # experiment knob: hipStream priority of the auxiliary streams
+        st = _SIDE[key] = torch.cuda.Stream(device=device, priority=prio)
     return st
 
 

@@ -202,6 +202,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    main_prio = int(os.environ.get("ACT_MAIN_PRIO", "0"))           # experiment knob: run the student chain on a high-priority hipStream
+    if main_prio:
+        hp = torch.cuda.Stream(device=device, priority=main_prio)
+        hp.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(hp)
     for i in range(args.warmup):
         step(i)
     barrier()

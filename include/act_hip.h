@@ -108,6 +108,31 @@ int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const floa
                      float* C, int ldc, const act_gemm_epilogue_t* epilogue, float* workspace, size_t workspace_bytes,
                      int tile, int splits, act_stream_t stream);
 
+/* GEMM with the producer / consumer passes of the mini-PointNet fused in (models/dvae.py:201-215: Conv1d -> BatchNorm1d -> ReLU -> Conv1d -> max):
+ *  (1,1) forward conv:  a_scale/a_shift [K] (nullable, K <= 1024): A'[r,k] = max(0, A[r,k]*a_scale[k] + a_shift[k]) applied while A is staged --
+ *        the BatchNorm + ReLU of the producing layer, whose output tensor then never exists;  tile_stats (nullable): per 128-row tile the
+ *        column mean and sum of squared deviations of the stored values, [M/128][2][N] (act_sgemm_fx_tile_stats_floats), input of
+ *        act_bn_tiles_finalize_f32 -- no statistics pass over the output;  gmax (nullable) [M/group][N] (+ garg int32, first arg-max): max over
+ *        every `group` (32 | 64) consecutive rows, the max-pool over the points of a group;  store_c = 0: C itself is not written.
+ *        Needs M % 128 == 0, N % 64 == 0, K % 16 == 0, 16-byte aligned operands.
+ *  (0,0) weight gradient: b_scale/b_shift [N]: B'[k,n] = max(0, B[k,n]*b_scale[n] + b_shift[n]) applied while B is staged (M, N % 128 == 0, K % 32 == 0,
+ *        deterministic split-K through `workspace`). */
+typedef struct {
+    const float *a_scale, *a_shift, *b_scale, *b_shift;
+    float*   tile_stats;
+    float*   gmax;
+    int32_t* garg;
+    int      group, store_c;
+} act_gemm_fx_t;
+size_t act_sgemm_fx_tile_stats_floats(int M, int N);
+int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                     const act_gemm_epilogue_t* epilogue, const act_gemm_fx_t* fx, float* workspace, size_t workspace_bytes, act_stream_t stream);
+/* BatchNorm (train mode) statistics from those tile partials: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale, running stats updated
+ * in place when non-NULL (what act_bn_stats_f32 produces from a pass over the tensor). */
+int act_bn_tiles_finalize_f32(const float* tile_stats, int tiles, int rows_per_tile, int C, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                              act_stream_t stream);
+
 /* ---- row-wise fused kernels of a Transformer block ------------------------------------------- */
 /* xin = x + pos (pos nullable); y = LayerNorm(xin) * gamma + beta  (models/act.py:87-90 with the
  * `x = blk(x + pos)` of :109-112,140-143 fused in).  xin_out / mean / rstd are nullable. D % 4 == 0, D <= 2048. */

@@ -154,3 +154,36 @@ def test_composite_gemm_shape_collection(dev):
     assert shapes == [(1, 1, 28, 192, 64), (1, 1, 28, 64, 64), (1, 1, 28, 256, 64), (1, 1, 28, 64, 256)]
     assert (out == 7.0).all()                       # nothing was launched
     assert CP.lib.act_composite_collect_end(buf, 10) < 0      # not collecting any more
+
+
+@pytest.mark.parametrize("C,n,bs,g", [(384, 32, 8, 16), (128, 32, 4, 64), (192, 64, 2, 24), (768, 64, 2, 8)])
+def test_encoder_fused_schedule_matches_plain(dev, C, n, bs, g):
+    """mini-PointNet with BatchNorm statistics / apply + ReLU / max-pool fused into the GEMMs (csrc/composite.hip, fused schedule) against
+    the one-kernel-per-layer host path: forward, running statistics, every parameter gradient (train mode) and the eval-mode forward.
+    Not bit-identical by construction (other summation order of the statistics): 1e-5 relative to the largest element."""
+    import act_amd.composite as CP
+    from act_amd.models.dvae import Encoder
+    from tests.golden.fill import fill_module
+    torch.manual_seed(4)
+    nb = 0.2 * torch.randn(bs, g, n, 3, device=dev)
+    dout = torch.randn(bs, g, C, device=dev)
+    res = []
+    for enabled in (False, True):
+        enc = fill_module(Encoder(C), "fz.enc.").to(dev).train()
+        saved, CP.ENABLED = CP.ENABLED, enabled
+        try:
+            y = enc(nb); y.backward(dout)
+            enc.eval()
+            with torch.no_grad():
+                ye = enc(nb)
+        finally:
+            CP.ENABLED = saved
+        torch.cuda.synchronize()
+        res.append(dict([("y", y.detach()), ("y_eval", ye)] + [(k, p.grad) for k, p in enc.named_parameters()] +
+                        [("buf." + k, b.clone().float()) for k, b in enc.named_buffers()]))
+    rel = lambda a, b: ((a.double() - b.double()).abs().max() / max(1.0, b.double().abs().max().item())).item()
+    for k, a in res[0].items():
+        # a conv bias in front of a train-mode BatchNorm has an exactly-zero gradient: both paths return cancellation noise of ~1e-7 x the
+        # summands (hundreds), not a value to compare to 1e-5
+        tol = 2e-3 if k in ("first_conv.0.bias", "second_conv.0.bias") else 2e-5
+        assert rel(res[1][k], a) <= tol, (k, rel(res[1][k], a))
