@@ -580,6 +580,159 @@ __global__ __launch_bounds__(256, OCC) void attn_bwd_mfma_kernel(const AttnBwdAr
     }
 }
 
+
+// =================================================================================== S <= 16: one wave per (cloud, head), registers only
+// The student encoder of Stage II runs on 13 visible tokens + cls = 14 (models/act.py:255): a 32- or 64-wide tile is 80-95 % padding and
+// the LDS-staged kernels above are pure latency (7 % MFMA utilisation in the backward).  Here one wave owns one (cloud, head) pair; every
+// product is a handful of v_mfma_f32_16x16x4_f32 whose operands come straight from global memory into registers -- no LDS, no barrier:
+//   operand "form R" : lane (r = lane&15, g = lane>>4) holds X[r][E*g .. E*g+E-1]  (E = HD/4 contiguous floats, MFMA k-step i uses element i:
+//                      the reduction over the head dimension is order-free, so both operands simply use the same permutation)
+//   operand "form C" : lane (c, g) holds X[4g + s][16*blk + c] for s = 0..3 (k-step s reduces over rows 4g+s: again a free permutation)
+//   MFMA C/D layout  : lane (c, g) holds D[4g + reg][c]
+// forward : St = K Q^t (D: key = 4g+reg, query = c) -> softmax over keys = in-lane + two lane^16/32 exchanges -> Pt is directly the
+//           B operand of Ot = Vt Pt (key = 4g+s at k-step s) with V in form C; each lane stores 4 consecutive output floats.
+// backward: S = Q K^t and St = K Q^t (P and Pt), dP = dO V^t and dPt = V dO^t, dS = P (dP - delta) (both orientations) and then
+//           dVt = dOt P, dKt = Qt dS, dQt = Kt dSt with P / dS / dSt as B operands straight from their D registers.
+template <int HD>
+__device__ __forceinline__ void load_form_r(const float* __restrict__ base, int ld, int r, int g, int S, float* x) {
+    constexpr int E = HD / 4;
+    if (r < S) {
+        const float4* p = reinterpret_cast<const float4*>(base + (size_t)r * ld + E * g);
+#pragma unroll
+        for (int i = 0; i < E / 4; ++i) { const float4 t = p[i]; x[4 * i] = t.x; x[4 * i + 1] = t.y; x[4 * i + 2] = t.z; x[4 * i + 3] = t.w; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) x[i] = 0.f;
+    }
+}
+template <int HD>
+__device__ __forceinline__ void load_form_c(const float* __restrict__ base, int ld, int c, int g, int S, float (*x)[HD / 16]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int row = 4 * g + s;
+#pragma unroll
+        for (int blk = 0; blk < HD / 16; ++blk) x[s][blk] = row < S ? base[(size_t)row * ld + 16 * blk + c] : 0.f;
+    }
+}
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_small_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
+                                                             int B, int S, int H, float scale) {
+    constexpr int E = HD / 4, NB = HD / 16;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (long long)B * H) return;
+    const int b = (int)(pair / H), h = (int)(pair % H);
+    const int D = H * HD, ld = 3 * D;
+    const float* q0 = qkv + (size_t)b * S * ld + h * HD;
+    float qr[E], kr[E], vc[4][NB];
+    load_form_r<HD>(q0, ld, c, g, S, qr);
+    load_form_r<HD>(q0 + D, ld, c, g, S, kr);
+    load_form_c<HD>(q0 + 2 * D, ld, c, g, S, vc);
+    f32x4s st = {0.f, 0.f, 0.f, 0.f};                                  // St[key = 4g+reg][query = c]
+#pragma unroll
+    for (int i = 0; i < E; ++i) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[i], qr[i], st, 0, 0, 0);
+    float m = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { if (4 * g + r >= S) st[r] = -3.0e38f; m = fmaxf(m, st[r]); }
+    m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[r] = __expf(scale * (st[r] - m)); l += st[r]; }
+    l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+    const float inv_l = 1.0f / l;
+    float* op = out + ((size_t)b * S + min(c, S - 1)) * D + h * HD;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {                               // Ot[d = 16 blk + 4g + reg][query = c]; MFMAs outside divergent control flow
+        f32x4s o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) o = __builtin_amdgcn_mfma_f32_16x16x4f32(vc[s2][blk], st[s2], o, 0, 0, 0);
+        if (c < S) *reinterpret_cast<float4*>(op + 16 * blk + 4 * g) = make_float4(o[0] * inv_l, o[1] * inv_l, o[2] * inv_l, o[3] * inv_l);
+    }
+    if (lse && g == 0 && c < S) lse[((size_t)b * H + h) * S + c] = scale * m + __logf(l);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out, const float* __restrict__ dout,
+                                                             const float* __restrict__ lse, float* __restrict__ dqkv, int B, int S, int H, float scale) {
+    constexpr int E = HD / 4, NB = HD / 16;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long long pair = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= (long long)B * H) return;
+    const int b = (int)(pair / H), h = (int)(pair % H);
+    const int D = H * HD, ld = 3 * D;
+    const float* q0 = qkv + (size_t)b * S * ld + h * HD;
+    const float* o0 = out + (size_t)b * S * D + h * HD;
+    const float* do0 = dout + (size_t)b * S * D + h * HD;
+    float* dq0 = dqkv + (size_t)b * S * ld + h * HD;
+    float qr[E], kr[E], vr[E], dor[E], orr[E];
+    load_form_r<HD>(q0, ld, c, g, S, qr);
+    load_form_r<HD>(q0 + D, ld, c, g, S, kr);
+    load_form_r<HD>(q0 + 2 * D, ld, c, g, S, vr);
+    load_form_r<HD>(do0, D, c, g, S, dor);
+    load_form_r<HD>(o0, D, c, g, S, orr);
+    // delta[row c] = sum_d dO[c][d] O[c][d]; log-sum-exp of row c
+    float delta = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) delta += dor[i] * orr[i];
+    delta += __shfl_xor(delta, 16); delta += __shfl_xor(delta, 32);
+    const float lse_c = c < S ? lse[((size_t)b * H + h) * S + c] : 0.f;
+    // S / St and dP / dPt
+    f32x4s s_qk = {0.f, 0.f, 0.f, 0.f}, s_kq = s_qk, dp = s_qk, dpt = s_qk;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        s_qk = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[i], kr[i], s_qk, 0, 0, 0);      // S [query = 4g+reg][key = c]
+        s_kq = __builtin_amdgcn_mfma_f32_16x16x4f32(kr[i], qr[i], s_kq, 0, 0, 0);      // St[key = 4g+reg][query = c]
+        dp   = __builtin_amdgcn_mfma_f32_16x16x4f32(dor[i], vr[i], dp, 0, 0, 0);       // dP [query = 4g+reg][key = c]
+        dpt  = __builtin_amdgcn_mfma_f32_16x16x4f32(vr[i], dor[i], dpt, 0, 0, 0);      // dPt[key = 4g+reg][query = c]
+    }
+    f32x4s p, ds, dst;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        // orientation 1: query = row, key = c   (needs lse / delta of the ROW query: fetched from the lane that owns it)
+        const float lse_r = __shfl(lse_c, row), del_r = __shfl(delta, row);
+        const bool v1 = row < S && c < S;
+        p[r] = v1 ? __expf(scale * s_qk[r] - lse_r) : 0.f;
+        ds[r] = p[r] * (dp[r] - del_r) * scale;
+        // orientation 2: key = row, query = c
+        const bool v2 = row < S && c < S;
+        const float pt = v2 ? __expf(scale * s_kq[r] - lse_c) : 0.f;
+        dst[r] = pt * (dpt[r] - delta) * scale;
+    }
+    float xc[4][NB];
+    // dVt[d][key = c] = sum_q dOt[d][q] P[q][key]      (A: dO form C, B: P)
+    load_form_c<HD>(do0, D, c, g, S, xc);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        f32x4s a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) a = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[s2][blk], p[s2], a, 0, 0, 0);
+        if (c < S) *reinterpret_cast<float4*>(dq0 + 2 * D + (size_t)c * ld + 16 * blk + 4 * g) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    // dKt[d][key = c] = sum_q Qt[d][q] dS[q][key]
+    load_form_c<HD>(q0, ld, c, g, S, xc);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        f32x4s a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) a = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[s2][blk], ds[s2], a, 0, 0, 0);
+        if (c < S) *reinterpret_cast<float4*>(dq0 + D + (size_t)c * ld + 16 * blk + 4 * g) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    // dQt[d][query = c] = sum_key Kt[d][key] dSt[key][query]
+    load_form_c<HD>(q0 + D, ld, c, g, S, xc);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        f32x4s a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) a = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[s2][blk], dst[s2], a, 0, 0, 0);
+        if (c < S) *reinterpret_cast<float4*>(dq0 + (size_t)c * ld + 16 * blk + 4 * g) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+static const bool g_attn_small = [] { const char* e = getenv("ACT_ATTN_SMALL"); return !(e && e[0] == '0'); }();      // dev A/B knob
+
 template <int HD>
 static int launch_attn_bwd_mfma_t(const AttnBwdArgs& a, hipStream_t s) {
     const size_t smem = ((size_t)3 * 64 * HD + 64 * 65 + 128) * sizeof(float);
@@ -631,6 +784,13 @@ extern "C" int act_attention_fwd_f32(const float* qkv, float* out, float* lse, i
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_ATTN_FWD, s, 4.0 * B * H * (double)S * S * head_dim, 16.0 * B * S * (double)H * head_dim);
     const int D = H * head_dim;
+    if (S <= 16 && g_attn_small) {                                     // register-resident kernel: one wave per (cloud, head)
+        const unsigned grid = (unsigned)(((long long)B * H + 3) / 4);
+        if (head_dim == 64) hipLaunchKernelGGL(attn_small_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, qkv, out, lse, B, S, H, scale);
+        else                hipLaunchKernelGGL(attn_small_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, qkv, out, lse, B, S, H, scale);
+        ACT_LAUNCH_CHECK();
+        return 0;
+    }
     AttnFwdArgs a;
     a.q = qkv; a.k0 = nullptr; a.v0 = nullptr; a.k1 = qkv + D; a.v1 = qkv + 2 * D;
     a.q_bs = (long long)S * 3 * D; a.kv0_bs = 0; a.kv1_bs = a.q_bs; a.ldq = 3 * D; a.ld0 = 0; a.ld1 = 3 * D;
@@ -662,6 +822,15 @@ extern "C" int act_attention_bwd_f32(const float* qkv, const float* out, const f
     if (B < 0 || S <= 0 || H <= 0 || (head_dim != 64 && head_dim != 32)) return ACT_E_BADARG;
     if (B == 0) return 0;
     static const bool use_valu = [] { const char* e = getenv("ACT_ATTN_BWD_VALU"); return e && e[0] == '1'; }();   // dev A/B knob
+    if (S <= 16 && g_attn_small) {
+        hipStream_t s = (hipStream_t)stream;
+        ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)S * S * head_dim, 28.0 * B * S * (double)H * head_dim);
+        const unsigned grid = (unsigned)(((long long)B * H + 3) / 4);
+        if (head_dim == 64) hipLaunchKernelGGL(attn_small_bwd_kernel<64>, dim3(grid), dim3(256), 0, s, qkv, out, dout, lse, dqkv, B, S, H, scale);
+        else                hipLaunchKernelGGL(attn_small_bwd_kernel<32>, dim3(grid), dim3(256), 0, s, qkv, out, dout, lse, dqkv, B, S, H, scale);
+        ACT_LAUNCH_CHECK();
+        return 0;
+    }
     if (!use_valu) {
         hipStream_t s = (hipStream_t)stream;
         ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)S * S * head_dim, 28.0 * B * S * (double)H * head_dim);

@@ -50,8 +50,21 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_planes(const unsigned short*
     __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * PB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = N / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int tiles_n = N / BN, tiles_m = M / BM;
+    int wg = blockIdx.x;
+    if (!(ABL & 8)) {                                         // XCD-aware remap (workgroup b runs on XCD b % 8) + grouped rasterisation
+        const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int tile_m, tile_n;
+    if (ABL & 8) { tile_m = wg / tiles_n; tile_n = wg % tiles_n; }
+    else {
+        constexpr int GM = 8;
+        const int per_group = GM * tiles_n, group = wg / per_group, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM), in_group = wg - group * per_group;
+        tile_m = first_m + in_group % gsz; tile_n = in_group / gsz;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int ntiles = K / BK;
     const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
 
@@ -181,6 +194,7 @@ int main(int argc, char** argv) {
     float ms; HIPCHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
     printf("M=%d N=%d K=%d   split3 of A [%d,%d]: %.3f ms (%.0f GB/s)\n", M, N, K, M, K, ms, hA.size() * 10.0 / (ms * 1e-3) / 1e9);
     run<128, 128, 2>("128x128 occ2", dAp, dBp, dC, M, N, K, hA, hB);
+    run<128, 128, 2, 8>("  row-major raster", dAp, dBp, dC, M, N, K, hA, hB);
     run<128, 128, 2, 1>("  no gload", dAp, dBp, dC, M, N, K, hA, hB);
     run<128, 128, 2, 5>("  no gload/lds st", dAp, dBp, dC, M, N, K, hA, hB);
     run<128, 128, 2, 7>("  + no barriers", dAp, dBp, dC, M, N, K, hA, hB);
