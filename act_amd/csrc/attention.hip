@@ -768,8 +768,12 @@ static int launch_attn_fwd3(const AttnFwdArgs& a, hipStream_t s) {
 template <int HD>
 static int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t s) {
     const int Sk = a.S0 + a.S1;
-    const int JT = Sk > 128 ? 4 : (Sk + 31) / 32;                    // key tiles per LDS chunk
+    int JT = Sk > 128 ? 4 : (Sk + 31) / 32;                          // key tiles per LDS chunk
     const int QT = a.Sq > 128 ? 4 : (a.Sq + 31) / 32;                // query tiles per workgroup
+    // K / V of all pairs of a workgroup live in LDS: beyond ~80 KB only one workgroup fits a CU and the kernel turns into pure latency.
+    // 64-key chunks with the online softmax halve the footprint (teacher prompt-prefix shape 64 q x 128 k: 139 -> 70 KB, 70 -> 57 us).
+    const int pairs = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
+    if (JT == 4 && QT <= 2 && (size_t)pairs * 2 * JT * 32 * (HD + 4) * sizeof(float) > 80 * 1024) JT = 2;
 #define C3(J, Q) if (JT == J && QT == Q) return launch_attn_fwd3<HD, J, Q>(a, s)
     C3(1, 1); C3(2, 1); C3(2, 2); C3(3, 1); C3(3, 2); C3(3, 3); C3(4, 1); C3(4, 2); C3(4, 3); C3(4, 4);
 #undef C3

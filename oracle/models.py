@@ -422,3 +422,153 @@ def param_groups(model, weight_decay):
         else:
             decay.append(p)
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+# ---- ACT_PointBERT: the Point-BERT style alternative recipe (models/act.py:532-725 MaskTransformer, :913-1096 ACT_PointBERT) -----------
+class MaskTransformer(nn.Module):
+    """models/act.py:532-725.  Random draws by key (``tag`` distinguishes the three passes of one ACT_PointBERT.forward):
+    ``<tag>.ratio`` (python float in [lo, hi)), ``<tag>.mask_u`` [B,G] uniforms (mask = u < ratio), ``<tag>.replace_u`` [B,G] uniforms,
+    ``<tag>.perm`` permutation of B*G; block masking: ``<tag>.seed`` [B] indices + ``<tag>.ratios`` [B]."""
+
+    def __init__(self, config):
+        super().__init__()
+        tc = config.transformer_config
+        self.mask_ratio, self.mask_type = tc.mask_ratio, tc.mask_type
+        self.embed_dim, self.depth, self.cls_dim = tc.embed_dim, tc.depth, tc.cls_dim
+        self.replace_pob, self.num_heads, self.encoder_dims = tc.replace_pob, tc.num_heads, tc.encoder_dims
+        self.encoder = Encoder(self.encoder_dims)
+        self.reduce_dim = nn.Linear(self.encoder_dims, self.embed_dim)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.mask_token = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.cls_pos = nn.Parameter(torch.randn(1, 1, self.embed_dim))
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
+        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(self.embed_dim, self.depth, self.num_heads, dpr, tag="bert")
+        self.norm = nn.LayerNorm(self.embed_dim)
+        self.num_tokens = config.dvae_config.num_tokens
+        self.lm_head = nn.Linear(self.embed_dim, self.num_tokens)
+        self.cls_head = nn.Sequential(nn.Linear(self.embed_dim, self.cls_dim), nn.GELU(), nn.Linear(self.cls_dim, self.cls_dim))
+        for t in (self.cls_token, self.cls_pos, self.mask_token):
+            trunc_normal_(t)
+        self.apply(VisableOnlyMaskTransformer._init_weights)
+
+    def _mask(self, center, noaug, draws, tag):
+        B, G, _ = center.shape
+        if noaug or self.mask_ratio[1] == 0:
+            return torch.zeros(B, G, dtype=torch.bool)
+        lo, hi = self.mask_ratio
+        if self.mask_type == 'rand':                # :648-659
+            import random
+            ratio = draws.get(f"{tag}.ratio", lambda: random.random() * (hi - lo) + lo)
+            return draws.get(f"{tag}.mask_u", lambda: torch.rand(B, G)) < float(ratio)
+        seed = draws.get(f"{tag}.seed", lambda: torch.randint(0, G, (B,)))                  # :620-646
+        ratios = draws.get(f"{tag}.ratios", lambda: lo + (hi - lo) * torch.rand(B))
+        out = torch.zeros(B, G, dtype=torch.bool)
+        for b in range(B):
+            d = torch.norm(center[b, int(seed[b])].reshape(1, 3) - center[b], p=2, dim=-1)
+            idx = torch.argsort(d, dim=-1, descending=False)
+            out[b, idx[:int(float(ratios[b]) * G)]] = True
+        return out
+
+    def _random_replace(self, tok, mask, noaug, draws, tag):                             # :661-689
+        if noaug or self.replace_pob == 0:
+            return tok, mask
+        B, G, C = tok.shape
+        rep = (draws.get(f"{tag}.replace_u", lambda: torch.rand(B, G)) < self.replace_pob) & ~mask
+        overall = rep | mask
+        perm = draws.get(f"{tag}.perm", lambda: torch.randperm(B * G))
+        shuffled = tok.detach().reshape(B * G, C)[perm].reshape(B, G, C)
+        w = rep.unsqueeze(-1).to(tok.dtype)
+        return tok * (1 - w) + shuffled * w, overall
+
+    def forward(self, neighborhood, center, draws, return_all_tokens=False, only_cls_tokens=False, noaug=False, tag="q"):
+        mask = self._mask(center, noaug, draws, tag)
+        tok = self.reduce_dim(self.encoder(neighborhood))
+        tok, overall = self._random_replace(tok, mask.clone(), noaug, draws, tag)
+        B, G, _ = tok.shape
+        w = mask.unsqueeze(-1).to(tok.dtype)
+        tok = tok * (1 - w) + self.mask_token.expand(B, G, -1) * w
+        x = torch.cat((self.cls_token.expand(B, -1, -1), tok), dim=1)
+        pos = torch.cat((self.cls_pos.expand(B, -1, -1), self.pos_embed(center)), dim=1)
+        x = self.norm(self.blocks(x, pos, draws))
+        if only_cls_tokens:
+            return self.cls_head(x[:, 0])
+        logits = self.lm_head(x[:, 1:])
+        if return_all_tokens:
+            return self.cls_head(x[:, 0]), logits
+        return self.cls_head(x[:, 0]), logits[~overall], logits[overall], overall
+
+
+class ACT_PointBERT(nn.Module):
+    """models/act.py:913-1096: MoCo-style query / momentum-key MaskTransformers, dVAE token prediction, cut-mix contrast.
+    forward -> (moco_loss, dvae_loss, cutmix_loss).  Draw keys: ``mixup_ratio`` [B], ``mixup_u`` [B,G], plus the MaskTransformer keys
+    under tags ``q`` / ``mix`` / ``k``."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.m, self.T, self.K = config.m, config.T, config.K
+        tc = config.transformer_config
+        self.moco_loss, self.dvae_loss, self.cutmix_loss = tc.moco_loss, tc.dvae_loss, tc.cutmix_loss
+        self.return_all_tokens = tc.return_all_tokens
+        self.transformer_q = MaskTransformer(config)
+        self.transformer_k = MaskTransformer(config)
+        for pq, pk in zip(self.transformer_q.parameters(), self.transformer_k.parameters()):
+            pk.data.copy_(pq.data); pk.requires_grad = False
+        self.dvae = ACTPromptedDiscreteVAEwithVIT(config.dvae_config)
+        for p in self.dvae.parameters():
+            p.requires_grad = False
+        self.group_divider = Group(config.dvae_config.num_group, config.dvae_config.group_size)
+        self.register_buffer("queue", F.normalize(torch.randn(tc.cls_dim, self.K), dim=0))
+        self.register_buffer("queue_ptr", torch.zeros(1, dtype=torch.long))
+
+    def forward_tokenizer(self, neighborhood, center):
+        d = self.dvae
+        return d.dgcnn_1(d.encoder(neighborhood), center, knn_graph_ref(center, 4)).argmax(-1).long()   # models/dvae.py:578-582
+
+    def forward(self, pts, draws=None, noaug=False):
+        draws = draws if draws is not None else Draws()
+        neighborhood, center = self.group_divider(pts)
+        if noaug:
+            with torch.no_grad():
+                return self.transformer_q(neighborhood, center, draws, only_cls_tokens=True, noaug=True)
+        B, G = center.shape[:2]
+        with torch.no_grad():
+            label = self.forward_tokenizer(neighborhood, center)
+        rat = self.return_all_tokens
+        q_out = self.transformer_q(neighborhood, center, draws, return_all_tokens=rat, tag="q")
+        q_cls = F.normalize(q_out[0], dim=1)
+        ratio = draws.get("mixup_ratio", lambda: torch.rand(B))                                   # _mixup_pc :1015-1032
+        mm = (draws.get("mixup_u", lambda: torch.rand(B, G)) < ratio.unsqueeze(-1)).to(neighborhood.dtype)
+        mix_nb = neighborhood * mm[..., None, None] + neighborhood.flip(0) * (1 - mm[..., None, None])
+        mix_c = center * mm.unsqueeze(-1) + center.flip(0) * (1 - mm.unsqueeze(-1))
+        mix_label = (label * mm + label.flip(0) * (1 - mm)).long()
+        m_out = self.transformer_q(mix_nb, mix_c, draws, return_all_tokens=rat, tag="mix")
+        m_cls = F.normalize(m_out[0], dim=1)
+        with torch.no_grad():
+            for pq, pk in zip(self.transformer_q.parameters(), self.transformer_k.parameters()):
+                pk.data = pk.data * self.m + pq.data * (1. - self.m)
+            k_cls = F.normalize(self.transformer_k(neighborhood, center, draws, only_cls_tokens=True, tag="k"), dim=1)
+        zero = torch.tensor(0.)
+        queue = self.queue.clone().detach()
+        moco = zero
+        if self.moco_loss:
+            lg = torch.cat([(q_cls * k_cls).sum(1, keepdim=True), q_cls @ queue], dim=1) / self.T
+            moco = F.cross_entropy(lg, torch.zeros(B, dtype=torch.long))
+        dv = zero
+        if self.dvae_loss:
+            if rat:
+                dv = F.cross_entropy(q_out[1].reshape(-1, q_out[1].size(-1)), label.reshape(-1)) + \
+                    F.cross_entropy(m_out[1].reshape(-1, m_out[1].size(-1)), mix_label.reshape(-1))
+            else:
+                dv = F.cross_entropy(q_out[2], label[q_out[3]]) + F.cross_entropy(m_out[2], mix_label[m_out[3]])
+        cm = zero
+        if self.cutmix_loss:
+            lg = torch.cat([m_cls @ k_cls.t(), m_cls @ queue], dim=1) / self.T
+            lab = torch.arange(B, dtype=torch.long)
+            cm = (ratio * F.cross_entropy(lg, lab, reduction='none') + (1 - ratio) * F.cross_entropy(lg, lab.flip(0), reduction='none')).mean()
+        with torch.no_grad():                                                                      # _dequeue_and_enqueue :991-1005
+            ptr = int(self.queue_ptr)
+            assert self.K % B == 0
+            self.queue[:, ptr:ptr + B] = k_cls.T
+            self.queue_ptr[0] = (ptr + B) % self.K
+        return moco, dv, cm

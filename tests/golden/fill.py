@@ -66,6 +66,14 @@ TINY_STAGE2 = dict(
 )
 TINY_B, TINY_N = 2, 128
 
+# ACT_PointBERT (models/act.py:913-1096): the reference ships no YAML for it; keys as the constructor reads them
+TINY_POINTBERT = dict(
+    NAME="ACT_PointBERT", m=0.9, T=0.07, K=16,
+    transformer_config=dict(mask_ratio=[0.25, 0.45], mask_type="rand", embed_dim=64, encoder_dims=64, depth=2, drop_path_rate=0.0, cls_dim=32,
+                            replace_pob=0.2, num_heads=2, moco_loss=True, dvae_loss=True, cutmix_loss=True, return_all_tokens=False),
+    dvae_config=dict(TINY_STAGE2["dvae_config"]),
+)
+
 TINY_FINETUNE = dict(NAME="PointTransformer", embed_dim=64, depth=2, drop_path_rate=0.0, cls_dim=10, num_heads=2,
                      group_size=8, num_group=16, encoder_dims=32, transfer_type="full")
 TINY_FT_LABELS = [3, 1, 4, 1]
