@@ -58,8 +58,15 @@ class Dgcnn(ctypes.Structure):
                 [(n, _vp) for n in ("w_in", "b_in", "w5")] + [("stacked", _vp * 4), ("gn_w", _vp * 4), ("gn_b", _vp * 4)])
 
 
+class GemmFx(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("a_scale", "a_shift", "b_scale", "b_shift", "tile_stats", "gmax", "garg")] + [("group", _i), ("store_c", _i)]
+
+
 _P = ctypes.POINTER
 _SIGS = {
+    "act_sgemm_fx_tile_stats_floats": [_i, _i],
+    "act_sgemm_fx_f32": [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _P(K.GemmEpilogue), _P(GemmFx), _vp, _sz, _vp],
+    "act_bn_tiles_finalize_f32": [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "act_gemm_tune_set": [_i] * 7,
     "act_gemm_tune_get": [_i] * 5 + [_P(_i), _P(_i)],
     "act_gemm_tune_clear": [],

@@ -84,6 +84,8 @@ def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, 
     if augment and not _Announced.is_marked(points):
         points = train_transforms(points)
     loss = base_model(points, draws=draws) if draws is not None else base_model(points)
+    if isinstance(loss, tuple):                      # ACT_PointBERT returns (moco, dvae, cutmix): summed (tools/runner_pretrain.py:140-142)
+        loss = loss[0] + loss[1] + loss[2]
     if next_points is not None:
         if augment:
             next_points = train_transforms(next_points)

@@ -185,5 +185,6 @@ def test_encoder_fused_schedule_matches_plain(dev, C, n, bs, g):
     for k, a in res[0].items():
         # a conv bias in front of a train-mode BatchNorm has an exactly-zero gradient: both paths return cancellation noise of ~1e-7 x the
         # summands (hundreds), not a value to compare to 1e-5
-        tol = 2e-3 if k in ("first_conv.0.bias", "second_conv.0.bias") else 2e-5
+        # (first_conv.3.bias too: a constant shift of h2 and of its group max moves h3 by a constant, which BatchNorm-2 removes)
+        tol = 2e-3 if k in ("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias") else 2e-5
         assert rel(res[1][k], a) <= tol, (k, rel(res[1][k], a))

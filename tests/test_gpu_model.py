@@ -501,3 +501,51 @@ def test_reference_format_checkpoints_load_strictly(dev, tmp_path):
     for m in (m_load, m_res):
         m.to(dev).train(); m.dvae_tokenizer.prompt_dropout.p = 0.0
         assert abs(m(pts.to(dev), draws=Draws(rec.table, device=dev)).item() - lo.item()) <= TOL
+
+
+def test_act_pointbert_golden_and_oracle(dev):
+    """ACT_PointBERT (models/act.py:913-1096): golden g14 from the reference's own forward/backward (three losses, gradient norms,
+    queue update, momentum update), every gradient element-wise against the oracle, one runner step (tuple loss summed), noaug feature."""
+    import copy
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg, MODELS
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import train_step, _Single
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    from tests.golden.fill import TINY_POINTBERT
+    from tests.test_oracle_golden import _pointbert_draws, _pointbert_oracle
+    assert "ACT_PointBERT" in MODELS
+    g = golden("g14_pointbert")
+    oracle = _pointbert_oracle(g)
+    torch.manual_seed(3)
+    with pytest.warns(UserWarning):
+        model = build_model_from_cfg(EasyDict(copy.deepcopy(TINY_POINTBERT)))
+    assert sorted(k for k in model.state_dict() if not k.startswith("dvae.")) == [str(k) for k in g["state_dict_keys"]]
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model.to(dev).train()
+    assert not any(p.requires_grad for p in model.transformer_k.parameters()) and not any(p.requires_grad for p in model.dvae.parameters())
+    pts = torch.from_numpy(clouds(14, 4, 128))
+    lo = oracle(pts, _pointbert_draws(g, OL.Draws)); sum(lo).backward()
+    lg = model(pts.to(dev), draws=_pointbert_draws(g, Draws, device=dev)); (lg[0] + lg[1] + lg[2]).backward()
+    for got, ora, want in zip(lg, lo, g["losses"]):
+        assert abs(got.item() - want) <= TOL * max(1.0, abs(want)) and abs(got.item() - ora.item()) <= TOL, (got.item(), ora.item(), want)
+    pd, od = dict(model.named_parameters()), dict(oracle.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= TOL * max(1.0, v), n
+    for n, p in pd.items():
+        if p.grad is not None and od[n].grad is not None:
+            assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
+    assert _rel(model.queue, g["queue1"]) <= 1e-5 and int(model.queue_ptr) == int(g["queue_ptr"][0])
+    assert abs(pd["transformer_k.blocks.blocks.1.mlp.fc1.weight"].norm().item() - g["key_norm_after"][0]) <= 1e-5
+    # eval feature + one optimisation step through the runner (free-running draws, tuple loss)
+    f = model(pts.to(dev), noaug=True)
+    assert tuple(f.shape) == (4, 32) and _rel(f, oracle(pts, OL.Draws(), noaug=True)) <= TOL
+    cfg = EasyDict(optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3, weight_decay=0.05)),
+                   scheduler=dict(type="CosLR", kwargs=dict(epochs=300, initial_epochs=10)), step_per_update=1)
+    wrapped = _Single(model)
+    opt, _ = builder.build_opti_sche(wrapped, cfg)
+    before = pd["transformer_q.lm_head.weight"].detach().clone()
+    loss = train_step(wrapped, opt, pts.to(dev).clone(), cfg)
+    assert torch.isfinite(loss).all() and not torch.equal(before, pd["transformer_q.lm_head.weight"].detach())
+    assert int(model.queue_ptr) == 8

@@ -286,3 +286,44 @@ def test_g13_cls_loss_branch_matches_reference():
         assert abs(pd[str(n)].grad.norm().item() - v) <= 1e-4 * max(1.0, v), n
     _close(pd["cls_pos"].grad, g["grad_cls_pos"])
     assert sorted(k for k in model.state_dict() if not k.startswith("dvae_tokenizer.")) == [str(k) for k in g["state_dict_keys"]]
+
+
+def _pointbert_draws(g, DrawsCls, **kw):
+    table = {}
+    for k in g.files:
+        if k.startswith("draw."):
+            v = g[k]
+            table[k[5:]] = float(v) if v.ndim == 0 else torch.from_numpy(v)
+    return DrawsCls(table, **kw)
+
+
+def _pointbert_oracle(g):
+    from tests.golden.fill import TINY_POINTBERT
+    torch.manual_seed(3)
+    m = M.ACT_PointBERT(M.edict(TINY_POINTBERT))
+    fill_module(m.dvae, "g14.dvae.")
+    fill_module(m.transformer_q, "g14.q.")
+    with torch.no_grad():
+        for pq, pk in zip(m.transformer_q.parameters(), m.transformer_k.parameters()):
+            pk.copy_(0.5 * pq)
+        m.transformer_q.encoder.load_state_dict(m.dvae.encoder.state_dict())
+        m.queue.copy_(torch.from_numpy(g["queue0"]))
+    return m.train()
+
+
+def test_g14_act_pointbert_matches_reference():
+    """ACT_PointBERT (models/act.py:913-1096): the three losses, gradient norms, the MoCo queue update and the momentum update of the key
+    encoder of the oracle against the reference's own forward / backward with every random draw replayed."""
+    g = golden("g14_pointbert")
+    m = _pointbert_oracle(g)
+    assert sorted(k for k in m.state_dict() if not k.startswith("dvae.")) == [str(k) for k in g["state_dict_keys"]]
+    moco, dv, cm = m(torch.from_numpy(clouds(14, 4, 128)), _pointbert_draws(g, L.Draws))
+    (moco + dv + cm).backward()
+    for got, want in zip((moco, dv, cm), g["losses"]):
+        assert abs(got.item() - want) <= 1e-5 * max(1.0, abs(want)), (got.item(), want)
+    pd = dict(m.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 1e-4 * max(1.0, v), n
+    _close(m.queue, g["queue1"], 1e-5)
+    assert int(m.queue_ptr) == int(g["queue_ptr"][0])
+    assert abs(pd["transformer_k.blocks.blocks.1.mlp.fc1.weight"].norm().item() - g["key_norm_after"][0]) <= 1e-5
