@@ -313,10 +313,10 @@ def main():
                                "avg_launch_us": 1e3 * dv["ms"] / dv["launches"], "launches_per_step": dv["launches"] / nprof}
         # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command (profiles/)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(dom)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["kernels"].get(dom)
             if pm:
                 out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE (calibrated), profiles/r01_pmc_traffic.json"
+                out["roofline"]["traffic_note"] = "bytes/launch, rocprofv3 FETCH_SIZE+WRITE_SIZE (calibrated), profiles/r02_pmc_traffic.json"
                 out["roofline"]["algorithmic_bytes_per_launch"] = dv["bytes"] / dv["launches"]
         except Exception:
             pass

@@ -30,6 +30,9 @@ def fold(name):
         return "sgemm_nt" if ak and bk else ("sgemm_nn" if ak else ("sgemm_tn" if not bk else "sgemm_tt"))
     if n.startswith("sgemm_nt16_kernel"):
         return "sgemm_nt"
+    m = re.match(r"sgemm_q16_kernel<\d+, \d+, (true|false), (true|false)", n)
+    if m:
+        return "sgemm_nn" if m.group(1) == "true" else "sgemm_tn"
     if n.startswith("sgemm_tn_skinny_kernel"):
         return "sgemm_tn"
     return re.sub(r"<.*", "", n)[:60]
@@ -46,15 +49,18 @@ def collect(d, counter):
     return {k: (v[0] / max(1, len(v[1])), len(v[1])) for k, v in tot.items()}
 
 
-CAL_KERNEL, CAL_BYTES = "affine_act_kernel", 262144.0 * (128 + 512) / 2 * 4
+# round 2: the BatchNorm apply is fused into the consuming GEMM, so the calibration kernel is the BatchNorm backward apply pass
+# (bn_bwd_apply_kernel: reads x and dy, writes dx, each [262144, C] fp32, C = 128 and 512 once per Stage-II step)
+CAL_KERNEL, CAL_BYTES = "bn_bwd_apply_kernel", 262144.0 * (128 + 512) / 2 * 4
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-kf = CAL_BYTES / (fetch[CAL_KERNEL][0] * 1024.0)
+kf = 2.0 * CAL_BYTES / (fetch[CAL_KERNEL][0] * 1024.0)
 kw = CAL_BYTES / (write[CAL_KERNEL][0] * 1024.0)
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
                  "--no-cpu-baseline --no-instrument",
        "units": "bytes per launch = counter [KiB] * 1024 * calibration factor",
-       "calibration": {"kernel": CAL_KERNEL, "known_bytes_read_and_written_per_launch": CAL_BYTES, "fetch_factor": kf, "write_factor": kw,
-                       "cross_check": "bn_bwd_apply_kernel must come out at 2x / 1x the calibration bytes"},
+       "calibration": {"kernel": CAL_KERNEL, "known_bytes_written_per_launch": CAL_BYTES, "known_bytes_read_per_launch": 2.0 * CAL_BYTES,
+                       "fetch_factor": kf, "write_factor": kw,
+                       "cross_check": "group_max_bwd_kernel writes 262144 x (384 + 256) / 2 x 4 = 335,544,320 B per launch on average"},
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     fb = fetch.get(k, (0.0, 0))[0] * 1024.0 * kf
