@@ -21,6 +21,9 @@ SHAPES = [  # (tag, a_kmajor, b_kmajor, M, N, K)
     ("s1.dfc2", 1, 0, 8192, 3072, 768), ("s1.dfc1", 1, 0, 8192, 768, 3072), ("s1.dproj", 1, 0, 8192, 768, 768), ("s1.dqkv", 1, 0, 8192, 768, 2304),
     ("s1.dl5", 1, 0, 8192, 2304, 8192), ("s1.dWl5", 0, 0, 8192, 2304, 8192), ("pn.dA1", 1, 0, 262144, 128, 256), ("pn.dW2", 0, 0, 256, 128, 262144),
     ("enc.dWfc2", 0, 0, 384, 1536, 1792), ("enc.dproj", 1, 0, 1792, 384, 384),
+    # the frozen teacher Transformer as it runs in the Stage-II step (8,192 patch-token rows / 8,192 prompt rows)
+    ("t8.fc1", 1, 1, 8192, 3072, 768), ("t8.fc2", 1, 1, 8192, 768, 3072), ("t8.qkv", 1, 1, 8192, 2304, 768), ("t8.kv", 1, 1, 8192, 1536, 768),
+    ("t8.proj", 1, 1, 8192, 768, 768),
 ]
 
 
