@@ -476,13 +476,23 @@ class ACT_PointDistillation(nn.Module):
             self.ACT_decoder = TransformerDecoder(embed_dim=self.embed_dim, depth=self.decoder_depth, drop_path_rate=dpr,
                                                   num_heads=self.decoder_num_heads)
             trunc_normal_(self.mask_token, std=.02)
-        else:
-            raise NotImplementedError("mask_ratio == 0 (no masked decoder) is off the ACT Stage-II path")
+        else:                                                           # models/act.py:1175-1178: plain feature regression, no decoder
+            print_log('[ACT] pretraining without masked decoder ...', logger='ACT')
+            self.mask_token = None
+            self.ACT_decoder = None
 
     def forward_eval(self, pts):
         with torch.no_grad():
             neighborhood, center = self.group_divider(pts)
             return self.ACT_encoder(neighborhood, center, only_cls_tokens=True, noaug=True)
+
+    def _project(self, x_rec):
+        if self.proj_type == 'linear':
+            return K.linear(x_rec, self.proj_head.weight, self.proj_head.bias)
+        if self.proj_type == 'conv':
+            c = self.proj_head[0]
+            return K.linear(x_rec, c.weight.view(c.weight.shape[0], -1), c.bias)
+        return x_rec
 
     def prefetch_teacher(self, next_pts):
         """Software pipelining across steps (exact: the teacher is frozen, so its features for batch i+1 do not depend on the
@@ -557,19 +567,21 @@ class ACT_PointDistillation(nn.Module):
         if not overlap:
             with torch.no_grad():
                 teacher_feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
+        if self.mask_token is None:                                     # mask_ratio 0 (models/act.py:1238-1240): every token is visible
+            if overlap:
+                main.wait_stream(side)
+                teacher_feat.record_stream(main)
+            student_feat = self._project(x_vis)
+            if self.loss_type == 'cosine':
+                return K.cosine_distill_loss(student_feat, teacher_feat)
+            return K.regression_distill_loss(student_feat, teacher_feat, self.loss_type)
         num_mask = self.ACT_encoder.num_mask
         vis_idx, msk_idx = split_indices(mask, num_mask)
         dp = self.decoder_pos_embed
         # decoder_pos_embed of [visible (ascending), masked (ascending)] centres in one launch pair
         pos_full = K.mlp(take_rows(center, torch.cat((vis_idx, msk_idx), dim=1)), dp[0].weight, dp[0].bias, dp[2].weight, dp[2].bias)
         x_full = torch.cat([x_vis, self.mask_token.expand(B, num_mask, -1)], dim=1)
-        def project(x_rec):
-            if self.proj_type == 'linear':
-                return K.linear(x_rec, self.proj_head.weight, self.proj_head.bias)
-            if self.proj_type == 'conv':
-                c = self.proj_head[0]
-                return K.linear(x_rec, c.weight.view(c.weight.shape[0], -1), c.bias)
-            return x_rec
+        project = self._project
         student_feat = project(self.ACT_decoder(x_full, pos_full, num_mask, draws=draws))
         student_feat_global = None
         if self.cls_loss:                      # second decoder pass on [cls, shallow visible tokens, mask tokens] (models/act.py:1231-1236)

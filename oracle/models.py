@@ -273,6 +273,7 @@ class ACT_PointDistillation(nn.Module):
         super().__init__()
         tc = config.transformer_config
         self.mask_ratio, self.embed_dim = tc.mask_ratio, tc.embed_dim
+        self.loss_type = config.get("loss", "cosine") if hasattr(config, "get") else "cosine"
         self.cls_loss = bool(tc.get("cls_loss", False)) if hasattr(tc, "get") else False
         self.register_shallow_hook = int(tc.get("register_shallow_hook", -1)) if hasattr(tc, "get") else -1
         self.ACT_encoder = VisableOnlyMaskTransformer(config)
@@ -284,16 +285,24 @@ class ACT_PointDistillation(nn.Module):
             p.requires_grad = False
         self.group_divider = Group(config.dvae_config.num_group, config.dvae_config.group_size)
         self.proj_head = nn.Linear(self.embed_dim, config.dvae_config.tokens_dims)
-        self.mask_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
-        self.decoder_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
-        dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, tc.decoder_depth)]
-        self.ACT_decoder = TransformerDecoder(self.embed_dim, tc.decoder_depth, tc.decoder_num_heads, dpr)
-        for m in self.ACT_decoder.modules():
-            if isinstance(m, nn.Linear):
-                nn.init.xavier_uniform_(m.weight)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
-        trunc_normal_(self.mask_token)
+        if self.mask_ratio > 0:                    # models/act.py:1158-1178: no decoder at all when nothing is masked
+            self.mask_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
+            self.decoder_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
+            dpr = [x.item() for x in torch.linspace(0, tc.drop_path_rate, tc.decoder_depth)]
+            self.ACT_decoder = TransformerDecoder(self.embed_dim, tc.decoder_depth, tc.decoder_num_heads, dpr)
+            for m in self.ACT_decoder.modules():
+                if isinstance(m, nn.Linear):
+                    nn.init.xavier_uniform_(m.weight)
+                    if m.bias is not None:
+                        nn.init.constant_(m.bias, 0)
+            trunc_normal_(self.mask_token)
+
+    def _loss(self, student, teacher):              # models/act.py:1186-1191,1243-1256
+        if self.loss_type == "l2":
+            return F.mse_loss(student, teacher)
+        if self.loss_type == "smoothl1":
+            return F.smooth_l1_loss(student, teacher)
+        return cosine_distill_loss(student, teacher)
 
     def forward(self, pts, draws=None, noaug=False):
         draws = draws if draws is not None else Draws()
@@ -308,6 +317,8 @@ class ACT_PointDistillation(nn.Module):
         B, _, C = x_vis.shape
         with torch.no_grad():
             teacher = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, draws)
+        if self.mask_ratio == 0:                    # models/act.py:1238-1240: no decoder, every token regressed
+            return self._loss(self.proj_head(x_vis), teacher)
         pos_vis = self.decoder_pos_embed(center[~mask]).reshape(B, -1, C)
         pos_msk = self.decoder_pos_embed(center[mask]).reshape(B, -1, C)
         num_mask = pos_msk.shape[1]
@@ -315,8 +326,8 @@ class ACT_PointDistillation(nn.Module):
         pos_full = torch.cat([pos_vis, pos_msk], dim=1)
         student = self.proj_head(self.ACT_decoder(x_full, pos_full, num_mask, draws))
         teacher = teacher[mask].reshape(B, -1, student.shape[-1])
-        loss = cosine_distill_loss(student, teacher)
-        if self.cls_loss:                          # second decoder pass on [cls, shallow visible tokens, mask tokens] (models/act.py:1231-1236,1248-1249)
+        loss = self._loss(student, teacher)
+        if self.cls_loss and self.loss_type == "cosine":                          # second decoder pass on [cls, shallow visible tokens, mask tokens] (models/act.py:1231-1236,1248-1249)
             x_sh = torch.cat([x_cls.unsqueeze(1), x_shallow, self.mask_token.expand(B, num_mask, -1)], dim=1)
             pos_sh = torch.cat([self.cls_pos.expand(B, -1, -1), pos_full], dim=1)
             student_g = self.proj_head(self.ACT_decoder(x_sh, pos_sh, num_mask, draws, tag="dec_shallow"))

@@ -67,7 +67,29 @@ def main():
              "mask_token", "ACT_decoder.blocks.0.attn.proj.weight", "proj_head.weight", "decoder_pos_embed.0.weight",
              "ACT_encoder.encoder.first_conv.0.weight"]
     pd = dict(model.named_parameters())
-    save("g13_cls_loss", mask=mask, loss=np.array([loss.item()], dtype=np.float64), grad_names=np.array(names),
+    # mask_ratio: 0 on the plain tiny geometry (models/act.py:1175-1178,1238-1240): no decoder, every token regressed
+    # (with loss: cosine the reference itself dies there -- `student_feat_global` is unbound at models/act.py:1248 -- so the golden is taken with 'l2')
+    cfg0 = EasyDict(copy.deepcopy(TINY_STAGE2)); cfg0.transformer_config.mask_ratio = 0; cfg0.loss = "l2"
+    tok0 = dvae.ACTPromptedDiscreteVAEwithVIT(cfg0.dvae_config)
+    torch.load = lambda *a, **k: {"base_model": tok0.state_dict()}
+    try:
+        m0 = build_model_from_cfg(cfg0)
+    finally:
+        torch.load = real_load
+    fill_module(m0, "nm.")
+    m0.dvae_tokenizer.prompt_dropout.p = 0.0
+    m0.train()
+    F.gumbel_softmax = seeded_gumbel
+    try:
+        l0 = m0(torch.from_numpy(clouds(19, TINY_B, TINY_N)))
+        l0.backward()
+    finally:
+        F.gumbel_softmax = real_gs
+    pd0 = dict(m0.named_parameters())
+    n0 = ["ACT_encoder.blocks.blocks.1.attn.proj.weight", "proj_head.weight", "ACT_encoder.encoder.second_conv.3.weight"]
+    save("g13_cls_loss", nomask_loss=np.array([l0.item()], dtype=np.float64), nomask_grad_names=np.array(n0),
+         nomask_grad_norms=np.array([pd0[n].grad.norm().item() for n in n0], dtype=np.float64),
+         nomask_state_dict_keys=np.array(sorted(k for k in m0.state_dict() if not k.startswith("dvae_tokenizer."))), mask=mask, loss=np.array([loss.item()], dtype=np.float64), grad_names=np.array(names),
          grad_norms=np.array([pd[n].grad.norm().item() for n in names], dtype=np.float64),
          grad_cls_pos=pd["cls_pos"].grad.clone(),
          state_dict_keys=np.array(sorted(k for k in model.state_dict() if not k.startswith("dvae_tokenizer."))))

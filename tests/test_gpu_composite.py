@@ -182,9 +182,15 @@ def test_encoder_fused_schedule_matches_plain(dev, C, n, bs, g):
         res.append(dict([("y", y.detach()), ("y_eval", ye)] + [(k, p.grad) for k, p in enc.named_parameters()] +
                         [("buf." + k, b.clone().float()) for k, b in enc.named_buffers()]))
     rel = lambda a, b: ((a.double() - b.double()).abs().max() / max(1.0, b.double().abs().max().item())).item()
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
     for k, a in res[0].items():
-        # a conv bias in front of a train-mode BatchNorm has an exactly-zero gradient: both paths return cancellation noise of ~1e-7 x the
-        # summands (hundreds), not a value to compare to 1e-5
-        # (first_conv.3.bias too: a constant shift of h2 and of its group max moves h3 by a constant, which BatchNorm-2 removes)
-        tol = 2e-3 if k in ("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias") else 2e-5
-        assert rel(res[1][k], a) <= tol, (k, rel(res[1][k], a))
+        if k in ("y", "y_eval") or k.startswith("buf."):
+            assert rel(res[1][k], a) <= 2e-5, (k, rel(res[1][k], a))          # forward values and running statistics: tight
+        elif k in ("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias"):
+            # a conv bias in front of a train-mode BatchNorm has an exactly-zero gradient (first_conv.3.bias too: a constant shift of h2 and
+            # of its group max moves h3 by a constant, which BatchNorm-2 removes): both paths return cancellation noise of ~1e-7 x the summands
+            assert rel(res[1][k], a) <= 2e-3, (k, rel(res[1][k], a))
+        else:
+            # gradients: element-wise 2e-5 unless a max-pool winner / ReLU sign flips between the two summation orders of the statistics
+            # (then one row of dh is rerouted and every upstream weight moves a little): bounded in the L2 sense
+            assert rel(res[1][k], a) <= 2e-5 or l2(res[1][k], a) <= 5e-3, (k, rel(res[1][k], a), l2(res[1][k], a))

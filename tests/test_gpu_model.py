@@ -549,3 +549,36 @@ def test_act_pointbert_golden_and_oracle(dev):
     loss = train_step(wrapped, opt, pts.to(dev).clone(), cfg)
     assert torch.isfinite(loss).all() and not torch.equal(before, pd["transformer_q.lm_head.weight"].detach())
     assert int(model.queue_ptr) == 8
+
+
+def test_mask_ratio_zero_regresses_every_token(dev):
+    """transformer_config.mask_ratio: 0 (models/act.py:1175-1178,1238-1240): no mask token / decoder, the student's 64 tokens are
+    regressed onto the teacher's directly; state_dict has no decoder keys; loss + gradients vs the oracle."""
+    import copy
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    cfg = copy.deepcopy(TINY_STAGE2); cfg["transformer_config"]["mask_ratio"] = 0; cfg["loss"] = "l2"   # the reference's cosine branch is broken here
+    torch.manual_seed(6)
+    oracle = fill_module(OM.ACT_PointDistillation(OM.edict(cfg)), "nm.").train()
+    model = build_model_from_cfg(EasyDict(cfg))
+    assert not any(k.startswith(("mask_token", "ACT_decoder", "decoder_pos_embed")) for k in model.state_dict())
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model.to(dev).train()
+    pts = torch.from_numpy(clouds(19, TINY_B, TINY_N))
+    rec = OL.Draws(record=True)
+    lo = oracle(pts, rec); lo.backward()
+    lg = model(pts.to(dev), draws=Draws(rec.table, device=dev)); lg.backward()
+    assert abs(lg.item() - lo.item()) <= TOL
+    od = dict(oracle.named_parameters())
+    for n, p in model.named_parameters():
+        if p.requires_grad and od[n].grad is not None and p.grad is not None:
+            assert _rel(p.grad, od[n].grad) <= TOL, n
+    from act_amd.tools.runner_pretrain import train_step, _Single, freeze_unused_heads
+    from act_amd.tools import builder
+    freeze_unused_heads(model)
+    ocfg = EasyDict(optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3, weight_decay=0.05)),
+                    scheduler=dict(type="CosLR", kwargs=dict(epochs=300, initial_epochs=10)), step_per_update=1)
+    w = _Single(model); opt, _ = builder.build_opti_sche(w, ocfg)
+    assert torch.isfinite(train_step(w, opt, pts.to(dev).clone(), ocfg, next_points=pts.to(dev).clone()))

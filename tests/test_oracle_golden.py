@@ -327,3 +327,20 @@ def test_g14_act_pointbert_matches_reference():
     _close(m.queue, g["queue1"], 1e-5)
     assert int(m.queue_ptr) == int(g["queue_ptr"][0])
     assert abs(pd["transformer_k.blocks.blocks.1.mlp.fc1.weight"].norm().item() - g["key_norm_after"][0]) <= 1e-5
+
+
+def test_g13_mask_ratio_zero_matches_reference():
+    """mask_ratio: 0 (no decoder, every token regressed; models/act.py:1175-1178,1238-1240) against the reference's own forward / backward."""
+    import copy
+    g = golden("g13_cls_loss")
+    cfg = copy.deepcopy(TINY_STAGE2); cfg["transformer_config"]["mask_ratio"] = 0; cfg["loss"] = "l2"   # the reference's cosine branch is broken here
+    torch.manual_seed(0)
+    model = fill_module(M.ACT_PointDistillation(M.edict(cfg)), "nm.").train()
+    model.dvae_tokenizer.prompt_p = 0.0
+    assert sorted(k for k in model.state_dict() if not k.startswith("dvae_tokenizer.")) == [str(k) for k in g["nomask_state_dict_keys"]]
+    loss = model(torch.from_numpy(clouds(19, TINY_B, TINY_N)), L.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}))
+    loss.backward()
+    assert abs(loss.item() - g["nomask_loss"][0]) <= 1e-5
+    pd = dict(model.named_parameters())
+    for n, v in zip(g["nomask_grad_names"], g["nomask_grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 1e-4 * max(1.0, v), n
