@@ -238,13 +238,10 @@ _VIT_GEOMETRY = {            # timm names -> (depth, heads); width must equal co
 
 
 @MODELS.register_module()
-class ACTPromptedDiscreteVAEwithVIT(nn.Module):
-    """Stage-I autoencoder / Stage-II frozen teacher (models/dvae.py:360-615).
-
-    The pretrained image Transformer is represented by its ``blocks`` + ``norm`` (what the reference keeps,
-    :405-410) with timm's key names; weights come from the dVAE checkpoint (``ckpt``), never from the network.
-    Optional config keys (absent from the reference YAML): ``visual_embed_depth`` / ``visual_embed_heads``
-    override the geometry implied by ``visual_embed_type``."""
+class DiscreteVAE(nn.Module):
+    """The plain Point-BERT tokenizer / autoencoder (models/dvae.py:278-358, recipe cfgs/autoencoder/pointbert_dvae.yaml):
+    Group -> mini-PointNet -> DGCNN -> gumbel-softmax over the codebook -> DGCNN -> FoldingNet; everything trainable.
+    ``forward(inp, temperature, hard)`` -> the 6-tuple, ``get_loss(ret, gt)`` -> (loss_recon, loss_klv)."""
 
     def __init__(self, config, **kwargs):
         super().__init__()
@@ -252,16 +249,8 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         self.num_group = config.num_group
         self.encoder_dims = config.encoder_dims
         self.tokens_dims = config.tokens_dims
-        self.visual_embed_type = config.visual_embed_type
-        self.visual_embed_dim = config.visual_embed_dim
-        self.freeze_visual_embed = config.freeze_visual_embed
-        self.num_prompt_token = config.num_prompt_token
-        self.use_deep_prompt = config.use_deep_prompt
         self.decoder_dims = config.decoder_dims
         self.num_tokens = config.num_tokens
-        if not self.use_deep_prompt or self.num_prompt_token <= 0:
-            raise NotImplementedError("only the deep-prompt configuration of the ACT recipe is on this path")
-
         self.group_divider = Group(num_group=self.num_group, group_size=self.group_size, skip_near_origin=config.get("fps_skip_near_origin", None))
         self.encoder = Encoder(encoder_channel=self.encoder_dims)
         self.dgcnn_1 = DGCNN(encoder_channel=self.encoder_dims, output_channel=self.num_tokens)
@@ -269,6 +258,123 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         self.dgcnn_2 = DGCNN(encoder_channel=self.tokens_dims, output_channel=self.decoder_dims)
         self.decoder = Decoder(encoder_channel=self.decoder_dims, num_fine=self.group_size)
         self.build_loss_func()
+
+    def build_loss_func(self):
+        self.loss_func_cdl1 = ChamferDistanceL1()
+        self.loss_func_cdl2 = ChamferDistanceL2()
+
+    # ---- losses (Stage I) ------------------------------------------------------------------------
+    def recon_loss(self, ret, gt):
+        whole_coarse, whole_fine, coarse, fine, group_gt, _ = ret
+        bs, g, _, _ = coarse.shape
+        coarse = coarse.reshape(bs * g, -1, 3).contiguous()
+        fine = fine.reshape(bs * g, -1, 3).contiguous()
+        group_gt = group_gt.reshape(bs * g, -1, 3).contiguous()
+        return self.loss_func_cdl1(coarse, group_gt) + self.loss_func_cdl1(fine, group_gt)
+
+    def get_loss(self, ret, gt):
+        loss_recon = self.recon_loss(ret, gt)
+        loss_klv = K.kl_to_uniform(ret[-1])        # KL(mean_g softmax(logits) || uniform), 'batchmean' (models/dvae.py:470-476)
+        return loss_recon, loss_klv
+
+    def visual_embedding(self, input, center, draws=None, rng=None):
+        return input                               # the plain tokenizer feeds the codebook vectors straight to dgcnn_2 (:340, :350)
+
+    def _rng(self, device):
+        """(base seed, device-resident step counter) of the in-kernel Philox draws of the frozen-teacher path.  The counter lives
+        in HBM and is bumped by a device op per teacher forward, so a captured hipGraph of that forward draws fresh noise on
+        every replay and eager / replayed executions produce the same sequence."""
+        st = self.__dict__.get("_rng_state")
+        if st is None or st[1].device != device:
+            st = (int(torch.randint(0, 2 ** 62, (1,)).item()), torch.zeros(1, dtype=torch.int64, device=device))
+            self.__dict__["_rng_state"] = st
+        return st
+
+    # ---- tokenizer ----------------------------------------------------------------------------------
+    def _gumbel_codes(self, logits, tau, hard, draws):
+        g = None
+        if draws is not None and (draws.has("gumbel") or draws.record):
+            g = draws.get("gumbel", lambda: -torch.empty_like(logits).exponential_().log())
+        if hard:
+            if g is None:
+                g = -torch.empty_like(logits).exponential_().log()
+            index = ((logits + g) / tau).argmax(dim=-1)    # one-hot x codebook == row gather (models/dvae.py:587-588)
+            codes = F.embedding(index, self.codebook)
+            if torch.is_grad_enabled() and logits.requires_grad:
+                # straight-through estimator of F.gumbel_softmax(hard=True): y = y_hard - y_soft.detach() + y_soft, so the value is the
+                # codebook row while the gradient reaches the logits through y_soft (and the codebook only through the selected rows)
+                soft = K.gumbel_softmax(logits, tau, noise=g)
+                through = K.linear(soft, self.codebook.detach().t().contiguous(), None)
+                codes = codes + (through - through.detach())
+            return codes
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if g is None else 0       # host RNG (no device sync)
+        y = K.gumbel_softmax(logits, tau, noise=g, seed=seed)                       # soft one-hot [B,G,N], noise from Philox in-kernel
+        return K.linear(y, self.codebook.t().contiguous(), None)
+
+    def forward_tokenizer(self, neighborhood, center):
+        gt_logits = self.dgcnn_1(self.encoder(neighborhood), center)
+        return gt_logits.argmax(-1).long()
+
+    def forward_tokenizer_features(self, neighborhood, center, return_global=True, draws=None):
+        with torch.no_grad():
+            idx = DGCNN.graph_index(center)                # the k=4 graph is identical for all 8 edge-conv layers
+        if not torch.is_grad_enabled():
+            # frozen teacher: head GroupNorm + LeakyReLU + hard gumbel + codebook lookup in one pass over the logits
+            B, G, _ = center.shape
+            h = self.dgcnn_1.features(self.encoder(neighborhood), center, idx)
+            noise = None
+            if draws is not None and (draws.has("gumbel") or draws.record):
+                noise = draws.get("gumbel", lambda: -torch.empty(B, G, h.shape[1], device=h.device).exponential_().log())
+            rng = self._rng(h.device)
+            sampled, _, _ = K.gn_gumbel_argmax_gather(h, B, G, self.dgcnn_1.layer5[1], self.codebook, noise=noise,
+                                                      seed=rng[0] ^ 0x5bd1e995, seed_dev=rng[1])
+            feature = self.visual_embedding(sampled, center, draws, rng)
+            if return_global:
+                feature = self.dgcnn_2(feature, center, idx)
+            rng[1].add_(1)                                 # next teacher forward draws a fresh Philox stream
+            return feature
+        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
+        sampled = self._gumbel_codes(logits, 1.0, True, draws)
+        feature = self.visual_embedding(sampled, center, draws)
+        if return_global:
+            feature = self.dgcnn_2(feature, center, idx)
+        return feature
+
+    def forward(self, inp, temperature=1., hard=False, draws=None, **kwargs):
+        neighborhood, center = self.group_divider(inp)
+        with torch.no_grad():
+            idx = DGCNN.graph_index(center)
+        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
+        sampled = self._gumbel_codes(logits, temperature, hard, draws)
+        sampled = self.visual_embedding(sampled, center, draws)
+        feature = self.dgcnn_2(sampled, center, idx)
+        coarse, fine = self.decoder(feature)
+        with torch.no_grad():
+            whole_fine = (fine + center.unsqueeze(2)).reshape(inp.size(0), -1, 3)
+            whole_coarse = (coarse + center.unsqueeze(2)).reshape(inp.size(0), -1, 3)
+        assert fine.size(2) == self.group_size
+        return (whole_coarse, whole_fine, coarse, fine, neighborhood, logits)
+
+
+@MODELS.register_module()
+class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
+    """Stage-I autoencoder / Stage-II frozen teacher (models/dvae.py:360-615): DiscreteVAE with the prompt-tuned image Transformer
+    between the codebook lookup and dgcnn_2.
+
+    The pretrained image Transformer is represented by its ``blocks`` + ``norm`` (what the reference keeps,
+    :405-410) with timm's key names; weights come from the dVAE checkpoint (``ckpt``), never from the network.
+    Optional config keys (absent from the reference YAML): ``visual_embed_depth`` / ``visual_embed_heads``
+    override the geometry implied by ``visual_embed_type``."""
+
+    def __init__(self, config, **kwargs):
+        if not config.use_deep_prompt or config.num_prompt_token <= 0:
+            raise NotImplementedError("only the deep-prompt configuration of the ACT recipe is on this path")
+        super().__init__(config)
+        self.visual_embed_type = config.visual_embed_type
+        self.visual_embed_dim = config.visual_embed_dim
+        self.freeze_visual_embed = config.freeze_visual_embed
+        self.num_prompt_token = config.num_prompt_token
+        self.use_deep_prompt = config.use_deep_prompt
         self.build_visual_embedding(config)
 
     def build_visual_embedding(self, config):
@@ -297,24 +403,6 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
             for param in self.visual_embed.parameters():
                 param.requires_grad = False
 
-    def build_loss_func(self):
-        self.loss_func_cdl1 = ChamferDistanceL1()
-        self.loss_func_cdl2 = ChamferDistanceL2()
-
-    # ---- losses (Stage I) ------------------------------------------------------------------------
-    def recon_loss(self, ret, gt):
-        whole_coarse, whole_fine, coarse, fine, group_gt, _ = ret
-        bs, g, _, _ = coarse.shape
-        coarse = coarse.reshape(bs * g, -1, 3).contiguous()
-        fine = fine.reshape(bs * g, -1, 3).contiguous()
-        group_gt = group_gt.reshape(bs * g, -1, 3).contiguous()
-        return self.loss_func_cdl1(coarse, group_gt) + self.loss_func_cdl1(fine, group_gt)
-
-    def get_loss(self, ret, gt):
-        loss_recon = self.recon_loss(ret, gt)
-        loss_klv = K.kl_to_uniform(ret[-1])        # KL(mean_g softmax(logits) || uniform), 'batchmean' (models/dvae.py:470-476)
-        return loss_recon, loss_klv
-
     # ---- prompt-tuned frozen Transformer ---------------------------------------------------------
     def _drop(self, t, draws, key):
         p = self.prompt_dropout.p
@@ -329,16 +417,6 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
 
     def visual_embedding(self, input, center, draws=None, rng=None):
         return self.visual_embedding_deep_prompt(input, center, draws=draws, rng=rng)
-
-    def _rng(self, device):
-        """(base seed, device-resident step counter) of the in-kernel Philox draws of the frozen-teacher path.  The counter lives
-        in HBM and is bumped by a device op per teacher forward, so a captured hipGraph of that forward draws fresh noise on
-        every replay and eager / replayed executions produce the same sequence."""
-        st = self.__dict__.get("_rng_state")
-        if st is None or st[1].device != device:
-            st = (int(torch.randint(0, 2 ** 62, (1,)).item()), torch.zeros(1, dtype=torch.int64, device=device))
-            self.__dict__["_rng_state"] = st
-        return st
 
     def _visual_embedding_prefix(self, input, center, draws=None, rng=None):
         """Inference form of visual_embedding_deep_prompt.  Every layer REPLACES the prompt rows of its input
@@ -419,68 +497,3 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         nrm = self.visual_embed[1]
         feature = K.layer_norm(hidden[:, Pn:].contiguous(), nrm.weight, nrm.bias, nrm.eps)
         return K.linear(feature, self.proj_post.weight, self.proj_post.bias)
-
-    # ---- tokenizer ----------------------------------------------------------------------------------
-    def _gumbel_codes(self, logits, tau, hard, draws):
-        g = None
-        if draws is not None and (draws.has("gumbel") or draws.record):
-            g = draws.get("gumbel", lambda: -torch.empty_like(logits).exponential_().log())
-        if hard:
-            if g is None:
-                g = -torch.empty_like(logits).exponential_().log()
-            index = ((logits + g) / tau).argmax(dim=-1)    # one-hot x codebook == row gather (models/dvae.py:587-588)
-            codes = F.embedding(index, self.codebook)
-            if torch.is_grad_enabled() and logits.requires_grad:
-                # straight-through estimator of F.gumbel_softmax(hard=True): y = y_hard - y_soft.detach() + y_soft, so the value is the
-                # codebook row while the gradient reaches the logits through y_soft (and the codebook only through the selected rows)
-                soft = K.gumbel_softmax(logits, tau, noise=g)
-                through = K.linear(soft, self.codebook.detach().t().contiguous(), None)
-                codes = codes + (through - through.detach())
-            return codes
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if g is None else 0       # host RNG (no device sync)
-        y = K.gumbel_softmax(logits, tau, noise=g, seed=seed)                       # soft one-hot [B,G,N], noise from Philox in-kernel
-        return K.linear(y, self.codebook.t().contiguous(), None)
-
-    def forward_tokenizer(self, neighborhood, center):
-        gt_logits = self.dgcnn_1(self.encoder(neighborhood), center)
-        return gt_logits.argmax(-1).long()
-
-    def forward_tokenizer_features(self, neighborhood, center, return_global=True, draws=None):
-        with torch.no_grad():
-            idx = DGCNN.graph_index(center)                # the k=4 graph is identical for all 8 edge-conv layers
-        if not torch.is_grad_enabled():
-            # frozen teacher: head GroupNorm + LeakyReLU + hard gumbel + codebook lookup in one pass over the logits
-            B, G, _ = center.shape
-            h = self.dgcnn_1.features(self.encoder(neighborhood), center, idx)
-            noise = None
-            if draws is not None and (draws.has("gumbel") or draws.record):
-                noise = draws.get("gumbel", lambda: -torch.empty(B, G, h.shape[1], device=h.device).exponential_().log())
-            rng = self._rng(h.device)
-            sampled, _, _ = K.gn_gumbel_argmax_gather(h, B, G, self.dgcnn_1.layer5[1], self.codebook, noise=noise,
-                                                      seed=rng[0] ^ 0x5bd1e995, seed_dev=rng[1])
-            feature = self.visual_embedding(sampled, center, draws, rng)
-            if return_global:
-                feature = self.dgcnn_2(feature, center, idx)
-            rng[1].add_(1)                                 # next teacher forward draws a fresh Philox stream
-            return feature
-        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
-        sampled = self._gumbel_codes(logits, 1.0, True, draws)
-        feature = self.visual_embedding(sampled, center, draws)
-        if return_global:
-            feature = self.dgcnn_2(feature, center, idx)
-        return feature
-
-    def forward(self, inp, temperature=1., hard=False, draws=None, **kwargs):
-        neighborhood, center = self.group_divider(inp)
-        with torch.no_grad():
-            idx = DGCNN.graph_index(center)
-        logits = self.dgcnn_1(self.encoder(neighborhood), center, idx)
-        sampled = self._gumbel_codes(logits, temperature, hard, draws)
-        sampled = self.visual_embedding(sampled, center, draws)
-        feature = self.dgcnn_2(sampled, center, idx)
-        coarse, fine = self.decoder(feature)
-        with torch.no_grad():
-            whole_fine = (fine + center.unsqueeze(2)).reshape(inp.size(0), -1, 3)
-            whole_coarse = (coarse + center.unsqueeze(2)).reshape(inp.size(0), -1, 3)
-        assert fine.size(2) == self.group_size
-        return (whole_coarse, whole_fine, coarse, fine, neighborhood, logits)

@@ -164,64 +164,26 @@ class VisableOnlyMaskTransformer(nn.Module):
         return x_vis[:, 1:], mask
 
 
-class ACTPromptedDiscreteVAEwithVIT(nn.Module):
+class DiscreteVAE(nn.Module):
+    """The plain Point-BERT tokenizer (models/dvae.py:278-358): Group -> mini-PointNet -> DGCNN -> gumbel-softmax over the codebook ->
+    DGCNN -> FoldingNet.  ACTPromptedDiscreteVAEwithVIT (:360-615) is this plus the prompt-tuned image Transformer between the codebook
+    lookup and dgcnn_2."""
+
     def __init__(self, config):
         super().__init__()
         c = config
         self.group_size, self.num_group = c.group_size, c.num_group
         self.encoder_dims, self.tokens_dims = c.encoder_dims, c.tokens_dims
-        self.visual_embed_dim, self.num_prompt_token = c.visual_embed_dim, c.num_prompt_token
         self.decoder_dims, self.num_tokens = c.decoder_dims, c.num_tokens
-        self.visual_embed_depth = int(c.get("visual_embed_depth", 12))
-        vit_heads = int(c.get("visual_embed_heads", 12))
         self.group_divider = Group(self.num_group, self.group_size)
         self.encoder = Encoder(self.encoder_dims)
         self.dgcnn_1 = DGCNN(self.encoder_dims, self.num_tokens)
         self.codebook = nn.Parameter(torch.randn(self.num_tokens, self.tokens_dims))
         self.dgcnn_2 = DGCNN(self.tokens_dims, self.decoder_dims)
         self.decoder = Decoder(self.decoder_dims, self.group_size)
-        D = self.visual_embed_dim
-        # visual_embed = Sequential(blocks, norm) of a timm ViT (models/dvae.py:405-410): LN eps 1e-6, qkv bias
-        vit = BlockList(D, self.visual_embed_depth, vit_heads, 0.0, qkv_bias=True, eps=1e-6, tag="vit")
-        self.visual_embed = nn.Sequential(vit.blocks, nn.LayerNorm(D, eps=1e-6))
-        self.proj_pre = nn.Linear(self.tokens_dims, D)
-        self.visual_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, D))
-        self.proj_post = nn.Linear(D, self.tokens_dims)
-        self.prompt_p = 0.1
-        Pn = self.num_prompt_token
-        self.visual_prompt_token = nn.Parameter(torch.zeros(1, Pn, D))
-        self.visual_prompt_pos = nn.Parameter(torch.randn(1, Pn, D))
-        self.deep_prompt_tokens = nn.Parameter(torch.zeros(self.visual_embed_depth - 1, Pn, D))
-        self.deep_prompt_pos = nn.Parameter(torch.randn(self.visual_embed_depth - 1, Pn, D))
-        for t in (self.visual_prompt_token, self.visual_prompt_pos, self.deep_prompt_tokens, self.deep_prompt_pos):
-            trunc_normal_(t)
-        for p in self.visual_embed.parameters():
-            p.requires_grad = False
-
-    # -- pieces -----------------------------------------------------------------------------
-    def _prompt_dropout(self, t, draws, key):
-        if not self.training or self.prompt_p == 0:
-            return t
-        keep = draws.get(key, lambda: (torch.rand_like(t) >= self.prompt_p).to(t.dtype))
-        return t * keep / (1.0 - self.prompt_p)
 
     def visual_embedding(self, x, center, draws):
-        """visual_embedding_deep_prompt (models/dvae.py:536-576) + incorporate_prompt (:485-498)."""
-        B, Pn = x.shape[0], self.num_prompt_token
-        pos = self.visual_pos_embed(center)
-        f = self.proj_pre(x)
-        prm = self._prompt_dropout(self.visual_prompt_token.expand(B, -1, -1), draws, "prompt.0")
-        h = torch.cat((prm, f), dim=1)
-        pos = torch.cat((self.visual_prompt_pos.expand(B, -1, -1), pos), dim=1)
-        blocks = self.visual_embed[0]
-        for i in range(self.visual_embed_depth):
-            if i > 0:
-                prm = self._prompt_dropout(self.deep_prompt_tokens[i - 1].expand(B, -1, -1), draws, f"prompt.{i}")
-                h = torch.cat((prm, h[:, Pn:]), dim=1)
-                pos = torch.cat((self.deep_prompt_pos[i - 1].expand(B, -1, -1), pos[:, Pn:]), dim=1)
-            h = blocks[i](h + pos, draws)
-        h = self.visual_embed[1](h)[:, Pn:]
-        return self.proj_post(h)
+        return x
 
     def _gumbel(self, logits, tau, hard, draws):
         g = draws.get("gumbel", lambda: -torch.empty_like(logits).exponential_().log())
@@ -266,6 +228,57 @@ class ACTPromptedDiscreteVAEwithVIT(nn.Module):
         loss_klv = F.kl_div(log_qy, log_uniform.expand(log_qy.size(0), log_qy.size(1)), None, None, "batchmean",
                             log_target=True)
         return loss_recon, loss_klv
+
+
+class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
+    def __init__(self, config):
+        super().__init__(config)
+        c = config
+        self.visual_embed_dim, self.num_prompt_token = c.visual_embed_dim, c.num_prompt_token
+        self.visual_embed_depth = int(c.get("visual_embed_depth", 12))
+        vit_heads = int(c.get("visual_embed_heads", 12))
+        D = self.visual_embed_dim
+        # visual_embed = Sequential(blocks, norm) of a timm ViT (models/dvae.py:405-410): LN eps 1e-6, qkv bias
+        vit = BlockList(D, self.visual_embed_depth, vit_heads, 0.0, qkv_bias=True, eps=1e-6, tag="vit")
+        self.visual_embed = nn.Sequential(vit.blocks, nn.LayerNorm(D, eps=1e-6))
+        self.proj_pre = nn.Linear(self.tokens_dims, D)
+        self.visual_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, D))
+        self.proj_post = nn.Linear(D, self.tokens_dims)
+        self.prompt_p = 0.1
+        Pn = self.num_prompt_token
+        self.visual_prompt_token = nn.Parameter(torch.zeros(1, Pn, D))
+        self.visual_prompt_pos = nn.Parameter(torch.randn(1, Pn, D))
+        self.deep_prompt_tokens = nn.Parameter(torch.zeros(self.visual_embed_depth - 1, Pn, D))
+        self.deep_prompt_pos = nn.Parameter(torch.randn(self.visual_embed_depth - 1, Pn, D))
+        for t in (self.visual_prompt_token, self.visual_prompt_pos, self.deep_prompt_tokens, self.deep_prompt_pos):
+            trunc_normal_(t)
+        for p in self.visual_embed.parameters():
+            p.requires_grad = False
+
+    # -- pieces -----------------------------------------------------------------------------
+    def _prompt_dropout(self, t, draws, key):
+        if not self.training or self.prompt_p == 0:
+            return t
+        keep = draws.get(key, lambda: (torch.rand_like(t) >= self.prompt_p).to(t.dtype))
+        return t * keep / (1.0 - self.prompt_p)
+
+    def visual_embedding(self, x, center, draws):
+        """visual_embedding_deep_prompt (models/dvae.py:536-576) + incorporate_prompt (:485-498)."""
+        B, Pn = x.shape[0], self.num_prompt_token
+        pos = self.visual_pos_embed(center)
+        f = self.proj_pre(x)
+        prm = self._prompt_dropout(self.visual_prompt_token.expand(B, -1, -1), draws, "prompt.0")
+        h = torch.cat((prm, f), dim=1)
+        pos = torch.cat((self.visual_prompt_pos.expand(B, -1, -1), pos), dim=1)
+        blocks = self.visual_embed[0]
+        for i in range(self.visual_embed_depth):
+            if i > 0:
+                prm = self._prompt_dropout(self.deep_prompt_tokens[i - 1].expand(B, -1, -1), draws, f"prompt.{i}")
+                h = torch.cat((prm, h[:, Pn:]), dim=1)
+                pos = torch.cat((self.deep_prompt_pos[i - 1].expand(B, -1, -1), pos[:, Pn:]), dim=1)
+            h = blocks[i](h + pos, draws)
+        h = self.visual_embed[1](h)[:, Pn:]
+        return self.proj_post(h)
 
 
 class ACT_PointDistillation(nn.Module):

@@ -65,6 +65,8 @@ TINY_STAGE2 = dict(
                      visual_embed_depth=2, visual_embed_heads=2),
 )
 TINY_B, TINY_N = 2, 128
+# the plain Point-BERT tokenizer (models/dvae.py:278-358; keys of cfgs/autoencoder/pointbert_dvae.yaml `model:`)
+TINY_DVAE = dict(NAME="DiscreteVAE", group_size=8, num_group=16, num_tokens=64, encoder_dims=64, tokens_dims=64, decoder_dims=64)
 
 # ACT_PointBERT (models/act.py:913-1096): the reference ships no YAML for it; keys as the constructor reads them
 TINY_POINTBERT = dict(

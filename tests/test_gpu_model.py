@@ -17,7 +17,7 @@ def _rel(a, ref):
     return ((a - ref).abs().max() / max(1.0, ref.abs().max())).item()
 
 
-def _grad_close(a, ref, name, tol=TOL):
+def _grad_close(a, ref, name, tol=TOL, frac=1e-3):
     """Element-wise 1e-4 (relative to the largest element) -- or, for the full-geometry graphs whose discrete selections (max over 32 / 64
     points, max over k neighbours, arg-min of Chamfer, LeakyReLU / ReLU kinks at 262,144 x 512 activations) sit within rounding distance
     of a switch: the FLIPPED elements are counted.  A flipped selection reroutes one gradient row, so at most a 1e-3 fraction of a
@@ -31,7 +31,7 @@ def _grad_close(a, ref, name, tol=TOL):
         return 0
     flipped = int((err > tol * scale).sum())
     l2 = (err.norm() / ref.norm().clamp_min(1e-30)).item()
-    assert flipped <= 1e-3 * err.numel() and l2 <= 5e-3, (name, "flipped elements", flipped, "of", err.numel(), "max", err.max().item() / scale, "l2", l2)
+    assert flipped <= frac * err.numel() and l2 <= 5e-3, (name, "flipped elements", flipped, "of", err.numel(), "max", err.max().item() / scale, "l2", l2)
     print(f"[flip-tolerant] {name}: {flipped} of {err.numel()} elements beyond {tol} (max {err.max().item() / scale:.2e}, L2 {l2:.2e})")
     return flipped
 
@@ -195,6 +195,48 @@ def test_stage1_tiny_golden(dev):
             assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
             checked += 1
     assert checked >= 60
+
+
+def test_plain_dvae_golden_and_oracle(dev):
+    """g15: `DiscreteVAE` (models/dvae.py:278-358) -- Stage-I forward with soft gumbel, both losses, every gradient, and the frozen
+    tokenizer features (hard gumbel) against the reference golden and, element-wise, against the oracle."""
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    from tests.golden.fill import TINY_DVAE
+    g = golden("g15_dvae")
+    torch.manual_seed(15)
+    vae = fill_module(build_model_from_cfg(EasyDict(dict(TINY_DVAE))), "g15.").to(dev).train()
+    assert type(vae).__name__ == "DiscreteVAE" and sorted(vae.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    pts = torch.from_numpy(clouds(15, TINY_B, TINY_N)).to(dev)
+    ret = vae(pts, temperature=0.7, hard=False, draws=Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}, device=dev))
+    assert _rel(ret[2], g["coarse"]) <= TOL and _rel(ret[3], g["fine"]) <= TOL and _rel(ret[5], g["logits"]) <= TOL
+    assert _rel(ret[1], g["whole_fine"]) <= TOL and _rel(ret[0], g["whole_coarse"]) <= TOL
+    lr, lk = vae.get_loss(ret, pts)
+    assert abs(lr.item() - g["loss"][0]) <= TOL and abs(lk.item() - g["loss"][1]) <= TOL
+    (lr + 0.1 * lk).backward()
+    pd = dict(vae.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 5e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)   # conditioning: see test_stage1_tiny_golden
+    with torch.no_grad():
+        nb, c = vae.group_divider(pts)
+        feat = vae.forward_tokenizer_features(nb, c, draws=Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}, device=dev))
+    assert _rel(feat, g["tokenizer_feat"]) <= TOL
+    from oracle import models as OM, layers as OL
+    torch.manual_seed(15)
+    ora = fill_module(OM.DiscreteVAE(OM.edict(TINY_DVAE)), "g15.").train()
+    ro = ora(pts.cpu(), OL.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}), temperature=0.7, hard=False)
+    lo = ora.get_loss(ro); (lo[0] + 0.1 * lo[1]).backward()
+    od = dict(ora.named_parameters())
+    checked = 0
+    for n, p in pd.items():
+        if p.grad is not None and od[n].grad is not None:
+            # tiny tensors: ONE flipped selection (a max over k, a LeakyReLU kink) reroutes a 2,304-wide row = 0.2 % of dgcnn_2.layer5's
+            # weight gradient; the oracle run with 1 vs 8 threads differs from itself in exactly these elements
+            # (benchmarks/diag/dvae_tiny_grad_diff.py: HIP == oracle at 1 thread everywhere within 1e-4)
+            _grad_close(p.grad, od[n].grad, n, frac=5e-3)
+            checked += 1
+    assert checked >= 50
 
 
 def test_no_host_sync_in_training_step(dev):

@@ -168,6 +168,29 @@ def test_stage1_forward_and_losses():
         assert abs(pd[str(n)].grad.norm().item() - v) <= 2e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)
 
 
+def test_plain_dvae_forward_losses_and_tokenizer():
+    """g15: the reference's DiscreteVAE (models/dvae.py:278-358, the pointbert_dvae recipe) vs the oracle restatement."""
+    from tests.golden.fill import TINY_DVAE
+    g = golden("g15_dvae")
+    torch.manual_seed(15)
+    vae = fill_module(M.DiscreteVAE(M.edict(TINY_DVAE)), "g15.").train()
+    assert sorted(vae.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    pts = torch.from_numpy(clouds(15, TINY_B, TINY_N))
+    ret = vae(pts, L.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}), temperature=0.7, hard=False)
+    _close(ret[2].detach(), g["coarse"]); _close(ret[3].detach(), g["fine"]); _close(ret[5].detach(), g["logits"], 2e-4)
+    _close(ret[1], g["whole_fine"]); _close(ret[0], g["whole_coarse"])
+    lr, lk = vae.get_loss(ret)
+    assert abs(lr.item() - g["loss"][0]) <= TOL and abs(lk.item() - g["loss"][1]) <= TOL
+    (lr + 0.1 * lk).backward()
+    pd = dict(vae.named_parameters())
+    for n, v in zip(g["grad_names"], g["grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 2e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)
+    _close(pd["codebook"].grad, g["grad_codebook"], 2e-4)
+    with torch.no_grad():
+        nb, c = vae.group_divider(pts)
+        _close(vae.forward_tokenizer_features(nb, c, L.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))})), g["tokenizer_feat"])
+
+
 def test_chamfer_reductions_and_gradcheck():
     g = golden("g5_chamfer")
     x = fill_tensor("g5.x", (4, 64, 3), "code"); y = fill_tensor("g5.y", (4, 128, 3), "code")
