@@ -367,17 +367,22 @@ class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
     override the geometry implied by ``visual_embed_type``."""
 
     def __init__(self, config, **kwargs):
-        if not config.use_deep_prompt or config.num_prompt_token <= 0:
-            raise NotImplementedError("only the deep-prompt configuration of the ACT recipe is on this path")
         super().__init__(config)
         self.visual_embed_type = config.visual_embed_type
         self.visual_embed_dim = config.visual_embed_dim
         self.freeze_visual_embed = config.freeze_visual_embed
         self.num_prompt_token = config.num_prompt_token
         self.use_deep_prompt = config.use_deep_prompt
+        if self.use_deep_prompt and (self.visual_embed_dim == 'none' or self.num_prompt_token <= 0):
+            raise ValueError("use_deep_prompt needs an image Transformer and num_prompt_token > 0 (the reference fails on this combination too)")
         self.build_visual_embedding(config)
 
     def build_visual_embedding(self, config):
+        """models/dvae.py:390-444.  Configurations: deep prompts (the ACT recipe, `use_deep_prompt`), shallow prompts (prepended once), no
+        prompts (`num_prompt_token` 0), no image Transformer (`visual_embed_dim: none`)."""
+        if self.visual_embed_dim == 'none':
+            self.visual_embed = None
+            return
         depth, heads = _VIT_GEOMETRY.get(self.visual_embed_type, (12, 12))
         depth = int(config.get("visual_embed_depth", depth))
         heads = int(config.get("visual_embed_heads", heads))
@@ -388,17 +393,21 @@ class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
         self.proj_pre = nn.Linear(self.tokens_dims, D)
         self.visual_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, D))
         self.proj_post = nn.Linear(D, self.tokens_dims)
-        self.visual_prompt_proj = nn.Identity()
-        self.prompt_dropout = nn.Dropout(0.1)
         Pn = self.num_prompt_token
-        self.visual_prompt_token = nn.Parameter(torch.zeros(1, Pn, D))
-        self.visual_prompt_pos = nn.Parameter(torch.randn(1, Pn, D))
-        trunc_normal_(self.visual_prompt_token, std=.02)
-        trunc_normal_(self.visual_prompt_pos, std=.02)
-        self.deep_prompt_tokens = nn.Parameter(torch.zeros(depth - 1, Pn, D))
-        self.deep_prompt_pos = nn.Parameter(torch.randn(depth - 1, Pn, D))
-        trunc_normal_(self.deep_prompt_tokens, std=.02)
-        trunc_normal_(self.deep_prompt_pos, std=.02)
+        if Pn > 0:
+            self.visual_prompt_proj = nn.Identity()
+            self.prompt_dropout = nn.Dropout(0.1)
+            self.visual_prompt_token = nn.Parameter(torch.zeros(1, Pn, D))
+            self.visual_prompt_pos = nn.Parameter(torch.randn(1, Pn, D))
+            trunc_normal_(self.visual_prompt_token, std=.02)
+            trunc_normal_(self.visual_prompt_pos, std=.02)
+            if self.use_deep_prompt:
+                self.deep_prompt_tokens = nn.Parameter(torch.zeros(depth - 1, Pn, D))
+                self.deep_prompt_pos = nn.Parameter(torch.randn(depth - 1, Pn, D))
+                trunc_normal_(self.deep_prompt_tokens, std=.02)
+                trunc_normal_(self.deep_prompt_pos, std=.02)
+        else:
+            self.visual_prompt_token = None
         if self.freeze_visual_embed:
             for param in self.visual_embed.parameters():
                 param.requires_grad = False
@@ -416,7 +425,39 @@ class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
         return F.dropout(t, p, True)
 
     def visual_embedding(self, input, center, draws=None, rng=None):
-        return self.visual_embedding_deep_prompt(input, center, draws=draws, rng=rng)
+        if self.visual_embed is None:
+            return input
+        if self.use_deep_prompt:
+            return self.visual_embedding_deep_prompt(input, center, draws=draws, rng=rng)
+        return self._visual_embedding_shallow(input, center, draws)
+
+    def _visual_embedding_shallow(self, input, center, draws=None):
+        """models/dvae.py:517-534: the Transformer applied as `x = blk(x + pos)` (forward_visual_feature :500-511), either on the patch
+        tokens alone -- under no_grad when it is frozen (:522-524), so nothing upstream receives a gradient through it -- or behind prompts
+        that are prepended ONCE (incorporate_prompt :485-498) and whose outputs flow through all blocks before being dropped."""
+        B = input.shape[0]
+        Pn = self.num_prompt_token
+        vp = self.visual_pos_embed
+        pos = K.mlp(center, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias)
+        hidden = K.linear(input, self.proj_pre.weight, self.proj_pre.bias)
+        train_w = not self.freeze_visual_embed
+        nrm = self.visual_embed[1]
+
+        def stack(h, p):
+            for blk in self.visual_embed[0]:
+                h = blk(h, p, None, None, train_w)
+            return h
+        if self.visual_prompt_token is None:
+            if self.freeze_visual_embed:
+                with torch.no_grad():
+                    hidden = stack(hidden, pos)
+            else:
+                hidden = stack(hidden, pos)
+        else:
+            hidden = torch.cat((self._drop(self.visual_prompt_token.expand(B, -1, -1), draws, "prompt.0"), hidden), dim=1)
+            pos = torch.cat((self.visual_prompt_pos.expand(B, -1, -1), pos), dim=1)
+            hidden = stack(hidden, pos)[:, Pn:].contiguous()
+        return K.linear(K.layer_norm(hidden, nrm.weight, nrm.bias, nrm.eps), self.proj_post.weight, self.proj_post.bias)
 
     def _visual_embedding_prefix(self, input, center, draws=None, rng=None):
         """Inference form of visual_embedding_deep_prompt.  Every layer REPLACES the prompt rows of its input

@@ -231,10 +231,20 @@ class DiscreteVAE(nn.Module):
 
 
 class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
+    """models/dvae.py:360-615.  Configurations (:513-534): deep prompts (the ACT recipe), shallow prompts (`use_deep_prompt` false), no prompts
+    (`num_prompt_token` 0; with a frozen Transformer its output is then computed under no_grad, :522-524), no Transformer (`visual_embed_dim`
+    'none')."""
+
     def __init__(self, config):
         super().__init__(config)
         c = config
         self.visual_embed_dim, self.num_prompt_token = c.visual_embed_dim, c.num_prompt_token
+        self.use_deep_prompt = bool(c.get("use_deep_prompt", True))
+        self.freeze_visual_embed = bool(c.get("freeze_visual_embed", True))
+        self.prompt_p = 0.1
+        if self.visual_embed_dim == "none":
+            self.visual_embed = None
+            return
         self.visual_embed_depth = int(c.get("visual_embed_depth", 12))
         vit_heads = int(c.get("visual_embed_heads", 12))
         D = self.visual_embed_dim
@@ -244,16 +254,20 @@ class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
         self.proj_pre = nn.Linear(self.tokens_dims, D)
         self.visual_pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, D))
         self.proj_post = nn.Linear(D, self.tokens_dims)
-        self.prompt_p = 0.1
         Pn = self.num_prompt_token
-        self.visual_prompt_token = nn.Parameter(torch.zeros(1, Pn, D))
-        self.visual_prompt_pos = nn.Parameter(torch.randn(1, Pn, D))
-        self.deep_prompt_tokens = nn.Parameter(torch.zeros(self.visual_embed_depth - 1, Pn, D))
-        self.deep_prompt_pos = nn.Parameter(torch.randn(self.visual_embed_depth - 1, Pn, D))
-        for t in (self.visual_prompt_token, self.visual_prompt_pos, self.deep_prompt_tokens, self.deep_prompt_pos):
-            trunc_normal_(t)
-        for p in self.visual_embed.parameters():
-            p.requires_grad = False
+        if Pn > 0:
+            self.visual_prompt_token = nn.Parameter(torch.zeros(1, Pn, D))
+            self.visual_prompt_pos = nn.Parameter(torch.randn(1, Pn, D))
+            trunc_normal_(self.visual_prompt_token); trunc_normal_(self.visual_prompt_pos)
+            if self.use_deep_prompt:
+                self.deep_prompt_tokens = nn.Parameter(torch.zeros(self.visual_embed_depth - 1, Pn, D))
+                self.deep_prompt_pos = nn.Parameter(torch.randn(self.visual_embed_depth - 1, Pn, D))
+                trunc_normal_(self.deep_prompt_tokens); trunc_normal_(self.deep_prompt_pos)
+        else:
+            self.visual_prompt_token = None
+        if self.freeze_visual_embed:
+            for p in self.visual_embed.parameters():
+                p.requires_grad = False
 
     # -- pieces -----------------------------------------------------------------------------
     def _prompt_dropout(self, t, draws, key):
@@ -262,11 +276,30 @@ class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
         keep = draws.get(key, lambda: (torch.rand_like(t) >= self.prompt_p).to(t.dtype))
         return t * keep / (1.0 - self.prompt_p)
 
+    def _plain_stack(self, h, pos, draws):
+        """forward_visual_feature (models/dvae.py:500-511): `x = blk(x + pos)` for every block, then the final norm."""
+        for blk in self.visual_embed[0]:
+            h = blk(h + pos, draws)
+        return self.visual_embed[1](h)
+
     def visual_embedding(self, x, center, draws):
-        """visual_embedding_deep_prompt (models/dvae.py:536-576) + incorporate_prompt (:485-498)."""
+        if self.visual_embed is None:
+            return x
         B, Pn = x.shape[0], self.num_prompt_token
         pos = self.visual_pos_embed(center)
         f = self.proj_pre(x)
+        if not self.use_deep_prompt:                                   # models/dvae.py:517-534
+            if self.visual_prompt_token is None:
+                if self.freeze_visual_embed:
+                    with torch.no_grad():
+                        h = self._plain_stack(f, pos, draws)
+                else:
+                    h = self._plain_stack(f, pos, draws)
+            else:                                                      # incorporate_prompt (:485-498) once, prompt outputs flow through
+                prm = self._prompt_dropout(self.visual_prompt_token.expand(B, -1, -1), draws, "prompt.0")
+                h = self._plain_stack(torch.cat((prm, f), dim=1), torch.cat((self.visual_prompt_pos.expand(B, -1, -1), pos), dim=1), draws)[:, Pn:]
+            return self.proj_post(h)
+        # visual_embedding_deep_prompt (models/dvae.py:536-576) + incorporate_prompt (:485-498)
         prm = self._prompt_dropout(self.visual_prompt_token.expand(B, -1, -1), draws, "prompt.0")
         h = torch.cat((prm, f), dim=1)
         pos = torch.cat((self.visual_prompt_pos.expand(B, -1, -1), pos), dim=1)

@@ -65,6 +65,9 @@ TINY_STAGE2 = dict(
                      visual_embed_depth=2, visual_embed_heads=2),
 )
 TINY_B, TINY_N = 2, 128
+# non-default configurations of ACTPromptedDiscreteVAEwithVIT (models/dvae.py:513-534), as overrides of TINY_STAGE2["dvae_config"]
+PROMPT_VARIANTS = {"shallow": dict(use_deep_prompt=False), "noprompt": dict(use_deep_prompt=False, num_prompt_token=0),
+                   "novit": dict(use_deep_prompt=False, num_prompt_token=0, visual_embed_dim="none")}
 # the plain Point-BERT tokenizer (models/dvae.py:278-358; keys of cfgs/autoencoder/pointbert_dvae.yaml `model:`)
 TINY_DVAE = dict(NAME="DiscreteVAE", group_size=8, num_group=16, num_tokens=64, encoder_dims=64, tokens_dims=64, decoder_dims=64)
 

@@ -239,6 +239,60 @@ def test_plain_dvae_golden_and_oracle(dev):
     assert checked >= 50
 
 
+@pytest.mark.parametrize("tag", ["shallow", "noprompt", "novit"])
+def test_prompt_variants_golden_and_oracle(dev, tag):
+    """g16: shallow prompts / no prompts (frozen Transformer under no_grad) / no image Transformer (models/dvae.py:513-534)."""
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    from tests.golden.fill import PROMPT_VARIANTS
+    g = golden("g16_prompt_variants")
+    cfg = dict(TINY_STAGE2["dvae_config"]); cfg.update(PROMPT_VARIANTS[tag]); cfg["NAME"] = "ACTPromptedDiscreteVAEwithVIT"
+    torch.manual_seed(16)
+    vae = fill_module(build_model_from_cfg(EasyDict(cfg)), f"g16.{tag}.").to(dev).train()
+    if hasattr(vae, "prompt_dropout"):
+        vae.prompt_dropout.p = 0.0
+    assert sorted(vae.state_dict().keys()) == [str(k) for k in g[f"{tag}.state_dict_keys"]]
+    pts = torch.from_numpy(clouds(16, TINY_B, TINY_N)).to(dev)
+    ret = vae(pts, temperature=0.7, hard=False, draws=Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}, device=dev))
+    assert _rel(ret[3], g[f"{tag}.fine"]) <= TOL and _rel(ret[5], g[f"{tag}.logits"]) <= TOL
+    lr, lk = vae.get_loss(ret, pts)
+    assert abs(lr.item() - g[f"{tag}.loss"][0]) <= TOL and abs(lk.item() - g[f"{tag}.loss"][1]) <= TOL
+    (lr + 0.1 * lk).backward()
+    pd = dict(vae.named_parameters())
+    assert sorted(n for n, p in pd.items() if p.grad is not None) == [str(n) for n in g[f"{tag}.grad_names"]]
+    for n, v in zip(g[f"{tag}.grad_names"], g[f"{tag}.grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 5e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)
+    with torch.no_grad():
+        nb, c = vae.group_divider(pts)
+        feat = vae.forward_tokenizer_features(nb, c, draws=Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}, device=dev))
+    assert _rel(feat, g[f"{tag}.tokenizer_feat"]) <= TOL
+    # every gradient against the oracle, measured in units of the reference's own fp32 noise: the oracle run with 1 and with N CPU threads
+    # (another summation order, nothing else) moves these gradients by up to 1e-3 in L2 on the `noprompt` graph (large activations behind the
+    # un-prompted Transformer, BatchNorm + ReLU switch points in the folding decoder); the HIP gradient must sit within 3x that spread of one of
+    # the two runs, or within 1e-3 in L2 (a handful of flipped ReLU decisions: benchmarks/diag/variant_grad_diff.py lists them)
+    from oracle import models as OM, layers as OL
+    ocfg = dict(cfg); ocfg.pop("NAME")
+    runs = []
+    nthreads = torch.get_num_threads()
+    try:
+        for nt in (1, max(2, nthreads)):
+            torch.set_num_threads(nt)
+            ora = fill_module(OM.ACTPromptedDiscreteVAEwithVIT(OM.edict(ocfg)), f"g16.{tag}.").train(); ora.prompt_p = 0.0
+            ro = ora(pts.cpu(), OL.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}), temperature=0.7, hard=False)
+            lo = ora.get_loss(ro); (lo[0] + 0.1 * lo[1]).backward()
+            runs.append({n: q.grad.double() for n, q in ora.named_parameters() if q.grad is not None})
+    finally:
+        torch.set_num_threads(nthreads)
+    l2 = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    for n, p in pd.items():
+        if p.grad is None or runs[0][n].norm().item() < 1e-6:          # (conv biases in front of a BatchNorm: analytically zero)
+            continue
+        a = p.grad.double().cpu()
+        spread = l2(runs[0][n], runs[1][n])
+        assert min(l2(a, runs[0][n]), l2(a, runs[1][n])) <= max(1e-3, 3 * spread), (n, l2(a, runs[0][n]), l2(a, runs[1][n]), spread)
+
+
 def test_no_host_sync_in_training_step(dev):
     """the Stage-II step must not synchronise with the host (reference: 5 boolean-index syncs + loss loop)."""
     model = _tiny(dev)

@@ -191,6 +191,30 @@ def test_plain_dvae_forward_losses_and_tokenizer():
         _close(vae.forward_tokenizer_features(nb, c, L.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))})), g["tokenizer_feat"])
 
 
+@pytest.mark.parametrize("tag", ["shallow", "noprompt", "novit"])
+def test_prompt_variants(tag):
+    """g16: the non-default configurations of ACTPromptedDiscreteVAEwithVIT (models/dvae.py:513-534) vs the oracle restatement."""
+    from tests.golden.fill import PROMPT_VARIANTS
+    g = golden("g16_prompt_variants")
+    cfg = dict(TINY_STAGE2["dvae_config"]); cfg.update(PROMPT_VARIANTS[tag])
+    torch.manual_seed(16)
+    vae = fill_module(M.ACTPromptedDiscreteVAEwithVIT(M.edict(cfg)), f"g16.{tag}.").train(); vae.prompt_p = 0.0
+    assert sorted(vae.state_dict().keys()) == [str(k) for k in g[f"{tag}.state_dict_keys"]]
+    pts = torch.from_numpy(clouds(16, TINY_B, TINY_N))
+    ret = vae(pts, L.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}), temperature=0.7, hard=False)
+    _close(ret[3].detach(), g[f"{tag}.fine"]); _close(ret[5].detach(), g[f"{tag}.logits"], 2e-4)
+    lr, lk = vae.get_loss(ret)
+    assert abs(lr.item() - g[f"{tag}.loss"][0]) <= TOL and abs(lk.item() - g[f"{tag}.loss"][1]) <= TOL
+    (lr + 0.1 * lk).backward()
+    pd = dict(vae.named_parameters())
+    assert sorted(n for n, p in pd.items() if p.grad is not None) == [str(n) for n in g[f"{tag}.grad_names"]]     # who receives a gradient at all
+    for n, v in zip(g[f"{tag}.grad_names"], g[f"{tag}.grad_norms"]):
+        assert abs(pd[str(n)].grad.norm().item() - v) <= 3e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)
+    with torch.no_grad():
+        nb, c = vae.group_divider(pts)
+        _close(vae.forward_tokenizer_features(nb, c, L.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))})), g[f"{tag}.tokenizer_feat"])
+
+
 def test_chamfer_reductions_and_gradcheck():
     g = golden("g5_chamfer")
     x = fill_tensor("g5.x", (4, 64, 3), "code"); y = fill_tensor("g5.y", (4, 128, 3), "code")
