@@ -86,8 +86,10 @@ __global__ __launch_bounds__(256) void edge_gn_apply_max_kernel(const float* __r
 }
 
 __device__ __forceinline__ float gumbel_from_bits(uint32_t bits) {
-    const float u = ((float)(bits >> 8) + 0.5f) * (1.0f / 16777216.0f);     // (0,1)
-    return -__logf(-__logf(u));                                              // -log(Exponential(1))
+    // 23 random bits + 1/2 is exact in fp32, so u lies in [2^-24, 1 - 2^-24]: never 0 and never 1.  (24 bits + 1/2 rounds its largest
+    // value up to u == 1, i.e. +inf noise once per 2^24 draws -- a NaN in the soft-max of every Stage-I step at B = 128 x 64 x 8192.)
+    const float u = ((float)(bits >> 9) + 0.5f) * (1.0f / 8388608.0f);
+    return -__logf(-__logf(u));                                              // -log(Exponential(1)), finite: |g| <= 16.7
 }
 
 // one workgroup per token row: index = argmax_c ( lrelu(gn(h[row,c])) + gumbel ), out[row,:] = codebook[index,:]

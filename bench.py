@@ -11,6 +11,7 @@ fp32, random weights, inputs resident in HBM.  Rank 0 prints ONE JSON line: whol
   cpu_baseline  the CPU oracle (pure-PyTorch restatement of the reference path) timed on the host cores (N=1 only)
 """
 import argparse
+import math
 import json
 import os
 import sys
@@ -237,6 +238,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     loss_val = float(loss.item())
+    if not math.isfinite(loss_val):                      # a diverged / NaN step would still be timed happily: refuse to report it
+        raise RuntimeError(f"bench: non-finite loss {loss_val} after {args.warmup + args.steps + 3} steps")
 
     out = {
         "metric": {1: "stage1_autoencoder_point_clouds_per_sec", 2: "stage2_pretrain_point_clouds_per_sec",

@@ -365,6 +365,20 @@ def test_soft_gumbel_softmax_and_kl_to_uniform(K, B, G, C, tau):
     assert _rel(lg2.grad, ld2.grad) <= 5e-5
 
 
+def test_in_kernel_gumbel_noise_is_finite_at_full_batch(K):
+    """Regression: 24 random bits + 1/2 rounds its largest value up to u == 1 in fp32 -> -log(-log(1)) = +inf once per 2^24 draws, i.e. a NaN
+    row in the soft gumbel-softmax of (almost) every Stage-I step at the benchmark batch (128 x 64 x 8192 = 2^26 draws per call).  The noise
+    must be finite for every one of the 2^32 bit patterns; here: five full-batch calls (3.4e8 draws) and the extreme bit patterns' images."""
+    logits = torch.zeros(128, 64, 8192, device="cuda")
+    for seed in (1, 2, 3, 12345, 2 ** 61 + 7):
+        y = K.gumbel_softmax(logits, 1.0, seed=seed)
+        assert torch.isfinite(y).all(), seed
+        assert (y.sum(-1) - 1).abs().max() < 1e-4
+        # softmax of pure gumbel noise: y = e^g / sum e^g with e^g = 1/E, E ~ Exp(1); an infinite g would show up as y == 1 exactly
+        assert y.max() < 1.0
+    del y, logits
+
+
 def test_prompt_layernorm_fused_dropout(K):
     """LN(dropout(tok) + ppos): exact against the oracle formula for p = 0; for p = 0.1 the rows are valid LayerNorm outputs of
     a mask with the right drop rate, deterministic per seed and different per cloud."""
