@@ -36,6 +36,26 @@ out["stage2"] = {"steps": 300, "batch": 128, "lr": 5e-4, "loss_first10_mean": su
 print("stage2", out["stage2"]["loss_first10_mean"], "->", out["stage2"]["loss_last10_mean"], flush=True)
 del model, w, opt, pool
 
+# ---- Stage I: 200 steps, B=128 (full-batch soft gumbel-softmax over 8,192 codes: 2^26 in-kernel noise draws per step)
+from act_amd.tools.runner_autoencoder import train_step as train_step_ae
+torch.manual_seed(0)
+cfg1 = cfg_from_yaml_file("cfgs/autoencoder/act_dvae_with_pretrained_transformer.yaml")
+ae = build_model_from_cfg(cfg1.model).to(dev).train()
+w1 = _Single(ae); opt1, _ = builder.build_opti_sche(w1, cfg1)
+for g in opt1.param_groups:
+    g["lr"] = 5e-4
+pool = [bench.synthetic_clouds(128, 1024, 300 + i, dev) for i in range(16)]
+rec = []
+for i in range(200):
+    l1, l2, _ = train_step_ae(w1, opt1, pool[i % 16], cfg1, 20000 + i)
+    rec.append(torch.stack([l1.detach(), l2.detach()]))
+r = torch.stack(rec).cpu().tolist()
+assert all(x == x and abs(x) < 1e30 for row in r for x in row), "non-finite Stage-I loss"
+out["stage1"] = {"steps": 200, "batch": 128, "lr": 5e-4, "recon_first10_mean": sum(x[0] for x in r[:10]) / 10, "recon_last10_mean": sum(x[0] for x in r[-10:]) / 10,
+                 "recon_every_10": [round(x[0], 5) for x in r[::10]], "klv_every_10": [round(x[1], 5) for x in r[::10]]}
+print("stage1", out["stage1"]["recon_first10_mean"], "->", out["stage1"]["recon_last10_mean"], flush=True)
+del ae, w1, opt1, pool
+
 # ---- finetune: synthetic 40-class ModelNet-shaped data, 150 steps at B=32
 from act_amd.datasets import build_dataset_from_cfg
 from act_amd.utils.config import EasyDict
