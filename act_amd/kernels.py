@@ -159,10 +159,13 @@ AUTOTUNE = os.environ.get("ACT_GEMM_AUTOTUNE", "1") != "0"
 # ACT_GEMM_TUNE_SAVE=<file>): first use of a listed shape costs nothing; unlisted shapes are still tuned on first use.
 _TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.json")
 _GEMM_TABLE = {}
+_MAX_SPLIT = int(os.environ.get("ACT_GEMM_MAX_SPLIT", "0"))              # experiment knob: cap split-K (table entries above the cap are re-tuned on first use)
 if os.environ.get("ACT_GEMM_TUNE_TABLE", "1") != "0" and os.path.exists(_TUNE_FILE):
     import json as _json
     with open(_TUNE_FILE) as _fh:
         _GEMM_TABLE = {tuple(int(v) for v in k.split(",")): tuple(c) for k, c in _json.load(_fh)["configs"].items()}
+    if _MAX_SPLIT > 0:
+        _GEMM_TABLE = {k: c for k, c in _GEMM_TABLE.items() if c[1] <= _MAX_SPLIT or k[4] > 8192}
 _NEW_TUNED = {}
 if os.environ.get("ACT_GEMM_TUNE_SAVE"):
     import atexit as _atexit
@@ -188,6 +191,8 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
             sp_list += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nb * s <= 8192]
         # prune hopeless configurations (a long serial K loop on a handful of workgroups takes tens of ms per trial)
         sp_list = [s for s in sp_list if not (K // s > 8192 and nb * s < 256) or s == sp_list[-1]]
+        if _MAX_SPLIT > 0 and K <= 8192:
+            sp_list = [s for s in sp_list if s <= _MAX_SPLIT]
         cands += [(tile, s) for s in sp_list]
         if M % bm == 0 and N % bn == 0 and K % 32 == 0:
             cands += [(tile + 3, s) for s in sp_list if s <= 4 and (K // s) % 32 == 0]       # software-pipelined main loop
@@ -200,6 +205,8 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
             nbq = -(-M // (128 if tile == 1 else 64)) * (N // 128)
             if K >= 1024 and nbq < 2048:
                 qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
+            if _MAX_SPLIT > 0 and K <= 8192:
+                qsp = [s for s in qsp if s <= _MAX_SPLIT]
             cands += [(12 + tile, s) for s in qsp if (K // s) % 32 == 0]                     # NN / TN: quad fragments (13: 128x128, 14: 64x128)
     scratch = torch.empty(M, N, dtype=torch.float32, device=a.device)
     e = GemmEpilogue(alpha=1.0)
