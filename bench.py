@@ -122,7 +122,7 @@ def main():
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)        # RCCL over xGMI
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)        # RCCL over xGMI
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import act_amd._C as C
