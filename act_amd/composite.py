@@ -59,7 +59,8 @@ class Dgcnn(ctypes.Structure):
 
 
 class GemmFx(ctypes.Structure):
-    _fields_ = [(n, _vp) for n in ("a_scale", "a_shift", "b_scale", "b_shift", "tile_stats", "gmax", "garg")] + [("group", _i), ("store_c", _i)]
+    _fields_ = ([(n, _vp) for n in ("a_scale", "a_shift", "b_scale", "b_shift", "tile_stats", "gmax", "garg")] + [("group", _i), ("store_c", _i)]
+                + [(n, _vp) for n in ("sa_src", "sa_arg", "ep_src", "ep_arg")])
 
 
 _P = ctypes.POINTER

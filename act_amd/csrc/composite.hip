@@ -362,6 +362,13 @@ bool pn_fused(const act_pointnet_dims_t& d) {
     const long long R = (long long)d.BG * d.n;
     return on && (d.n == 32 || d.n == 64) && R % 128 == 0 && d.C % 64 == 0;
 }
+// fused schedule with C % 128 == 0: the scattered gradient of the second max-pool (dh4, [R][C]) is never written -- the two GEMMs that
+// consume it generate it from (dout, arg2) while they stage their A operand, and the first pool's scatter-add is an epilogue of the GEMM
+// that produces dh2
+bool pn_pool_bwd_on_load(const act_pointnet_dims_t& d) {
+    static const bool on = [] { const char* e = getenv("ACT_PN_POOL_BWD_FUSE"); return !(e && e[0] == '0'); }();
+    return on && pn_fused(d) && d.C % 128 == 0;
+}
 size_t carve_pn(float* base, const act_pointnet_dims_t& d, PnSaved& sv) {
     const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
     const bool fused = pn_fused(d);
@@ -377,7 +384,7 @@ struct PnBwdScratch { float *dh4, *da3, *dh3, *dgw, *dh2, *dfg, *da1, *dh1, *act
 size_t carve_pn_bwd(float* base, const act_pointnet_dims_t& d, PnBwdScratch& sc) {
     const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
     Carver c(base);
-    sc.dh4 = c.take(R * C); sc.da3 = c.take(R * 512); sc.dh3 = c.take(R * 512); sc.dgw = c.take(BG * 512); sc.dh2 = c.take(R * 256);
+    sc.dh4 = pn_pool_bwd_on_load(d) ? nullptr : c.take(R * C); sc.da3 = c.take(R * 512); sc.dh3 = c.take(R * 512); sc.dgw = c.take(BG * 512); sc.dh2 = c.take(R * 256);
     sc.dfg = c.take(BG * 256); sc.da1 = c.take(R * 128); sc.dh1 = c.take(R * 128);
     sc.act = (pn_fused(d) && d.C % 128 != 0) ? c.take(R * 512) : nullptr;      // a3 rebuilt for the one weight gradient the fused TN kernel cannot take
     return c.used;
@@ -476,21 +483,36 @@ int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params
         RUN(act_affine_act_f32(h, st(stt, Cc, 2), st(stt, Cc, 3), 1, R, Cc, sc.act, s));
         return gemm_tn(N_, Cc, R, dy, N_, sc.act, Cc, dw, Cc, ws, wsb, s);
     };
-    RUN(act_group_max_bwd_f32(dout, sv.arg2, BG, n, C, 0, sc.dh4, s));
-    CK(wgrad_act(sc.dh4, C, sv.h3, sv.a3, sv.st2, 512, g->c4_w));
-    if (fused) CK(colsum(dout, BG, C, g->c4_b, ws, wsb, s));                                  // sum_r dh4[r,c] = sum_g dout[g,c]
-    else       CK(colsum(sc.dh4, R, C, g->c4_b, ws, wsb, s));
-    CK(gemm_nn(R, 512, C, sc.dh4, C, w->c4_w, 512, sc.da3, 512, epi0(), ws, wsb, s));
+    const bool pool_on_load = pn_pool_bwd_on_load(*d);
+    if (pool_on_load) {
+        // dW4 = dh4^T . relu(bn2(h3)) and da3 = dh4 . W4 with dh4[r][c] = (arg2[r/n][c] == r % n ? dout[r/n][c] : 0) generated on load
+        act_gemm_fx_t fx{}; fx.sa_src = dout; fx.sa_arg = sv.arg2; fx.group = n; fx.b_scale = st(sv.st2, 512, 2); fx.b_shift = st(sv.st2, 512, 3);
+        CK(gemm_fx(0, 0, C, 512, R, nullptr, C, sv.h3, 512, g->c4_w, 512, epi0(), fx, ws, wsb, s));
+        CK(colsum(dout, BG, C, g->c4_b, ws, wsb, s));                                         // sum_r dh4[r,c] = sum_g dout[g,c]
+        act_gemm_fx_t fa{}; fa.sa_src = dout; fa.sa_arg = sv.arg2; fa.group = n;
+        CK(gemm_fx(1, 0, R, 512, C, nullptr, C, w->c4_w, 512, sc.da3, 512, epi0(), fa, ws, wsb, s));
+    } else {
+        RUN(act_group_max_bwd_f32(dout, sv.arg2, BG, n, C, 0, sc.dh4, s));
+        CK(wgrad_act(sc.dh4, C, sv.h3, sv.a3, sv.st2, 512, g->c4_w));
+        if (fused) CK(colsum(dout, BG, C, g->c4_b, ws, wsb, s));                              // sum_r dh4[r,c] = sum_g dout[g,c]
+        else       CK(colsum(sc.dh4, R, C, g->c4_b, ws, wsb, s));
+        CK(gemm_nn(R, 512, C, sc.dh4, C, w->c4_w, 512, sc.da3, 512, epi0(), ws, wsb, s));
+    }
     RUN(act_bn_bwd_f32(sv.h3, sc.da3, st(sv.st2, 512, 2), st(sv.st2, 512, 3), st(sv.st2, 512, 0), st(sv.st2, 512, 1), 1, R, 512, sc.dh3, g->bn2_w, g->bn2_b,
                        ws, wsb, s));
     // the two column halves of dW3 [512, 512]: [:, :256] from the per-group path, [:, 256:] from the per-point path
     CK(gemm_tn(512, 256, R, sc.dh3, 512, sv.h2, 256, g->c3_w + 256, 512, ws, wsb, s));
     RUN(act_group_sum_f32(sc.dh3, BG, n, 512, sc.dgw, s));
-    CK(gemm_nn(R, 256, 512, sc.dh3, 512, w->c3_w + 256, 512, sc.dh2, 256, epi0(), ws, wsb, s));
     CK(gemm_tn(512, 256, BG, sc.dgw, 512, sv.fg, 256, g->c3_w, 512, ws, wsb, s));
     CK(colsum(sc.dgw, BG, 512, g->c3_b, ws, wsb, s));
     CK(gemm_nn(BG, 256, 512, sc.dgw, 512, w->c3_w, 512, sc.dfg, 256, epi0(), ws, wsb, s));
-    RUN(act_group_max_bwd_f32(sc.dfg, sv.arg1, BG, n, 256, 1, sc.dh2, s));
+    if (pool_on_load) {                                 // dh2 = dh3 . W3[:, 256:] + the first pool's backward of dfg, added in the epilogue
+        act_gemm_fx_t fe{}; fe.ep_src = sc.dfg; fe.ep_arg = sv.arg1; fe.group = n;
+        CK(gemm_fx(1, 0, R, 256, 512, sc.dh3, 512, w->c3_w + 256, 512, sc.dh2, 256, epi0(), fe, ws, wsb, s));
+    } else {
+        CK(gemm_nn(R, 256, 512, sc.dh3, 512, w->c3_w + 256, 512, sc.dh2, 256, epi0(), ws, wsb, s));
+        RUN(act_group_max_bwd_f32(sc.dfg, sv.arg1, BG, n, 256, 1, sc.dh2, s));
+    }
     CK(wgrad_act(sc.dh2, 256, sv.h1, sv.a1, sv.st1, 128, g->c2_w));
     CK(colsum(sc.dh2, R, 256, g->c2_b, ws, wsb, s));
     CK(gemm_nn(R, 128, 256, sc.dh2, 256, w->c2_w, 128, sc.da1, 128, epi0(), ws, wsb, s));

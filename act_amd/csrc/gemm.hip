@@ -482,7 +482,8 @@ extern "C" size_t act_sgemm_fx_tile_stats_floats(int M, int N) { return (size_t)
 extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                                 const act_gemm_epilogue_t* epi_in, const act_gemm_fx_t* fx, float* workspace, size_t workspace_bytes,
                                 act_stream_t stream) {
-    if (!A || !B || !fx) return ACT_E_NULLPTR;
+    if (!B || !fx) return ACT_E_NULLPTR;
+    if (!A && !fx->sa_src) return ACT_E_NULLPTR;                       // (the virtual max-pool-backward operand needs no A)
     if (M <= 0 || N <= 0 || K <= 0) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     GemmParams p{};
@@ -490,11 +491,25 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     if (epi_in) p.epi = *epi_in; else p.epi.alpha = 1.0f;
     p.fx.a_scale = fx->a_scale; p.fx.a_shift = fx->a_shift; p.fx.b_scale = fx->b_scale; p.fx.b_shift = fx->b_shift;
     p.fx.tile_stats = fx->tile_stats; p.fx.gmax = fx->gmax; p.fx.garg = fx->garg; p.fx.group = fx->group; p.fx.store_c = fx->store_c;
+    p.fx.sa_src = fx->sa_src; p.fx.sa_arg = fx->sa_arg; p.fx.ep_src = fx->ep_src; p.fx.ep_arg = fx->ep_arg;
+    int scatter = 0;                                                   // max-pool backward generated on load / added in the epilogue
+    if (fx->sa_src || fx->sa_arg) {
+        if (!fx->sa_src || !fx->sa_arg) return ACT_E_NULLPTR;
+        if ((fx->group != 32 && fx->group != 64) || (lda & 3) || ((reinterpret_cast<uintptr_t>(fx->sa_src) | reinterpret_cast<uintptr_t>(fx->sa_arg)) & 15))
+            return ACT_E_BADARG;
+        scatter |= FX_SCATTER_A;
+    }
+    if (fx->ep_src || fx->ep_arg) {
+        if (!fx->ep_src || !fx->ep_arg) return ACT_E_NULLPTR;
+        if ((fx->group != 32 && fx->group != 64) || ((reinterpret_cast<uintptr_t>(fx->ep_src) | reinterpret_cast<uintptr_t>(fx->ep_arg)) & 15)) return ACT_E_BADARG;
+        scatter |= FX_SCATTER_EPI;
+    }
     static const int group_m_env = [] { const char* e = getenv("ACT_GEMM_GROUP_M"); return e ? atoi(e) : 8; }();
     p.group_m = group_m_env;
     const bool aligned = ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && (lda & 3) == 0 && (ldb & 3) == 0;
     if (!aligned) return ACT_E_BADARG;
     if (a_kmajor && b_kmajor) {                                        // forward conv: A-side affine + ReLU, column statistics, group max
+        if (scatter) return ACT_E_BADARG;
         int mask = 0;
         if (fx->a_scale) { if (!fx->a_shift || K > 1024) return ACT_E_BADARG; mask |= FX_AFFINE_A; }
         if (fx->tile_stats) mask |= FX_COLSTATS;
@@ -508,9 +523,22 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         ACT_LAUNCH_CHECK();
         return 0;
     }
-    if (!a_kmajor && !b_kmajor) {                                      // weight gradient with the B operand activated on load
-        if (!fx->b_scale || !fx->b_shift || !C) return ACT_E_NULLPTR;
-        if ((M % 128) || (N % 128) || (K % 32)) return ACT_E_BADARG;
+    if (a_kmajor && !b_kmajor) {                                       // input gradient dX = dY . W with dY and / or one term of dX being a max-pool backward
+        if (!scatter || !C) return ACT_E_BADARG;
+        if ((M % 128) || (N % 128) || (K % 16) || (M % fx->group)) return ACT_E_BADARG;
+        if ((scatter & FX_SCATTER_EPI) && ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15))) return ACT_E_BADARG;
+        p.tiles_m = M / 128; p.tiles_n = N / 128; p.k_per_split = K; p.partial = nullptr;
+        ActProfScope ps(KID_GEMM_NN, s, 2.0 * M * N * (double)K, 4.0 * ((double)N * K + (double)M * N));
+        if (!launch_sgemm_q16_fx(p, 1, scatter, dim3((unsigned)(p.tiles_m * p.tiles_n)), s)) return ACT_E_BADARG;
+        ACT_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!a_kmajor && !b_kmajor) {                                      // weight gradient: B activated on load and / or A = max-pool backward on load
+        if (scatter & FX_SCATTER_EPI) return ACT_E_BADARG;
+        int mask = scatter;
+        if (fx->b_scale || fx->b_shift) { if (!fx->b_scale || !fx->b_shift) return ACT_E_NULLPTR; mask |= FX_AFFINE_B; }
+        if (!mask || !C) return ACT_E_NULLPTR;
+        if ((M % 128) || (N % 128) || (K % 32) || (scatter && (K % fx->group))) return ACT_E_BADARG;
         p.tiles_m = M / 128; p.tiles_n = N / 128;
         const long long nt = (long long)p.tiles_m * p.tiles_n;
         int splits = (int)((768 + nt - 1) / nt);                       // ~3 workgroups per CU; K = rows of the batch, a few hundred thousand
@@ -519,8 +547,8 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         int kps = (K + splits - 1) / splits; kps = (kps + 31) / 32 * 32; splits = (K + kps - 1) / kps;
         if (splits > 1 && !workspace) return ACT_E_NULLPTR;
         p.k_per_split = kps; p.partial = splits > 1 ? workspace : nullptr;
-        ActProfScope ps(KID_GEMM_TN, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-        launch_sgemm_q16_tn_fx(p, dim3((unsigned)nt, 1, (unsigned)splits), s);
+        ActProfScope ps(KID_GEMM_TN, s, 2.0 * M * N * (double)K, 4.0 * ((scatter ? 0.0 : (double)M * K) + (double)N * K + (double)M * N));
+        if (!launch_sgemm_q16_fx(p, 0, mask, dim3((unsigned)nt, 1, (unsigned)splits), s)) return ACT_E_BADARG;
         ACT_LAUNCH_CHECK();
         if (splits > 1) {
             const long long total = (long long)M * N;

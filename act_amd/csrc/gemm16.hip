@@ -395,9 +395,14 @@ bool launch_sgemm_nt16_fx(const GemmParams& p, int tile, int fx, dim3 grid, hipS
 // Constraint: a row-contiguous operand needs a 64-wide wave extent, i.e. BM = 128 when A is [K][M], BN = 128 when B is [K][N].
 // FXB (weight gradients of the mini-PointNet): B'[k,n] = relu(B[k,n] * b_scale[n] + b_shift[n]) while B is staged -- the activated input of
 // the layer is recomputed from the stored pre-BatchNorm tensor instead of being kept (a thread's float4 always covers the same 4 columns).
-template <int BM, int BN, bool A_K, bool B_K, bool MG = false, bool FXB = false>
+// FXA (max-pool backward on load): the A operand is virtual, A[r][c] = sa_arg[r/group][c] == r % group ? sa_src[r/group][c] : 0 with lda = channels:
+// the scattered gradient of torch.max(feature, dim=2) is generated while it is staged instead of being written (and read twice) as an
+// [R][C] tensor.  FXE: the same term added in the epilogue, C[r][c] += ep_arg[r/group][c] == r % group ? ep_src[r/group][c] : 0.
+template <int BM, int BN, bool A_K, bool B_K, bool MG = false, bool FXB = false, bool FXA = false, bool FXE = false>
 __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
     static_assert(!FXB || !B_K, "FXB: row-contiguous B");
+    static_assert(!(FXA || FXE) || (BM == 128 && !MG), "fused max-pool backward: 128-row tiles, no M tail");
+    static_assert(!FXE || !B_K, "FXE: float4 epilogue");
     static_assert(A_K || BM == 128, "row-contiguous A needs BM = 128");
     static_assert(B_K || BN == 128, "row-contiguous B needs BN = 128");
     static_assert(!(A_K && B_K), "NT is sgemm_nt16_kernel");
@@ -443,9 +448,33 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
     }
     float4 ra0, ra1, rb0, rb1;
     ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // FXA: the loads fetch (value, arg) of the group row; the select against the row's position in its group happens in store_lds, so the
+    // loads stay in flight across compute() like the plain ones
+    int4 qa0 = make_int4(0, 0, 0, 0), qa1 = make_int4(0, 0, 0, 0);
+    int pos0 = 0, pos1 = 0;                                 // r % group of the rows this thread stages (A_K: fixed; else: per K-tile)
+    const int gsh = (FXA || FXE) ? (p.fx.group == 64 ? 6 : 5) : 0, gmask = (1 << gsh) - 1;
+    size_t fa0 = 0, fa1 = 0;                                // A_K: offsets of the two group rows (+ k); else recomputed per tile
+    if constexpr (FXA && A_K) {
+        const int r0 = m0 + srow, r1 = r0 + 64;
+        pos0 = r0 & gmask; pos1 = r1 & gmask;
+        fa0 = (size_t)(r0 >> gsh) * p.lda + kbeg + sch * 4; fa1 = (size_t)(r1 >> gsh) * p.lda + kbeg + sch * 4;
+    }
     auto load_g = [&](int t) {
-        ra0 = *reinterpret_cast<const float4*>(ga + t * ga_step);
-        if constexpr (NA > 1) ra1 = *reinterpret_cast<const float4*>(ga + ga_second + t * ga_step);
+        if constexpr (FXA) {
+            if constexpr (A_K) {
+                ra0 = *reinterpret_cast<const float4*>(p.fx.sa_src + fa0 + t * BK); qa0 = *reinterpret_cast<const int4*>(p.fx.sa_arg + fa0 + t * BK);
+                ra1 = *reinterpret_cast<const float4*>(p.fx.sa_src + fa1 + t * BK); qa1 = *reinterpret_cast<const int4*>(p.fx.sa_arg + fa1 + t * BK);
+            } else {                                        // [K][M]: this thread's k-rows of tile t are r, r + 8
+                const int r = kbeg + t * BK + tid / (BM / 4), c = m0 + (tid % (BM / 4)) * 4;
+                pos0 = r & gmask; pos1 = (r + 8) & gmask;
+                const size_t o0 = (size_t)(r >> gsh) * p.lda + c, o1 = (size_t)((r + 8) >> gsh) * p.lda + c;
+                ra0 = *reinterpret_cast<const float4*>(p.fx.sa_src + o0); qa0 = *reinterpret_cast<const int4*>(p.fx.sa_arg + o0);
+                ra1 = *reinterpret_cast<const float4*>(p.fx.sa_src + o1); qa1 = *reinterpret_cast<const int4*>(p.fx.sa_arg + o1);
+            }
+        } else {
+            ra0 = *reinterpret_cast<const float4*>(ga + t * ga_step);
+            if constexpr (NA > 1) ra1 = *reinterpret_cast<const float4*>(ga + ga_second + t * ga_step);
+        }
         rb0 = *reinterpret_cast<const float4*>(gb + t * gb_step);
         if constexpr (NB > 1) rb1 = *reinterpret_cast<const float4*>(gb + gb_second + t * gb_step);
     };
@@ -456,6 +485,10 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
         bsh = *reinterpret_cast<const float4*>(p.fx.b_shift + n0 + (tid % (BN / 4)) * 4);
     }
     auto store_lds = [&](int buf) {
+        if constexpr (FXA) {
+            ra0.x = qa0.x == pos0 ? ra0.x : 0.f; ra0.y = qa0.y == pos0 ? ra0.y : 0.f; ra0.z = qa0.z == pos0 ? ra0.z : 0.f; ra0.w = qa0.w == pos0 ? ra0.w : 0.f;
+            ra1.x = qa1.x == pos1 ? ra1.x : 0.f; ra1.y = qa1.y == pos1 ? ra1.y : 0.f; ra1.z = qa1.z == pos1 ? ra1.z : 0.f; ra1.w = qa1.w == pos1 ? ra1.w : 0.f;
+        }
         if constexpr (FXB) {
             rb0.x = fmaxf(rb0.x * bsc.x + bsh.x, 0.f); rb0.y = fmaxf(rb0.y * bsc.y + bsh.y, 0.f);
             rb0.z = fmaxf(rb0.z * bsc.z + bsh.z, 0.f); rb0.w = fmaxf(rb0.w * bsc.w + bsh.w, 0.f);
@@ -520,6 +553,12 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
                 } else {
                     v.x = epilogue_apply(p.epi, v.x, row, col); v.y = epilogue_apply(p.epi, v.y, row, col + 1);
                     v.z = epilogue_apply(p.epi, v.z, row, col + 2); v.w = epilogue_apply(p.epi, v.w, row, col + 3);
+                    if constexpr (FXE) {
+                        const size_t o = (size_t)(row >> gsh) * p.N + col; const int pos = row & gmask;
+                        const int4 ea = *reinterpret_cast<const int4*>(p.fx.ep_arg + o);
+                        const float4 ev = *reinterpret_cast<const float4*>(p.fx.ep_src + o);
+                        v.x += ea.x == pos ? ev.x : 0.f; v.y += ea.y == pos ? ev.y : 0.f; v.z += ea.z == pos ? ev.z : 0.f; v.w += ea.w == pos ? ev.w : 0.f;
+                    }
                     float* c = p.C + (size_t)row * p.ldc + col;
                     if ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
                         float4* c4 = reinterpret_cast<float4*>(c);
@@ -567,9 +606,19 @@ bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor,
     return true;
 }
 
-bool launch_sgemm_q16_tn_fx(const GemmParams& p, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, false, false, false, true>), grid, dim3(256), 0, s, p);
-    return true;
+bool launch_sgemm_q16_fx(const GemmParams& p, int a_kmajor, int fx_mask, dim3 grid, hipStream_t s) {
+#define QL(AK, FB, FA, FE) hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, AK, false, false, FB, FA, FE>), grid, dim3(256), 0, s, p); return true
+    if (!a_kmajor) {                                                  // TN weight gradients
+        if (fx_mask == FX_AFFINE_B) { QL(false, true, false, false); }
+        if (fx_mask == (FX_AFFINE_B | FX_SCATTER_A)) { QL(false, true, true, false); }
+        if (fx_mask == FX_SCATTER_A) { QL(false, false, true, false); }
+    } else {                                                          // NN input gradients
+        if (fx_mask == FX_SCATTER_A) { QL(true, false, true, false); }
+        if (fx_mask == FX_SCATTER_EPI) { QL(true, false, false, true); }
+        if (fx_mask == (FX_SCATTER_A | FX_SCATTER_EPI)) { QL(true, false, true, true); }
+    }
+#undef QL
+    return false;
 }
 
 template <int BM, int BN>

@@ -16,8 +16,10 @@ struct GemmFx {
     float* tile_stats;                             // NT: [tiles_m][2][N] per-tile column mean and sum of squared deviations of the stored values
     float* gmax; int32_t* garg; int group;         // NT: max (+ first arg-max) over every `group` (32 | 64) consecutive rows -> [M/group][N]
     int store_c;                                   // 0: C is not written (only its group max is wanted)
+    const float* sa_src; const int32_t* sa_arg;    // NN / TN: virtual A[r][c] = sa_arg[r/group][c] == r % group ? sa_src[r/group][c] : 0 (max-pool backward on load)
+    const float* ep_src; const int32_t* ep_arg;    // NN: C[r][c] += ep_arg[r/group][c] == r % group ? ep_src[r/group][c] : 0 in the epilogue
 };
-enum { FX_AFFINE_A = 1, FX_COLSTATS = 2, FX_GROUPMAX = 4, FX_NOSTORE = 8, FX_AFFINE_B = 16 };
+enum { FX_AFFINE_A = 1, FX_COLSTATS = 2, FX_GROUPMAX = 4, FX_NOSTORE = 8, FX_AFFINE_B = 16, FX_SCATTER_A = 32, FX_SCATTER_EPI = 64 };
 
 struct GemmParams {
     GemmFx fx;
@@ -78,4 +80,5 @@ void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s);
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
 // NT kernels with fused producer / consumer passes (gemm16.hip); fx_mask = FX_* bits; tile 0 = 128x128, 1 = 128x64.  false = no such kernel
 bool launch_sgemm_nt16_fx(const GemmParams& p, int tile, int fx_mask, dim3 grid, hipStream_t s);
-bool launch_sgemm_q16_tn_fx(const GemmParams& p, dim3 grid, hipStream_t s);      // TN 128x128 with FX_AFFINE_B
+// quad-fragment 128x128 kernels with fused passes: TN with FX_AFFINE_B (+ FX_SCATTER_A), NN with FX_SCATTER_A and / or FX_SCATTER_EPI
+bool launch_sgemm_q16_fx(const GemmParams& p, int a_kmajor, int fx_mask, dim3 grid, hipStream_t s);

@@ -116,13 +116,23 @@ int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const floa
  *        every `group` (32 | 64) consecutive rows, the max-pool over the points of a group;  store_c = 0: C itself is not written.
  *        Needs M % 128 == 0, N % 64 == 0, K % 16 == 0, 16-byte aligned operands.
  *  (0,0) weight gradient: b_scale/b_shift [N]: B'[k,n] = max(0, B[k,n]*b_scale[n] + b_shift[n]) applied while B is staged (M, N % 128 == 0, K % 32 == 0,
- *        deterministic split-K through `workspace`). */
+ *        deterministic split-K through `workspace`).
+ *  backward of the max-pool (torch.max(feature, dim=2), models/dvae.py:211,214: the gradient goes to the arg-max row of every group only):
+ *        sa_src [R/group][C] + sa_arg int32 (nullable pair): the A operand is VIRTUAL, A[r][c] = sa_arg[r/group][c] == r % group ? sa_src[r/group][c] : 0,
+ *        generated while it is staged (A may be NULL, lda = C) -- for the input gradient (1,0: rows r = M, c = K) and the weight gradient
+ *        (0,0: r = K, c = M) of the conv in front of the pool, so the scattered [R][C] gradient tensor never exists;  ep_src / ep_arg
+ *        [M/group][N] (nullable pair, (1,0) only): C[r][c] += ep_arg[r/group][c] == r % group ? ep_src[r/group][c] : 0 in the epilogue (the
+ *        second path into the tensor in front of the first pool).  group 32 | 64, M % 128 == 0, N % 128 == 0, C % 4 == 0. */
 typedef struct {
     const float *a_scale, *a_shift, *b_scale, *b_shift;
     float*   tile_stats;
     float*   gmax;
     int32_t* garg;
     int      group, store_c;
+    const float*   sa_src;
+    const int32_t* sa_arg;
+    const float*   ep_src;
+    const int32_t* ep_arg;
 } act_gemm_fx_t;
 size_t act_sgemm_fx_tile_stats_floats(int M, int N);
 int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,

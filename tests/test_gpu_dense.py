@@ -636,3 +636,70 @@ def test_gemm_quad_fragment_kernels_nn_tn(K, tile):
     assert _rel(c2, 0.5 * ref + base.double().cpu()) <= 2e-5
     wide = _rnd("q.wide", Kd, 512).cuda()                                             # B = wide[:, 128:512] : [K][N] with ldb = 512
     assert _rel(K.gemm(a.cuda(), wide[:, 128:], True, False, cfg=(tile, 1)), a.double() @ wide[:, 128:].double().cpu()) <= 2e-5
+
+
+@pytest.mark.parametrize("group,R,C,N", [(32, 1024, 128, 256), (64, 2048, 384, 512)])
+def test_gemm_with_maxpool_backward_generated_on_load(K, group, R, C, N):
+    """act_sgemm_fx_f32 with the scattered gradient of torch.max(feature, dim=2) (models/dvae.py:211,214) as a VIRTUAL operand: input gradient
+    (1,0) with A generated on load and / or a second scatter added in the epilogue, weight gradient (0,0) with A generated on load (with and
+    without the activated-on-load B).  Against the same products on the materialised scatter: the generated values are the stored values, so
+    the fp32 result may differ only by the kernel's summation order (here: the same kernel family -> 1e-6), and against float64."""
+    import ctypes
+    import act_amd.composite as CP
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(group + C)
+    G = R // group
+    dout = torch.randn(G, C, generator=g).to(dev)
+    arg = torch.randint(0, group, (G, C), generator=g, dtype=torch.int32).to(dev)
+    dense = torch.zeros(G, group, C, device=dev)
+    dense.scatter_(1, arg.long().unsqueeze(1), dout.unsqueeze(1))
+    dense = dense.reshape(R, C)                                         # dh[r][c] = arg[r/group][c] == r % group ? dout[r/group][c] : 0
+    st = torch.cuda.current_stream().cuda_stream
+    epi = K.GemmEpilogue(); epi.alpha = 1.0
+    ws = torch.empty(64 << 20, device=dev)
+
+    def call(ak, bk, M, Nn, Kd, A, lda, Bm, ldb, out, fx):
+        rc = CP.lib.act_sgemm_fx_f32(ak, bk, M, Nn, Kd, A.data_ptr() if A is not None else None, lda, Bm.data_ptr(), ldb, out.data_ptr(), Nn,
+                                     ctypes.byref(epi), ctypes.byref(fx), ws.data_ptr(), ws.numel() * 4, st)
+        assert rc == 0, rc
+    # ---- input gradient dX = dh . W, W [C][N]
+    W = (torch.randn(C, N, generator=g) * 0.1).to(dev)
+    ep_src = torch.randn(G, N, generator=g).to(dev)
+    ep_arg = torch.randint(0, group, (G, N), generator=g, dtype=torch.int32).to(dev)
+    ep_dense = torch.zeros(G, group, N, device=dev).scatter_(1, ep_arg.long().unsqueeze(1), ep_src.unsqueeze(1)).reshape(R, N)
+    ref = dense.double() @ W.double()
+    fx = CP.GemmFx(); fx.sa_src = dout.data_ptr(); fx.sa_arg = arg.data_ptr(); fx.group = group
+    out = torch.empty(R, N, device=dev)
+    call(1, 0, R, N, C, None, C, W, N, out, fx)
+    assert _rel(out, ref) <= 1e-5
+    assert _rel(out, K.gemm(dense, W, True, False, cfg=(13, 1))) <= 1e-6          # the 128x128 quad kernel on the stored operand
+    fx2 = CP.GemmFx(); fx2.sa_src = dout.data_ptr(); fx2.sa_arg = arg.data_ptr(); fx2.group = group
+    fx2.ep_src = ep_src.data_ptr(); fx2.ep_arg = ep_arg.data_ptr()
+    out2 = torch.empty(R, N, device=dev)
+    call(1, 0, R, N, C, None, C, W, N, out2, fx2)
+    assert _rel(out2, ref + ep_dense.double()) <= 1e-5
+    fx3 = CP.GemmFx(); fx3.ep_src = ep_src.data_ptr(); fx3.ep_arg = ep_arg.data_ptr(); fx3.group = group
+    out3 = torch.empty(R, N, device=dev)
+    call(1, 0, R, N, C, dense, C, W, N, out3, fx3)
+    assert torch.equal(out3, out2)                                       # stored vs generated A: bit-identical
+    # ---- weight gradient dW = dh^T . act(X), X [R][N]
+    X = torch.randn(R, N, generator=g).to(dev)
+    sc = (torch.rand(N, generator=g) + 0.5).to(dev); sh = (torch.randn(N, generator=g) * 0.2).to(dev)
+    act = torch.relu(X * sc + sh)
+    fw = CP.GemmFx(); fw.sa_src = dout.data_ptr(); fw.sa_arg = arg.data_ptr(); fw.group = group
+    dw = torch.empty(C, N, device=dev)
+    call(0, 0, C, N, R, None, C, X, N, dw, fw)
+    assert _rel(dw, dense.double().t() @ X.double()) <= 1e-5
+    fw2 = CP.GemmFx(); fw2.sa_src = dout.data_ptr(); fw2.sa_arg = arg.data_ptr(); fw2.group = group; fw2.b_scale = sc.data_ptr(); fw2.b_shift = sh.data_ptr()
+    dw2 = torch.empty(C, N, device=dev)
+    call(0, 0, C, N, R, None, C, X, N, dw2, fw2)
+    assert _rel(dw2, dense.double().t() @ act.double()) <= 1e-5
+    fw3 = CP.GemmFx(); fw3.b_scale = sc.data_ptr(); fw3.b_shift = sh.data_ptr()
+    dw3 = torch.empty(C, N, device=dev)
+    call(0, 0, C, N, R, dense, C, X, N, dw3, fw3)
+    assert torch.equal(dw3, dw2)
+    # ---- argument checks
+    bad = CP.GemmFx(); bad.sa_src = dout.data_ptr()
+    assert CP.lib.act_sgemm_fx_f32(1, 0, R, N, C, None, C, W.data_ptr(), N, out.data_ptr(), N, ctypes.byref(epi), ctypes.byref(bad), None, 0, st) != 0
+    bad2 = CP.GemmFx(); bad2.sa_src = dout.data_ptr(); bad2.sa_arg = arg.data_ptr(); bad2.group = 48
+    assert CP.lib.act_sgemm_fx_f32(1, 0, R, N, C, None, C, W.data_ptr(), N, out.data_ptr(), N, ctypes.byref(epi), ctypes.byref(bad2), None, 0, st) != 0
