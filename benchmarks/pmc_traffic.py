@@ -60,7 +60,7 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (
        "units": "bytes per launch = counter [KiB] * 1024 * calibration factor",
        "calibration": {"kernel": CAL_KERNEL, "known_bytes_written_per_launch": CAL_BYTES, "known_bytes_read_per_launch": 2.0 * CAL_BYTES,
                        "fetch_factor": kf, "write_factor": kw,
-                       "cross_check": "group_max_bwd_kernel writes 262144 x (384 + 256) / 2 x 4 = 335,544,320 B per launch on average"},
+                       "cross_check": "colstats_stage1 (BatchNorm backward sums) reads x and dy = 2 x 262144 x (128 + 512) / 2 x 4 = 671,088,640 B per launch on average and writes (almost) nothing"},
        "kernels": {}}
 for k in sorted(set(fetch) | set(write)):
     fb = fetch.get(k, (0.0, 0))[0] * 1024.0 * kf
