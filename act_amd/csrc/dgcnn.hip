@@ -10,6 +10,7 @@
 // Tokenizer: hard gumbel-softmax + one-hot x codebook == argmax_n(logits + G) followed by a row gather, fused with the
 // head's GroupNorm + LeakyReLU so the [B,G,8192] logits are read exactly once and never rewritten.
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------- GN statistics
 // yz [B*G, ldy] with Y at column offset 0 and Z at column offset zoff (zoff < 0: no Z term); idx int64 [B,k,G] or null
@@ -144,6 +145,61 @@ static inline unsigned grid_for(long long total, int block) {
     long long g = (total + block - 1) / block; if (g > 8192) g = 8192; if (g < 1) g = 1; return (unsigned)g;
 }
 
+// Graph layers whose (sample, group) slice of [Y | Z] fits the LDS (G x C/groups x 2 floats <= 140 KB: every layer of the 64-token DGCNNs):
+// ONE kernel, one workgroup per (sample, group).  The slice is read from HBM once (the three-kernel path reads Y k times and Z once for the
+// statistics and again for the apply pass, through gathers), statistics and the max / LeakyReLU pass run out of LDS.
+#define EGF_THREADS 1024
+__global__ __launch_bounds__(EGF_THREADS) void edge_gn_fused_kernel(const float* __restrict__ yz, int ldy, int zoff, const int64_t* __restrict__ idx,
+                                                            int G, int k, int C, int groups, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, float slope,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            float* __restrict__ out, int ldo, int ooff) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float sh[2][EGF_THREADS / 64];
+    __shared__ float stat[2];
+    const int b = blockIdx.x / groups, gi = blockIdx.x % groups;
+    const int cpg = C / groups, c0 = gi * cpg, cq = cpg >> 2;
+    float* Ys = lds; float* Zs = lds + (size_t)G * cpg; int* Is = reinterpret_cast<int*>(lds + (size_t)2 * G * cpg);     // Is[j][g]
+    for (int i = threadIdx.x; i < G * cq; i += EGF_THREADS) {
+        const int g = i / cq, c4 = (i % cq) * 4;
+        const float* row = yz + ((size_t)b * G + g) * ldy + c0 + c4;
+        *reinterpret_cast<float4*>(&Ys[g * cpg + c4]) = *reinterpret_cast<const float4*>(row);
+        *reinterpret_cast<float4*>(&Zs[g * cpg + c4]) = *reinterpret_cast<const float4*>(row + zoff);
+    }
+    for (int i = threadIdx.x; i < k * G; i += EGF_THREADS) Is[i] = (int)idx[(size_t)b * k * G + i];
+    __syncthreads();
+    // statistics of pre = Y[src] + Z over (G, k, cpg), pivot = first element; channel fastest across the threads (conflict-free LDS rows)
+    const float pv = Ys[Is[0] * cpg] + Zs[0];
+    const int total = G * cpg;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < total; i += EGF_THREADS) {
+        const int g = i / cpg, c = i % cpg;
+        const float z = Zs[i] - pv;
+        for (int j = 0; j < k; ++j) { const float v = Ys[Is[j * G + g] * cpg + c] + z; s += v; q += v * v; }
+    }
+    s = wave_sum_f32(s); q = wave_sum_f32(q);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float S = 0.f, Q = 0.f;
+        for (int w = 0; w < EGF_THREADS / 64; ++w) { S += sh[0][w]; Q += sh[1][w]; }
+        const float n = (float)G * (float)k * (float)cpg;
+        const float dm = S / n, var = fmaxf(Q / n - dm * dm, 0.f);
+        stat[0] = pv + dm; stat[1] = rsqrtf(var + eps);
+        mean_out[blockIdx.x] = stat[0]; rstd_out[blockIdx.x] = stat[1];
+    }
+    __syncthreads();
+    const float mu = stat[0], rs = stat[1];
+    for (int i = threadIdx.x; i < total; i += EGF_THREADS) {
+        const int g = i / cpg, c = i % cpg;
+        float vmax = -3.0e38f, vmin = 3.0e38f;
+        for (int j = 0; j < k; ++j) { const float v = Ys[Is[j * G + g] * cpg + c]; vmax = fmaxf(vmax, v); vmin = fminf(vmin, v); }
+        const float a = rs * gamma[c0 + c];
+        const float v = (a >= 0.f ? vmax : vmin) + Zs[i];
+        out[((size_t)b * G + g) * ldo + ooff + c0 + c] = lrelu((v - mu) * a + beta[c0 + c], slope);
+    }
+}
+
 extern "C" int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C,
                                          int groups, const float* gamma, const float* beta, float eps, float slope,
                                          float* stats /* [18][B*groups] */, float* out, int ldo, int ooff, act_stream_t stream) {
@@ -153,6 +209,21 @@ extern "C" int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, con
     ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * k + (zoff >= 0 ? 2 : 0) + 1));
     float* mean = stats; float* rstd = stats + (size_t)B * groups;
     float* part = stats + (size_t)2 * B * groups;
+    {
+        static const bool fuse = [] { const char* e = getenv("ACT_EDGE_GN_FUSE"); return !(e && e[0] == '0'); }();
+        const int cpg = C / groups;
+        const size_t smem = ((size_t)2 * G * cpg + (size_t)k * G) * sizeof(float);
+        if (fuse && idx && zoff >= 0 && (cpg & 3) == 0 && (ldy & 3) == 0 && (zoff & 3) == 0 && smem <= 140 * 1024 &&
+            (reinterpret_cast<uintptr_t>(yz) & 15) == 0) {
+            if (smem > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(edge_gn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(edge_gn_fused_kernel, dim3(B * groups), dim3(EGF_THREADS), smem, s, yz, ldy, zoff, idx, G, k, C, groups, gamma, beta, eps, slope,
+                               mean, rstd, out, ldo, ooff);
+            ACT_LAUNCH_CHECK(); return 0;
+        }
+    }
     hipLaunchKernelGGL(edge_gn_stats_kernel, dim3(B * groups, GN_SPLIT), dim3(256), 0, s, yz, ldy, zoff, idx, G, k, C, groups, part);
     hipLaunchKernelGGL(edge_gn_finalize_kernel, dim3((B * groups + 63) / 64), dim3(64), 0, s, yz, ldy, zoff, idx, G, k, C, groups, B * groups,
                        part, eps, mean, rstd);

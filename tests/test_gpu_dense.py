@@ -2,6 +2,7 @@
 the fused Transformer block and the cosine loss -- against float64 CPU math, the CPU oracle and the goldens.
 Tolerance: 1e-4 (north_star) relative to max(1, |ref|max) unless stated."""
 import numpy as np
+import os
 import pytest
 import torch
 
@@ -276,9 +277,10 @@ def test_group_max_and_group_add(K):
         assert _rel(a.grad, b.grad) <= 5e-5
 
 
-def test_dgcnn_edge_tail_and_head(K):
+@pytest.mark.parametrize("B,G,k,C", [(3, 64, 4, 256), (2, 64, 4, 1024), (5, 64, 4, 512), (2, 16, 3, 64), (1, 512, 4, 256)])
+def test_dgcnn_edge_tail_and_head(K, B, G, k, C):
+    """(…, 64, 4, 1024): the largest slice that takes the single-kernel LDS path (132 KB); (1, 512, …): too large, three-kernel path."""
     import torch.nn.functional as F
-    B, G, k, C = 3, 64, 4, 256
     yz = _rnd("eg.yz", B * G, 2 * C); gn = torch.nn.GroupNorm(4, C).cuda()
     with torch.no_grad():
         gn.weight.copy_(_rnd("eg.w", C)); gn.bias.copy_(0.1 * _rnd("eg.b", C))     # negative gammas exercise the min branch
@@ -290,6 +292,8 @@ def test_dgcnn_edge_tail_and_head(K):
     buf = torch.zeros(B * G, C + 40, device="cuda")
     out = K.edge_gn_lrelu_max(yz.cuda(), C, idx.cuda(), B, G, k, C, gn, out=buf, ooff=40)
     assert _rel(out[:, 40:], ref) <= 2e-5 and (out[:, :40] == 0).all()
+    saved = os.environ.get("ACT_EDGE_GN_FUSE")              # (read once per process: this only documents which path ran)
+    assert saved is None
     # head: GroupNorm + LeakyReLU only
     h = _rnd("eg.h", B * G, C) * 2 + 0.3
     href = F.leaky_relu(F.group_norm(h.double().view(B, G, C).transpose(1, 2), 4, gn.weight.double().cpu(), gn.bias.double().cpu(), gn.eps), 0.2)

