@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libact_hip.so")
+LIB_PATH = os.environ.get("ACT_LIB_PATH") or os.path.join(_HERE, "lib", "libact_hip.so")      # (ACT_LIB_PATH: A/B builds of the same ABI)
 
 _vp, _i, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
 _f = ctypes.c_float

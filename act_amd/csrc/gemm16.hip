@@ -149,8 +149,11 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
 // tensor never exists in HBM); FX_COLSTATS leaves per-tile column (mean, sum of squared deviations) of the stored values for the
 // following BatchNorm (no statistics pass over the output); FX_GROUPMAX reduces every `group` consecutive rows to their max / first
 // arg-max (the max-pool over the points of a group) in the epilogue; FX_NOSTORE drops the C store when only that max is wanted.
+#ifndef NT16_OCC_SMALL
+#define NT16_OCC_SMALL 3
+#endif
 template <int BM, int BN, bool MG = false, int FX = 0>
-__global__ __launch_bounds__(256, 3) void sgemm_nt16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SMALL : 3) void sgemm_nt16_kernel(const GemmParams p) {
     constexpr int BK = 16;
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;
