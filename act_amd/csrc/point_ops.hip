@@ -246,6 +246,86 @@ __global__ __launch_bounds__(256) void knn_group_kernel(const float* __restrict_
 }
 
 
+// PPL >= 64 (N up to 8192: the stress geometry, 128 points per lane): the flat refresh above rescans the winner lane's whole chunk in every
+// one of the K rounds (K x PPL x ~3.5 instructions = 95 % of the kernel).  Two levels: the chunk is NG groups of 8 with cached group minima;
+// a round rescans only the winner's group and folds the NG minima.  Only the winner lane is active in the refresh, so the statically unrolled
+// `if (g == gsel)` chain executes exactly one group body (the others are skipped by execz branches) and every register index stays static.
+// Selection order is unchanged: lowest distance, then lowest lane, then lowest index in the lane (strict '<' scanning upwards at both levels).
+template <int PPL>
+__global__ __launch_bounds__(256) void knn_group2_kernel(const float* __restrict__ ref, const float* __restrict__ query,
+                                                         int B, int N, int Q, int K, int64_t* __restrict__ idx_out,
+                                                         int idx_kq, float* __restrict__ nbr_out,
+                                                         float* __restrict__ dist_out) {
+    constexpr int GS = 8, NG = PPL / GS;
+    const int lane = threadIdx.x & 63;
+    const long long qid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // b*Q + q
+    if (qid >= (long long)B * Q) return;
+    const int b = (int)(qid / Q), q = (int)(qid % Q);
+    const float* __restrict__ r = ref + (size_t)b * N * 3;
+    const float qx = query[qid * 3 + 0], qy = query[qid * 3 + 1], qz = query[qid * 3 + 2];
+    const float INF = __int_as_float(0x7f800000);
+    const int base = lane * PPL;
+
+    float d[PPL];
+    float gmin[NG]; int gj[NG];                          // minimum of group g and its position inside the group
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float m = INF; int mj = 0;
+#pragma unroll
+        for (int i = 0; i < GS; ++i) {
+            const int k = base + g * GS + i;
+            float v = INF;
+            if (k < N) v = sqdist3(r[k * 3 + 0], r[k * 3 + 1], r[k * 3 + 2], qx, qy, qz);
+            d[g * GS + i] = v;
+            if (v < m) { m = v; mj = i; }
+        }
+        gmin[g] = m; gj[g] = mj;
+    }
+    float lmin = INF; int lg = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) if (gmin[g] < lmin) { lmin = gmin[g]; lg = g; }
+    int my_idx = 0; float my_d = 0.f;
+    for (int round = 0; round < K; ++round) {
+        const float m = wave_min_f32(lmin, INF);
+        const int wl = first_lane(__ballot(lmin == m));
+        int lj = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) if (g == lg) lj = g * GS + gj[g];
+        const int widx = __builtin_amdgcn_readlane(base + lj, wl);
+        if (lane == round) { my_idx = widx; my_d = m; }
+        if (lane == wl) {                                // retire the winner: rescan its group, fold the group minima
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g == lg) {
+                    float nm = INF; int nj = 0;
+#pragma unroll
+                    for (int i = 0; i < GS; ++i) {
+                        const float v = (i == gj[g]) ? INF : d[g * GS + i];
+                        d[g * GS + i] = v;
+                        if (v < nm) { nm = v; nj = i; }
+                    }
+                    gmin[g] = nm; gj[g] = nj;
+                }
+            }
+            float nl = INF; int ng = 0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) if (gmin[g] < nl) { nl = gmin[g]; ng = g; }
+            lmin = nl; lg = ng;
+        }
+    }
+    if (lane < K) {
+        const size_t o = idx_kq ? ((size_t)b * K + lane) * Q + q : (size_t)qid * K + lane;
+        idx_out[o] = (int64_t)my_idx;
+        if (dist_out) dist_out[o] = sqrtf(my_d);
+        if (nbr_out) {
+            float* __restrict__ w = nbr_out + ((size_t)qid * K + lane) * 3;
+            w[0] = __fsub_rn(r[my_idx * 3 + 0], qx);
+            w[1] = __fsub_rn(r[my_idx * 3 + 1], qy);
+            w[2] = __fsub_rn(r[my_idx * 3 + 2], qz);
+        }
+    }
+}
+
 // fallback for N > 8192: nothing is kept in registers; each of the K rounds rescans the lane's chunk for the
 // smallest (distance, index) pair lexicographically greater than the previous winner.
 __global__ __launch_bounds__(256) void knn_group_big_kernel(const float* __restrict__ ref, const float* __restrict__ query,
@@ -289,6 +369,15 @@ static int launch_knn(const float* ref, const float* query, int B, int N, int Q,
                       float* nbr, float* dist, hipStream_t s) {
     const long long nq = (long long)B * Q;
     const int wpb = 4;
+    static const bool two_level = [] { const char* e = getenv("ACT_KNN_TWO_LEVEL"); return !(e && e[0] == '0'); }();
+    if constexpr (PPL >= 64) {
+        if (two_level) {
+            hipLaunchKernelGGL(knn_group2_kernel<PPL>, dim3((unsigned)((nq + wpb - 1) / wpb)), dim3(wpb * 64), 0, s, ref, query,
+                               B, N, Q, K, idx, idx_kq, nbr, dist);
+            ACT_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(knn_group_kernel<PPL>, dim3((unsigned)((nq + wpb - 1) / wpb)), dim3(wpb * 64), 0, s, ref, query,
                        B, N, Q, K, idx, idx_kq, nbr, dist);
     ACT_LAUNCH_CHECK();
