@@ -328,7 +328,7 @@ std::mutex g_tune_mu;
 std::unordered_map<TuneKey, std::pair<int, int>, TuneHash> g_tune;
 }  // namespace
 extern "C" int act_gemm_tune_set(int ak, int bk, int M, int N, int K, int tile, int splits) {
-    if (tile < 0 || tile > 14 || splits < 0) return ACT_E_BADARG;
+    if (tile < 0 || tile > 16 || splits < 0) return ACT_E_BADARG;
     std::lock_guard<std::mutex> g(g_tune_mu);
     g_tune[TuneKey{ak != 0, bk != 0, M, N, K}] = {tile, splits};
     return 0;
@@ -406,9 +406,10 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
             if (nb * sp >= 1024) break;
         }
     }
-    const bool q16 = tile == 13 || tile == 14;          // tiles 13 (128x128), 14 (64x128): quad-fragment kernels of the NN / TN layouts (gemm16.hip)
+    // tiles 13 (128x128), 14 (64x128), 15 (64x64), 16 (128x64): quad-fragment kernels of the NN / TN layouts (gemm16.hip); 14..16 NN only
+    const bool q16 = tile >= 13 && tile <= 16;
     const int q16_tile = tile - 13;
-    if (q16) { if (b_kmajor || (tile == 14 && !a_kmajor)) return ACT_E_BADARG; tile = tile == 13 ? 1 : 0; }
+    if (q16) { if (b_kmajor || (tile != 13 && !a_kmajor)) return ACT_E_BADARG; tile = tile == 13 ? 1 : 0; }
     const bool nt16 = tile >= 10 && tile <= 12;         // tiles 10..12 = tiles 1..3, NT-only b128-fragment kernel (gemm16.hip)
     if (nt16) { if (!(a_kmajor && b_kmajor)) return ACT_E_BADARG; tile -= 9; }
     const bool mi16 = tile >= 7 && tile <= 9;           // tiles 7..9 = tiles 1..3 on v_mfma_f32_16x16x4_f32 (gemm16.hip)
@@ -416,7 +417,7 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     const bool pipe = tile >= 4 && tile <= 6;           // tiles 4..6 = software-pipelined main loop of tiles 1..3
     if (pipe) tile -= 3;
     if (q16) {
-        BM = q16_tile == 1 ? 64 : 128; BN = 128;
+        BM = (q16_tile == 1 || q16_tile == 2) ? 64 : 128; BN = q16_tile >= 2 ? 64 : 128;
         splits = force_splits >= 1 ? force_splits : 1;
         if (splits > 1 && (!workspace || (size_t)splits * M * N * sizeof(float) > workspace_bytes)) return ACT_E_BADARG;
     } else if (tile >= 1 && tile <= 3) {                // explicit configuration (autotuner)

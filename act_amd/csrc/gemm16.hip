@@ -407,16 +407,18 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
     static_assert(!(FXA || FXE) || (BM == 128 && !MG), "fused max-pool backward: 128-row tiles, no M tail");
     static_assert(!FXE || !B_K, "FXE: float4 epilogue");
     static_assert(A_K || BM == 128, "row-contiguous A needs BM = 128");
-    static_assert(B_K || BN == 128, "row-contiguous B needs BN = 128");
+    static_assert(B_K || BN == 128 || (BN == 64 && A_K), "row-contiguous B needs a 64-wide wave extent: BN = 128 (2 x 2 waves) or 64 (4 x 1 waves, NN)");
     static_assert(!(A_K && B_K), "NT is sgemm_nt16_kernel");
+    static_assert(BN == 128 || !(FXB || FXA || FXE), "fused variants: BN = 128");
     constexpr int BK = 16;
-    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int WN = (BN == 64) ? 1 : 2, WM = 4 / WN;                 // wave grid: 2 x 2, or 4 x 1 for the 64-column NN tiles
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;
     __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * BK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
     tile_coords(p, wg, tile_m, tile_n);
@@ -510,8 +512,8 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
     const int kl = lane >> 4, ml = lane & 15;
     const int hsw = (4 - ((ml >> 2) & 3)) & 3;
     // K-contiguous: fragment i at +i*256 floats; row-contiguous: k-step s at +s*rows floats
-    const int a_off = A_K ? (wm * (BM / 2) + ml) * 16 + 4 * (kl ^ hsw) : (4 * kl) * BM + wm * 64 + 4 * ml;
-    const int b_off = B_K ? (wn * (BN / 2) + ml) * 16 + 4 * (kl ^ hsw) : (4 * kl) * BN + wn * 64 + 4 * ml;
+    const int a_off = A_K ? (wm * (BM / WM) + ml) * 16 + 4 * (kl ^ hsw) : (4 * kl) * BM + wm * 64 + 4 * ml;
+    const int b_off = B_K ? (wn * (BN / WN) + ml) * 16 + 4 * (kl ^ hsw) : (4 * kl) * BN + wn * 64 + 4 * ml;
     auto compute = [&](int buf) {
         float4 af[4], bf[4];                            // A_K: af[i] = 4 k-steps of block i; else af[s] = 4 blocks of k-step s  (TM, TN <= 4)
 #pragma unroll
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int r16 = kl * 4 + r;
-            const int row = m0 + (A_K ? wm * (BM / 2) + i * 16 + r16 : wm * 64 + 4 * r16 + i);
+            const int row = m0 + (A_K ? wm * (BM / WM) + i * 16 + r16 : wm * 64 + 4 * r16 + i);
             if (MG && row >= p.M) continue;
             if constexpr (!B_K) {
                 const int col = n0 + wn * 64 + 4 * ml;
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
             } else {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + wn * (BN / 2) + j * 16 + ml;
+                    const int col = n0 + wn * (BN / WN) + j * 16 + ml;
                     float v = acc[i][j][r];
                     if (p.partial) p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
                     else {
@@ -589,10 +591,21 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
         }
 }
 
-// tile: 0 = 128x128, 1 = 64x128 (NN only: A K-contiguous).  Returns false when the combination does not exist.
+// tile: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 128x64 (1..3 NN only: A K-contiguous; 2, 3: 4 x 1 waves).  false: no such kernel.
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s) {
     if (a_kmajor && b_kmajor) return false;
     if (b_kmajor) return false;                                       // (A [K][M], B [N][K]) never occurs on this path
+    if (a_kmajor && (tile == 2 || tile == 3)) {
+        const int bm = tile == 2 ? 64 : 128;
+        if (p.M % bm != 0) {
+            if (tile == 2) hipLaunchKernelGGL((sgemm_q16_kernel<64, 64, true, false, true>), grid, dim3(256), 0, s, p);
+            else           hipLaunchKernelGGL((sgemm_q16_kernel<128, 64, true, false, true>), grid, dim3(256), 0, s, p);
+        } else {
+            if (tile == 2) hipLaunchKernelGGL((sgemm_q16_kernel<64, 64, true, false>), grid, dim3(256), 0, s, p);
+            else           hipLaunchKernelGGL((sgemm_q16_kernel<128, 64, true, false>), grid, dim3(256), 0, s, p);
+        }
+        return true;
+    }
     if (a_kmajor) {                                                   // NN: dX = dY . W
         const int bm = tile == 1 ? 64 : 128;
         if (p.M % bm != 0) {

@@ -208,6 +208,14 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
             if _MAX_SPLIT > 0 and K <= 8192:
                 qsp = [s for s in qsp if s <= _MAX_SPLIT]
             cands += [(12 + tile, s) for s in qsp if (K // s) % 32 == 0]                     # NN / TN: quad fragments (13: 128x128, 14: 64x128)
+        if ak and not bk and N % 64 == 0 and K % 32 == 0 and tile in (2, 3):                  # NN, 64-column quad tiles (4 x 1 waves): 16 = 128x64, 15 = 64x64
+            qsp = [1]
+            nbq = -(-M // (128 if tile == 2 else 64)) * (N // 64)
+            if K >= 1024 and nbq < 2048:
+                qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
+            if _MAX_SPLIT > 0 and K <= 8192:
+                qsp = [s for s in qsp if s <= _MAX_SPLIT]
+            cands += [(16 if tile == 2 else 15, s) for s in qsp if (K // s) % 32 == 0]
     scratch = torch.empty(M, N, dtype=torch.float32, device=a.device)
     e = GemmEpilogue(alpha=1.0)
     best, best_t = (0, 0), float("inf")
