@@ -152,8 +152,14 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
 #ifndef NT16_OCC_SMALL
 #define NT16_OCC_SMALL 3
 #endif
-template <int BM, int BN, bool MG = false, int FX = 0>
+// PIPE: software-pipelined main loop -- the fragments of K-tile t+1 are read from LDS while the MFMAs of tile t run (two register sets),
+// tile t+2 is already in flight from global memory, and the barrier waits for LDS traffic only (bare s_barrier: the global loads stay in
+// flight across it).  Same products in the same order: results are bit-identical to the plain loop.  Needs an even number of K-tiles
+// (K per split % 32 == 0); loads past the end are clamped to the last tile and land in an LDS buffer nobody reads.  Pays on long K
+// (+3-4 % at K = 3,072, benchmarks/micro/nt_pipe.hip) and on launches with few workgroups per CU.
+template <int BM, int BN, bool MG = false, int FX = 0, bool PIPE = false>
 __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SMALL : 3) void sgemm_nt16_kernel(const GemmParams p) {
+    static_assert(!PIPE || (FX == 0 && !MG), "pipelined loop: plain full tiles");
     constexpr int BK = 16;
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;
@@ -249,6 +255,56 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
     };
+    if constexpr (PIPE) {
+        struct Frag { float4 a[TM], b[TN]; };
+        auto read_frags = [&](Frag& f, int buf) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const float4*>(&As[buf][a_off + i * 256]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const float4*>(&Bs[buf][b_off + j * 256]);
+        };
+        auto mfma_tile = [&](const Frag& f) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i].x, f.b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i].y, f.b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i].z, f.b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[i].w, f.b[j].w, acc[i][j], 0, 0, 0);
+        };
+        auto lds_barrier = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0); vmcnt untouched
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        if (ntiles > 0) {                                   // (tile 0 is in LDS buffer 0 and visible: prologue above)
+            Frag F0, F1;
+            const int last = ntiles - 1;
+            load_g(min(1, last));
+            read_frags(F0, 0);
+            store_lds(1, 0); load_g(min(2, last));
+            lds_barrier();
+            for (int t = 0; t < ntiles; t += 2) {
+                read_frags(F1, 1);
+                mfma_tile(F0);
+                store_lds(0, 0); load_g(min(t + 3, last));
+                lds_barrier();
+                read_frags(F0, 0);
+                mfma_tile(F1);
+                store_lds(1, 0); load_g(min(t + 4, last));
+                lds_barrier();
+            }
+        }
+    } else {
     for (int t = 0; t + 1 < ntiles; ++t) {              // steady state: fetch tile t+1 while computing tile t
         load_g(t + 1);
         compute(t & 1);
@@ -256,6 +312,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
         __syncthreads();
     }
     if (ntiles > 0) compute((ntiles - 1) & 1);
+    }
 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -651,6 +708,8 @@ static void launch16(const GemmParams& p, int ak, int bk, dim3 grid, hipStream_t
 }
 
 void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s) {
+    if (tile == 3) { hipLaunchKernelGGL((sgemm_nt16_kernel<128, 128, false, 0, true>), grid, dim3(256), 0, s, p); return; }   // pipelined loop: full tiles only
+    if (tile == 4) { hipLaunchKernelGGL((sgemm_nt16_kernel<128, 64, false, 0, true>), grid, dim3(256), 0, s, p); return; }
     const int bm = tile == 2 ? 64 : 128;
     if (p.M % bm != 0) {
         if (tile == 0)      hipLaunchKernelGGL((sgemm_nt16_kernel<128, 128, true>), grid, dim3(256), 0, s, p);

@@ -157,7 +157,7 @@ _GEMM_CACHE = {}
 AUTOTUNE = os.environ.get("ACT_GEMM_AUTOTUNE", "1") != "0"
 # Shipped winners for the shapes of the benchmarked workloads (measured on one MI355X by this same autotuner and dumped with
 # ACT_GEMM_TUNE_SAVE=<file>): first use of a listed shape costs nothing; unlisted shapes are still tuned on first use.
-_TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.json")
+_TUNE_FILE = os.environ.get("ACT_GEMM_TUNE_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.json")
 _GEMM_TABLE = {}
 _MAX_SPLIT = int(os.environ.get("ACT_GEMM_MAX_SPLIT", "0"))              # experiment knob: cap split-K (table entries above the cap are re-tuned on first use)
 if os.environ.get("ACT_GEMM_TUNE_TABLE", "1") != "0" and os.path.exists(_TUNE_FILE):
@@ -200,6 +200,8 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
             cands += [(tile + 6, s) for s in sp_list if (K // s) % 32 == 0]                  # v_mfma_f32_16x16x4_f32 main loop
             if ak and bk:
                 cands += [(tile + 9, s) for s in sp_list if (K // s) % 32 == 0]              # NT: K-contiguous LDS image, b128 fragments
+                if tile == 1 and M % bm == 0 and K >= 1536:                                   # ... with the software-pipelined main loop (17: 128x128; 18 = 128x64
+                    cands += [(17, s) for s in sp_list if (K // s) % 32 == 0]                 # exists but never won a shape): pays on long K only
         if not bk and N % 128 == 0 and K % 32 == 0 and ((tile == 1 and (ak or M % 128 == 0)) or (tile == 2 and ak)):
             qsp = [1]
             nbq = -(-M // (128 if tile == 1 else 64)) * (N // 128)

@@ -51,7 +51,7 @@ def main():
         ours = min(timeit(lambda: K.gemm(a, b, bool(ak), bool(bk), out=out), reps) for _ in range(3))
         cfgs = {}
         if os.environ.get("GEMM_BENCH_CFGS"):
-            for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16):
+            for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18):
                 try:
                     tt = min(timeit(lambda: K.gemm(a, b, bool(ak), bool(bk), out=out, cfg=(tile, 1)), reps) for _ in range(2))
                     cfgs[tile] = round(flops / tt / 1e9, 1)

@@ -707,3 +707,24 @@ def test_gemm_with_maxpool_backward_generated_on_load(K, group, R, C, N):
     assert CP.lib.act_sgemm_fx_f32(1, 0, R, N, C, None, C, W.data_ptr(), N, out.data_ptr(), N, ctypes.byref(epi), ctypes.byref(bad), None, 0, st) != 0
     bad2 = CP.GemmFx(); bad2.sa_src = dout.data_ptr(); bad2.sa_arg = arg.data_ptr(); bad2.group = 48
     assert CP.lib.act_sgemm_fx_f32(1, 0, R, N, C, None, C, W.data_ptr(), N, out.data_ptr(), N, ctypes.byref(epi), ctypes.byref(bad2), None, 0, st) != 0
+
+
+@pytest.mark.parametrize("tile,base", [(17, 10), (18, 11)])
+def test_gemm_nt_pipelined_loop_is_bit_identical(K, tile, base):
+    """tiles 17 / 18: the NT b128 kernels with the software-pipelined main loop (fragments of K-tile t+1 read during the MFMAs of tile t, LDS-only
+    barrier) compute the same products in the same order as tiles 10 / 11: bit-identical, with split-K and fused epilogues, for 2 .. 192 K-tiles."""
+    for (M, N, Kd) in [(256, 256, 32), (512, 384, 1024), (1024, 768, 3072), (128, 128, 96 * 32)]:
+        a = _rnd(f"p.a{Kd}", M, Kd).cuda(); b = _rnd(f"p.b{Kd}", N, Kd).cuda()
+        for sp in (1, 2, 3):
+            if Kd // sp < 32:
+                continue
+            assert torch.equal(K.gemm(a, b, True, True, cfg=(tile, sp)), K.gemm(a, b, True, True, cfg=(base, sp))), (tile, M, N, Kd, sp)
+        bias = _rnd("p.bias", N).cuda(); res = _rnd("p.res", M, N).cuda()
+        assert torch.equal(K.gemm(a, b, True, True, bias=bias, res=res, act=K.EPI_GELU, cfg=(tile, 1)),
+                           K.gemm(a, b, True, True, bias=bias, res=res, act=K.EPI_GELU, cfg=(base, 1)))
+    a = _rnd("p.a", 512, 1024).cuda(); b = _rnd("p.b", 384, 1024).cuda()
+    assert _rel(K.gemm(a, b, True, True, cfg=(tile, 1)), a.double().cpu() @ b.double().cpu().t()) <= 2e-5
+    with pytest.raises(Exception):                         # full tiles only
+        K.gemm(_rnd("p.t", 200, 64).cuda(), _rnd("p.u", 128, 64).cuda(), True, True, cfg=(tile, 1))
+    with pytest.raises(Exception):                         # NT only
+        K.gemm(a, b.t().contiguous(), True, False, cfg=(tile, 1))
