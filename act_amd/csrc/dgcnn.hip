@@ -492,8 +492,15 @@ __global__ __launch_bounds__(1024) void kl_uniform_kernel(const float* __restric
     __shared__ float sh[16];
     const float u = 1.0f / (float)C, lu = __logf(u);
     float acc = 0.f;
-    const long long per = (n + 1023) / 1024, k0 = threadIdx.x * per, k1 = k0 + per < n ? k0 + per : n;
-    for (long long i = k0; i < k1; ++i) acc += u * (lu - __logf(qbar[i]));
+    // consecutive threads read consecutive elements (a contiguous chunk per thread put every lane on its own cache line: 478 us for 1 M values)
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long i = threadIdx.x;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        a0 += u * (lu - __logf(qbar[i])); a1 += u * (lu - __logf(qbar[i + 1024]));
+        a2 += u * (lu - __logf(qbar[i + 2048])); a3 += u * (lu - __logf(qbar[i + 3072]));
+    }
+    for (; i < n; i += 1024) a0 += u * (lu - __logf(qbar[i]));
+    acc = (a0 + a1) + (a2 + a3);
     acc = wave_sum_f32(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
