@@ -327,6 +327,86 @@ extern "C" int act_prompt_layernorm_fwd_f32(const float* tok, const float* ppos,
     ACT_LAUNCH_CHECK(); return 0;
 }
 
+// Prompt rows of a TRAINED prompt layer (Stage I, models/dvae.py:485-498,556-566): y[b*P+p,:] = dropout(tok[p,:]) + ppos[p,:] for every cloud b
+// (one launch instead of expand + dropout + add), and its backward: dppos[p,:] = sum_b dy[b*P+p,:], dtok[p,:] = sum_b dy * keep / (1 - drop_p)
+// in a fixed order over b.  keep: the given 0/1 mask [B*P, D] (parity tests inject the reference's draws) or Philox keyed like
+// prompt_layernorm_fwd_kernel by (seed, row, column/4), regenerated in the backward.
+__global__ __launch_bounds__(256) void prompt_rows_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ ppos,
+                                                              const float* __restrict__ mask, int P, int D, float drop_p, uint64_t seed,
+                                                              float* __restrict__ y, long long total4) {
+    const int nv = D >> 2;
+    const float inv_keep = 1.0f / (1.0f - drop_p);
+    const uint32_t thr = (uint32_t)(drop_p * 16777216.0f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % nv); const long long row = i / nv; const int pr = (int)(row % P);
+        float4 a = reinterpret_cast<const float4*>(tok + (size_t)pr * D)[c];
+        if (mask) {
+            const float4 m = reinterpret_cast<const float4*>(mask)[i];
+            a.x *= m.x * inv_keep; a.y *= m.y * inv_keep; a.z *= m.z * inv_keep; a.w *= m.w * inv_keep;
+        } else if (drop_p > 0.f) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)c, (uint32_t)row, 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            a.x = (r[0] >> 8) < thr ? 0.f : a.x * inv_keep; a.y = (r[1] >> 8) < thr ? 0.f : a.y * inv_keep;
+            a.z = (r[2] >> 8) < thr ? 0.f : a.z * inv_keep; a.w = (r[3] >> 8) < thr ? 0.f : a.w * inv_keep;
+        }
+        const float4 b = reinterpret_cast<const float4*>(ppos + (size_t)pr * D)[c];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<float4*>(y)[i] = a;
+    }
+}
+// one thread per (prompt row p, float4 column c): walks the B clouds in order (4 loads in flight)
+__global__ __launch_bounds__(256) void prompt_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ mask, int B, int P, int D,
+                                                              float drop_p, uint64_t seed, float* __restrict__ dtok, float* __restrict__ dppos) {
+    const int nv = D >> 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * nv) return;
+    const int c = i % nv, pr = i / nv;
+    const float inv_keep = 1.0f / (1.0f - drop_p);
+    const uint32_t thr = (uint32_t)(drop_p * 16777216.0f);
+    float4 st = make_float4(0.f, 0.f, 0.f, 0.f), sp = st;
+#pragma unroll 4
+    for (int b = 0; b < B; ++b) {
+        const long long row = (long long)b * P + pr;
+        const float4 g = reinterpret_cast<const float4*>(dy + (size_t)row * D)[c];
+        sp.x += g.x; sp.y += g.y; sp.z += g.z; sp.w += g.w;
+        float4 k = make_float4(inv_keep, inv_keep, inv_keep, inv_keep);
+        if (mask) {
+            const float4 m = reinterpret_cast<const float4*>(mask + (size_t)row * D)[c];
+            k.x *= m.x; k.y *= m.y; k.z *= m.z; k.w *= m.w;
+        } else if (drop_p > 0.f) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)c, (uint32_t)row, 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            k.x = (r[0] >> 8) < thr ? 0.f : inv_keep; k.y = (r[1] >> 8) < thr ? 0.f : inv_keep;
+            k.z = (r[2] >> 8) < thr ? 0.f : inv_keep; k.w = (r[3] >> 8) < thr ? 0.f : inv_keep;
+        }
+        st.x += g.x * k.x; st.y += g.y * k.y; st.z += g.z * k.z; st.w += g.w * k.w;
+    }
+    reinterpret_cast<float4*>(dtok + (size_t)pr * D)[c] = st;
+    reinterpret_cast<float4*>(dppos + (size_t)pr * D)[c] = sp;
+}
+extern "C" int act_prompt_rows_fwd_f32(const float* tok, const float* ppos, const float* mask, int B, int P, int D, float drop_p, uint64_t seed,
+                                       float* y, act_stream_t stream) {
+    if (!tok || !ppos || !y) return ACT_E_NULLPTR;
+    if (B < 0 || P <= 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return ACT_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long long total4 = (long long)B * P * (D >> 2);
+    long long g = (total4 + 255) / 256; if (g > 8192) g = 8192;
+    ActProfScope ps(KID_ELTWISE, s, 0.0, 4.0 * B * P * (double)D * (mask ? 2 : 1));
+    hipLaunchKernelGGL(prompt_rows_fwd_kernel, dim3((unsigned)g), dim3(256), 0, s, tok, ppos, mask, P, D, drop_p, seed, y, total4);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_prompt_rows_bwd_f32(const float* dy, const float* mask, int B, int P, int D, float drop_p, uint64_t seed, float* dtok,
+                                       float* dppos, act_stream_t stream) {
+    if (!dy || !dtok || !dppos) return ACT_E_NULLPTR;
+    if (B <= 0 || P <= 0 || D <= 0 || (D & 3) || drop_p < 0.f || drop_p >= 1.f) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = P * (D >> 2);
+    ActProfScope ps(KID_ELTWISE, s, 0.0, 4.0 * B * P * (double)D * (mask ? 2 : 1));
+    hipLaunchKernelGGL(prompt_rows_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dy, mask, B, P, D, drop_p, seed, dtok, dppos);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
 static int ln_rows_per_block(int T) { int r = (T + 1023) / 1024; r = (r + 3) / 4 * 4; return r < 16 ? 16 : r; }
 extern "C" size_t act_layernorm_bwd_workspace(int T, int D) {
     const int rpb = ln_rows_per_block(T); const int nblk = (T + rpb - 1) / rpb;

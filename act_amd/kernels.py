@@ -1013,6 +1013,41 @@ _C._declare({"act_prompt_layernorm_fwd_f32": [_vp, _vp, _i, _i, _i, _f, _u64, _v
 _C.SIGNATURES.setdefault("act_prompt_layernorm_fwd_f32", _C.lib.act_prompt_layernorm_fwd_f32.argtypes)
 
 
+_C._declare({"act_prompt_rows_fwd_f32": [_vp, _vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp],
+             "act_prompt_rows_bwd_f32": [_vp, _vp, _i, _i, _i, _f, _u64, _vp, _vp, _vp]})
+for _n in ("act_prompt_rows_fwd_f32", "act_prompt_rows_bwd_f32"):
+    _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
+
+
+class PromptRowsFn(torch.autograd.Function):
+    """prompt rows of a trained prompt layer: y[b*P+p, :] = dropout(tok[p, :]) + ppos[p, :] (models/dvae.py:485-498, 556-566), one launch per
+    direction.  mask: 0/1 keep mask [B, P, D] (injected / recorded draws) or None -> in-kernel Philox(seed), regenerated in the backward."""
+
+    @staticmethod
+    def forward(ctx, tok, ppos, B, drop_p, seed, mask):
+        P, D = tok.shape
+        tok, ppos = _f32c(tok), _f32c(ppos)
+        mask = _f32c(mask).reshape(B * P, D) if mask is not None else None
+        y = torch.empty(B * P, D, dtype=torch.float32, device=tok.device)
+        check(lib.act_prompt_rows_fwd_f32(ptr(tok), ptr(ppos), ptr(mask), B, P, D, float(drop_p), int(seed), ptr(y), stream()), "act_prompt_rows_fwd_f32")
+        ctx.save_for_backward(mask)
+        ctx.cfg = (B, P, D, float(drop_p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        B, P, D, drop_p, seed = ctx.cfg
+        dy = _f32c(dy)
+        dtok = torch.empty(P, D, dtype=torch.float32, device=dy.device); dppos = torch.empty_like(dtok)
+        check(lib.act_prompt_rows_bwd_f32(ptr(dy), ptr(mask), B, P, D, drop_p, seed, ptr(dtok), ptr(dppos), stream()), "act_prompt_rows_bwd_f32")
+        return dtok, dppos, None, None, None, None
+
+
+def prompt_rows(tok, ppos, B, drop_p=0.0, seed=0, mask=None):
+    return PromptRowsFn.apply(tok, ppos, B, drop_p, seed, mask)
+
+
 def prompt_layernorm(tok, ppos, B, drop_p, seed, gamma, beta, eps, seed_dev=None):
     """LN(dropout(tok) + ppos) for the B x P prompt rows of one layer of the frozen teacher, dropout mask from in-kernel Philox."""
     P, D = tok.shape

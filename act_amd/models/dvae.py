@@ -424,6 +424,17 @@ class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
             return t * keep / (1.0 - p)
         return F.dropout(t, p, True)
 
+    def _prompt_rows(self, tok, ppos, B, draws, key):
+        """dropout(tok) + ppos for every cloud, [B*Pn, D], one HIP launch per direction (K.prompt_rows): injected / recorded keep masks
+        when the parity tests ask for them, in-kernel Philox otherwise."""
+        p = self.prompt_dropout.p if self.training else 0.0
+        mask = None
+        if p > 0 and draws is not None and (draws.has(key) or draws.record):
+            shape = (B,) + tuple(tok.shape)
+            mask = draws.get(key, lambda: (torch.rand(shape, device=tok.device) >= p).to(tok.dtype))
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0 and mask is None) else 0       # host RNG: no device sync
+        return K.prompt_rows(tok, ppos, B, p, seed, mask)
+
     def visual_embedding(self, input, center, draws=None, rng=None):
         if self.visual_embed is None:
             return input
@@ -504,7 +515,7 @@ class ACTPromptedDiscreteVAEwithVIT(DiscreteVAE):
         for i in range(self.visual_embed_depth):
             tok = self.visual_prompt_token[0] if i == 0 else self.deep_prompt_tokens[i - 1]
             ppos = self.visual_prompt_pos[0] if i == 0 else self.deep_prompt_pos[i - 1]
-            prm = (self._drop(tok.unsqueeze(0).expand(B, -1, -1), draws, f"prompt.{i}") + ppos).reshape(B * Pn, D)
+            prm = self._prompt_rows(tok, ppos, B, draws, f"prompt.{i}")
             blk = blocks[i]
             a, m = blk.attn, blk.mlp
             x = K.PrefixBlockFn.apply(x, pos, prm, B, Pn, G, blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias,

@@ -155,6 +155,12 @@ int act_layernorm_fwd_f32(const float* x, const float* pos, const float* gamma, 
 int act_prompt_layernorm_fwd_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
                                  const uint64_t* seed_dev, const float* gamma, const float* beta, float eps, float* y,
                                  act_stream_t stream);
+/* Prompt rows of a trained prompt layer (Stage I): y[b*P+p,:] = dropout(tok[p,:]) + ppos[p,:]; keep mask = `mask` (0/1 floats [B*P, D], nullable)
+ * or Philox keyed by (seed, row, column/4) as above; backward: dppos[p,:] = sum_b dy, dtok[p,:] = sum_b dy * keep / (1 - drop_p), fixed order. */
+int act_prompt_rows_fwd_f32(const float* tok, const float* ppos, const float* mask, int B, int P, int D, float drop_p, uint64_t seed,
+                            float* y, act_stream_t stream);
+int act_prompt_rows_bwd_f32(const float* dy, const float* mask, int B, int P, int D, float drop_p, uint64_t seed, float* dtok, float* dppos,
+                            act_stream_t stream);
 /* dx = dres (nullable, residual-stream gradient) + LayerNorm backward of dy; dgamma/dbeta (nullable) summed over
  * rows in a fixed order through `workspace` (act_layernorm_bwd_workspace bytes). */
 size_t act_layernorm_bwd_workspace(int T, int D);

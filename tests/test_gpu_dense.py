@@ -728,3 +728,32 @@ def test_gemm_nt_pipelined_loop_is_bit_identical(K, tile, base):
         K.gemm(_rnd("p.t", 200, 64).cuda(), _rnd("p.u", 128, 64).cuda(), True, True, cfg=(tile, 1))
     with pytest.raises(Exception):                         # NT only
         K.gemm(a, b.t().contiguous(), True, False, cfg=(tile, 1))
+
+
+def test_prompt_rows_fwd_bwd(K):
+    """K.prompt_rows: y[b, p, :] = dropout(tok[p, :]) + ppos[p, :] and its backward (sums over the clouds) with an injected keep mask against
+    float64 autograd; with in-kernel Philox: every row is tok * {0, 1/(1-p)} + ppos, the drop rate is right, the backward regenerates the same
+    mask, and p = 0 is the plain broadcast."""
+    B, P, D, p = 6, 64, 768, 0.1
+    tok = _rnd("pr.tok", P, D); ppos = _rnd("pr.pos", P, D); dy = _rnd("pr.dy", B * P, D)
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.rand(B, P, D, generator=g) >= p).float()
+    td, pd_ = tok.double().requires_grad_(True), ppos.double().requires_grad_(True)
+    ref = (td.unsqueeze(0) * mask.double() / (1 - p) + pd_.unsqueeze(0)).reshape(B * P, D)
+    (ref * dy.double()).sum().backward()
+    tg, pg = tok.cuda().requires_grad_(True), ppos.cuda().requires_grad_(True)
+    y = K.prompt_rows(tg, pg, B, p, 0, mask.cuda())
+    (y * dy.cuda()).sum().backward()
+    assert _rel(y, ref) <= 1e-6 and _rel(tg.grad, td.grad) <= 2e-6 and _rel(pg.grad, pd_.grad) <= 2e-6
+    # in-kernel noise
+    t2, p2 = tok.cuda().requires_grad_(True), ppos.cuda().requires_grad_(True)
+    y1 = K.prompt_rows(t2, p2, B, p, 1234); y2 = K.prompt_rows(tok.cuda(), ppos.cuda(), B, p, 1234); y3 = K.prompt_rows(tok.cuda(), ppos.cuda(), B, p, 99)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    yk = (tok.cuda() / (1 - p) + ppos.cuda()).unsqueeze(0); yd = ppos.cuda().unsqueeze(0); y3d = y1.detach().reshape(B, P, D)
+    kept = (y3d - yk).abs() <= 1e-6 * (1 + yk.abs()); dropped = ((y3d - yd).abs() <= 1e-7) & ~kept      # kept value, or ppos alone
+    assert bool((kept | dropped).all()) and abs(dropped.float().mean().item() - p) < 0.01
+    assert not torch.equal(dropped[0], dropped[1])                                           # a different mask per cloud
+    (y1 * dy.cuda()).sum().backward()
+    want = (dy.cuda().reshape(B, P, D) * kept.float() / (1 - p)).sum(0)
+    assert _rel(t2.grad, want) <= 2e-6 and _rel(p2.grad, dy.cuda().reshape(B, P, D).sum(0)) <= 2e-6
+    assert torch.equal(K.prompt_rows(tok.cuda(), ppos.cuda(), 3, 0.0, 0), (tok.cuda() + ppos.cuda()).repeat(3, 1))
