@@ -195,13 +195,13 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
             sp_list = [s for s in sp_list if s <= _MAX_SPLIT]
         cands += [(tile, s) for s in sp_list]
         if M % bm == 0 and N % bn == 0 and K % 32 == 0:
-            cands += [(tile + 3, s) for s in sp_list if s <= 4 and (K // s) % 32 == 0]       # software-pipelined main loop
+            cands += [(tile + 3, s) for s in sp_list if s <= 4 and K % 32 == 0]       # software-pipelined main loop
         if (M % bm == 0 or ak) and N % bn == 0 and K % 32 == 0:                              # the 16x16x4 kernels take an M tail (K-major A)
-            cands += [(tile + 6, s) for s in sp_list if (K // s) % 32 == 0]                  # v_mfma_f32_16x16x4_f32 main loop
+            cands += [(tile + 6, s) for s in sp_list if K % 32 == 0]                  # v_mfma_f32_16x16x4_f32 main loop
             if ak and bk:
-                cands += [(tile + 9, s) for s in sp_list if (K // s) % 32 == 0]              # NT: K-contiguous LDS image, b128 fragments
+                cands += [(tile + 9, s) for s in sp_list if K % 32 == 0]              # NT: K-contiguous LDS image, b128 fragments
                 if tile == 1 and M % bm == 0 and K >= 1536:                                   # ... with the software-pipelined main loop (17: 128x128; 18 = 128x64
-                    cands += [(17, s) for s in sp_list if (K // s) % 32 == 0]                 # exists but never won a shape): pays on long K only
+                    cands += [(17, s) for s in sp_list if K % 32 == 0]                 # exists but never won a shape): pays on long K only
         if not bk and N % 128 == 0 and K % 32 == 0 and ((tile == 1 and (ak or M % 128 == 0)) or (tile == 2 and ak)):
             qsp = [1]
             nbq = -(-M // (128 if tile == 1 else 64)) * (N // 128)
@@ -209,7 +209,7 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
                 qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
             if _MAX_SPLIT > 0 and K <= 8192:
                 qsp = [s for s in qsp if s <= _MAX_SPLIT]
-            cands += [(12 + tile, s) for s in qsp if (K // s) % 32 == 0]                     # NN / TN: quad fragments (13: 128x128, 14: 64x128)
+            cands += [(12 + tile, s) for s in qsp if K % 32 == 0]                     # NN / TN: quad fragments (13: 128x128, 14: 64x128)
         if ak and not bk and N % 64 == 0 and K % 32 == 0 and tile in (2, 3):                  # NN, 64-column quad tiles (4 x 1 waves): 16 = 128x64, 15 = 64x64
             qsp = [1]
             nbq = -(-M // (128 if tile == 2 else 64)) * (N // 64)
@@ -217,7 +217,7 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
                 qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
             if _MAX_SPLIT > 0 and K <= 8192:
                 qsp = [s for s in qsp if s <= _MAX_SPLIT]
-            cands += [(16 if tile == 2 else 15, s) for s in qsp if (K // s) % 32 == 0]
+            cands += [(16 if tile == 2 else 15, s) for s in qsp if K % 32 == 0]
     scratch = torch.empty(M, N, dtype=torch.float32, device=a.device)
     e = GemmEpilogue(alpha=1.0)
     best, best_t = (0, 0), float("inf")

@@ -757,3 +757,18 @@ def test_prompt_rows_fwd_bwd(K):
     want = (dy.cuda().reshape(B, P, D) * kept.float() / (1 - p)).sum(0)
     assert _rel(t2.grad, want) <= 2e-6 and _rel(p2.grad, dy.cuda().reshape(B, P, D).sum(0)) <= 2e-6
     assert torch.equal(K.prompt_rows(tok.cuda(), ppos.cuda(), 3, 0.0, 0), (tok.cuda() + ppos.cuda()).repeat(3, 1))
+
+
+@pytest.mark.parametrize("tile", [3, 6, 9, 12, 13, 17])
+def test_gemm_split_k_with_uneven_splits(K, tile):
+    """K = 3296 = 103 x 32 rows (32 clouds x 103 visible tokens, the stress geometry): a split-K factor that does not divide K is rounded to
+    32-row chunks (1664 + 1632, 1120 + 1120 + 1056, ...); every kernel family reduces exactly K rows."""
+    M, N, Kd = 256, 256, 3296
+    a = _rnd("us.a", M, Kd); b = _rnd("us.b", N, Kd)
+    ref = a.double() @ b.double().t()
+    for sp in (2, 3, 4, 6):
+        if tile in (13,):
+            got = K.gemm(a.t().contiguous().cuda(), b.t().contiguous().cuda(), False, False, cfg=(tile, sp))       # TN
+        else:
+            got = K.gemm(a.cuda(), b.cuda(), True, True, cfg=(tile, sp))
+        assert _rel(got, ref) <= 2e-5, (tile, sp)
