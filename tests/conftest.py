@@ -3,6 +3,12 @@ import sys
 import numpy as np
 import pytest
 
+# Run-to-run determinism of the GPU suite: GEMM shapes outside the shipped table take the built-in cost model instead of the first-use
+# autotuner, whose pick depends on a few microseconds of timing (another kernel family = another fp32 summation order = other flipped
+# max / arg-min decisions in the ill-conditioned tiny graphs).  Explicit-configuration tests still exercise every kernel; the autotuner itself
+# is tested where a test switches it on (ACT_GEMM_AUTOTUNE=1 in the environment overrides this default).
+os.environ.setdefault("ACT_GEMM_AUTOTUNE", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -9,6 +9,8 @@ def run(dev):
     from act_amd.utils.config import EasyDict
     from act_amd.utils.draws import Draws
 
+    import act_amd.kernels as K
+    K.AUTOTUNE = False                      # deterministic launch configurations (cost model / shipped table): same result on every box
     torch.manual_seed(0)
     oracle = fill_module(OM.ACT_PointDistillation(OM.edict(TINY_STAGE2)), "g4.").train()
     model = build_model_from_cfg(EasyDict(TINY_STAGE2))

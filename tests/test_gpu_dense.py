@@ -772,3 +772,25 @@ def test_gemm_split_k_with_uneven_splits(K, tile):
         else:
             got = K.gemm(a.cuda(), b.cuda(), True, True, cfg=(tile, sp))
         assert _rel(got, ref) <= 2e-5, (tile, sp)
+
+
+def test_gemm_autotuner_times_and_registers_a_config(K):
+    """the first-use autotuner (off by default in this suite for run-to-run determinism, tests/conftest.py): gemm_tune times every candidate of
+    a shape, returns a valid (tile, split-K) pair whose product is correct, and _gemm_config publishes it to the C-side table that the
+    composite entry points read (act_gemm_tune_get)."""
+    import ctypes
+    M, N, Kd = 1024, 512, 1536
+    a = _rnd("at.a", M, Kd).cuda(); b = _rnd("at.b", N, Kd).cuda()
+    ws = K.workspace(a.device)
+    (tile, sp), ms = K.gemm_tune(a, b, True, True, M, N, Kd, ws)
+    assert 1 <= tile <= 18 and sp >= 1 and 0 < ms < 10
+    assert _rel(K.gemm(a, b, True, True, cfg=(tile, sp)), a.double().cpu() @ b.double().cpu().t()) <= 2e-5
+    saved = K.AUTOTUNE
+    K.AUTOTUNE = True
+    try:
+        K._GEMM_CACHE.pop((1, 1, M, N, Kd, a.device.index), None)
+        cfg = K._gemm_config(a, b, True, True, M, N, Kd, ws)
+    finally:
+        K.AUTOTUNE = saved
+    t, s_ = ctypes.c_int(-1), ctypes.c_int(-1)
+    assert K.lib.act_gemm_tune_get(1, 1, M, N, Kd, ctypes.byref(t), ctypes.byref(s_)) == 0 and (t.value, s_.value) == tuple(cfg)
