@@ -116,13 +116,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP kernels are the product path; there is no CPU fallback)")
+    if os.environ.get("ACT_BENCH_SHARE_GPU") == "1":                # testing on a one-GPU box: every rank on cuda:0 (use with ACT_BENCH_BACKEND=gloo)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_ddp = os.environ.get("ACT_BENCH_FORCE_DDP") == "1"       # exercise the DDP/RCCL path on a single GPU (testing)
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)        # RCCL over xGMI
+        backend = os.environ.get("ACT_BENCH_BACKEND", "nccl")       # nccl == RCCL over xGMI; gloo only for the shared-GPU test mode
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import act_amd._C as C
@@ -273,22 +279,27 @@ def main():
         out["sustained"] = {"window_steps": WIN, "ms_per_step_by_window": windows, "first": windows[0], "last": windows[-1],
                             "note": "hipEvent time of consecutive 50-step windows of the timed region (clock / power drift shows as a slope)"}
 
-    if rank == 0 and not args.no_instrument:
+    nprof = 3
+    if not args.no_instrument:
         # ---- instrumented pass: hipEvents around every launch of libact_hip.so on the launch stream --------------
         # Per-kernel durations are only meaningful when kernels do not share the chip: the auxiliary stream (frozen teacher /
         # weight gradients, which the timed region above runs concurrently with the main chain) is serialised for this pass.
+        # EVERY rank runs these steps (each one contains the gradient all-reduce: a rank that skipped them would leave rank 0
+        # waiting in a collective); only rank 0 records.
         import act_amd.kernels as KK
         import act_amd.models.act as AM
         saved = (AM._OVERLAP_TEACHER, KK.OVERLAP_DW)
         AM._OVERLAP_TEACHER, KK.OVERLAP_DW = False, False
         step(0); torch.cuda.synchronize()
-        C.prof_reset(); C.prof_enable(True)
-        nprof = 3
+        if rank == 0:
+            C.prof_reset(); C.prof_enable(True)
         for i in range(nprof):
             step(i)
         torch.cuda.synchronize()
-        C.prof_enable(False)
+        if rank == 0:
+            C.prof_enable(False)
         AM._OVERLAP_TEACHER, KK.OVERLAP_DW = saved
+    if rank == 0 and not args.no_instrument:
         table = C.prof_table()
         tot_ms = sum(v["ms"] for v in table.values())
         kernels = {}

@@ -206,3 +206,24 @@ def test_sync_batchnorm_two_ranks_equals_full_batch(tmp_path):
         assert rel(r[rank]["rv"], enc.first_conv[1].running_var.cpu()) <= 1e-5
     # without synchronisation the two halves would normalise with their own statistics
     assert rel(r[0]["y"], enc(nb_all[:4].to(dev)).detach().cpu()) > 1e-3
+
+
+def test_bench_two_ranks_on_one_gpu_prints_one_line(tmp_path):
+    """bench.py under the driver's launcher with world size 2 (both ranks on cuda:0, gloo instead of RCCL: the only multi-rank form a one-GPU box
+    allows): warm-up, timed steps, the idle-GPU host-cost steps and the instrumented pass all run on EVERY rank (each step contains the gradient
+    all-reduce, so a rank-0-only pass would wait in a collective for ever), rank 0 prints exactly one JSON line with the whole-job value."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ACT_BENCH_SHARE_GPU="1", ACT_BENCH_BACKEND="gloo", ACT_GEMM_AUTOTUNE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # whole-job clouds/s = B * world / step time
+    assert "roofline" in d and "cpu_baseline" not in d and d["config"]["final_loss"] == d["config"]["final_loss"]
