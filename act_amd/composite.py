@@ -127,22 +127,26 @@ _SHAPE_BUF = (_i * (5 * 256))()
 
 
 def _tune_shape(ak, bk, M, N, Kd, device):
-    """the decision K._gemm_config would take for this product, registered with the C-side table"""
+    """the decision K._gemm_config would take for this product, registered with the C-side table; False when the shape could not be tuned
+    right now (stream capture in progress) and has to be looked at again"""
     if lib.act_gemm_tune_get(ak, bk, M, N, Kd, None, None) == 0:
-        return
+        return True
     if not K.AUTOTUNE or M * N * Kd < (1 << 24) or (not ak and not bk and min(M, N) <= 8):
-        return                                                  # built-in cost model / skinny streaming kernel (tile 0)
+        return True                                             # built-in cost model / skinny streaming kernel (tile 0)
     key = (int(ak), int(bk), M, N, Kd, device.index)
-    cfg = K._GEMM_CACHE.get(key) or K._GEMM_TABLE.get(key[:5])
+    cfg = K._GEMM_CACHE.get(key)                                # (0, 0) -- the cost model's pick -- is a valid cached decision: no `or`
+    if cfg is None:
+        cfg = K._GEMM_TABLE.get(key[:5])
     if cfg is None:
         if torch.cuda.is_current_stream_capturing():
-            return
+            return False
         a = torch.randn((M, Kd) if ak else (Kd, M), dtype=torch.float32, device=device)
         b = torch.randn((N, Kd) if bk else (Kd, N), dtype=torch.float32, device=device)
         cfg, _ = K.gemm_tune(a, b, ak, bk, M, N, Kd, K.workspace(device))
         K._NEW_TUNED[key[:5]] = cfg
     K._GEMM_CACHE[key] = cfg
     lib.act_gemm_tune_set(ak, bk, M, N, Kd, int(cfg[0]), int(cfg[1]))
+    return True
 
 
 def ensure_tuned(key, call, device):
@@ -155,9 +159,11 @@ def ensure_tuned(key, call, device):
     finally:
         n = lib.act_composite_collect_end(_SHAPE_BUF, 256)
     check(rc, "composite dry call")
+    done = True
     for i in range(min(n, 256)):
-        _tune_shape(*[int(_SHAPE_BUF[5 * i + j]) for j in range(5)], device)
-    _TUNED.add(key)
+        done = _tune_shape(*[int(_SHAPE_BUF[5 * i + j]) for j in range(5)], device) and done
+    if done:                                                    # a shape skipped during stream capture is tuned on the next eager call
+        _TUNED.add(key)
 
 
 def register_tuned(ak, bk, M, N, Kd, cfg):

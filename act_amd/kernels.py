@@ -713,7 +713,11 @@ class SyncBNActFn(torch.autograd.Function):
         db, dg = sums[0].clone(), sums[1].clone()
         dist.all_reduce(sums, group=ctx.group)
         dx = torch.empty_like(x)
-        count = float(R * dist.get_world_size(ctx.group))                   # equal shards (DistributedSampler with drop_last): no host sync
+        # the kernel divides by a HOST scalar; the true row count over all ranks lives on the device (``total``, gathered in forward).  Rescale
+        # the sums by (R * world) / total there: exactly 1.0 for equal shards (bit-identical to dividing by R * world), and the right
+        # normalisation for ragged last batches / non-drop_last loaders -- without a host synchronisation.
+        count = float(R * dist.get_world_size(ctx.group))
+        sums.mul_(count / total)
         check(lib.act_bn_bwd_apply_f32(ptr(x), ptr(dy), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(sums[0]), ptr(sums[1]), count, int(ctx.relu),
                                        R, C, ptr(dx), stream()), "act_bn_bwd_apply_f32")
         return dx, dg, db, None, None, None, None, None, None

@@ -21,6 +21,7 @@ from ..datasets import data_transforms
 from ..pointnet2_ops import pointnet2_utils
 from ..utils import dist_utils, misc
 from ..utils.AverageMeter import AverageMeter
+from ..utils.config import apply_fewshot_args
 from ..utils.logger import get_logger, print_log
 
 train_transforms = data_transforms.PointcloudRotate()
@@ -131,6 +132,7 @@ def train_step(base_model, optimizer, points, label, config, num_iter=1, augment
 
 def run_net(args, config, train_writer=None, val_writer=None, max_steps=None, log_every=20):
     logger = get_logger(args.log_name)
+    apply_fewshot_args(args, config)                  # --way / --shot / --fold -> dataset sections (main.py:72-78); no-op when already applied
     (train_sampler, train_dataloader), (_, test_dataloader) = builder.dataset_builder(args, config.dataset.train), \
         builder.dataset_builder(args, config.dataset.val)
     base_model = builder.model_builder(config.model)

@@ -79,6 +79,23 @@ def get_config(args, logger=None):
     config = cfg_from_yaml_file(args.config)
     if not args.resume and args.local_rank == 0:
         save_experiment_config(args, config, logger)
+    apply_fewshot_args(args, config)
+    return config
+
+
+def apply_fewshot_args(args, config):
+    """--way / --shot / --fold select the few-shot split: copied into the train and val dataset sections as the reference's entry script
+    does right after get_config (main.py:72-78).  Idempotent; a no-op when --shot is -1 / absent or the recipe has no dataset section."""
+    shot = getattr(args, "shot", -1)
+    if shot is None or shot == -1 or "dataset" not in config:
+        return config
+    for split in ("train", "val"):
+        sec = config.dataset.get(split)
+        if sec is None:
+            continue
+        if "others" not in sec:
+            sec.others = EasyDict()
+        sec.others.shot, sec.others.way, sec.others.fold = shot, getattr(args, "way", -1), getattr(args, "fold", -1)
     return config
 
 

@@ -51,11 +51,16 @@ def collect(d, counter):
 
 # round 2: the BatchNorm apply is fused into the consuming GEMM, so the calibration kernel is the BatchNorm backward apply pass
 # (bn_bwd_apply_kernel: reads x and dy, writes dx, each [262144, C] fp32, C = 128 and 512 once per Stage-II step)
-CAL_KERNEL, CAL_BYTES = "bn_bwd_apply_kernel", 262144.0 * (128 + 512) / 2 * 4
+# round 3: per-workload calibration bytes (argv[3] = c2 | s1 | c5): mean [rows, C] fp32 tensor size over the bn_bwd_apply launches of a step --
+# c2: mini-PointNet BN(128), BN(512) on 128*64*32 rows; s1: those two + the FoldingNet BN(512) x 2 on 128*64*32 rows; c5: 32*512*64 rows
+WORKLOAD = sys.argv[3] if len(sys.argv) > 3 else "c2"
+CAL_KERNEL = "bn_bwd_apply_kernel"
+CAL_BYTES = {"c2": 262144.0 * (128 + 512) / 2 * 4, "s1": 262144.0 * (128 + 512 + 512 + 512) / 4 * 4,
+             "c5": 1048576.0 * (128 + 512) / 2 * 4}[WORKLOAD]
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 kf = 2.0 * CAL_BYTES / (fetch[CAL_KERNEL][0] * 1024.0)
 kw = CAL_BYTES / (write[CAL_KERNEL][0] * 1024.0)
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
+out = {"workload": WORKLOAD, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
                  "--no-cpu-baseline --no-instrument",
        "units": "bytes per launch = counter [KiB] * 1024 * calibration factor",
        "calibration": {"kernel": CAL_KERNEL, "known_bytes_written_per_launch": CAL_BYTES, "known_bytes_read_per_launch": 2.0 * CAL_BYTES,

@@ -227,3 +227,61 @@ def test_bench_two_ranks_on_one_gpu_prints_one_line(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # whole-job clouds/s = B * world / step time
     assert "roofline" in d and "cpu_baseline" not in d and d["config"]["final_loss"] == d["config"]["final_loss"]
+
+
+# ---- the RCCL backend itself (backend "nccl" == RCCL on ROCm), world size 1 on the one GPU of the box --------------------------------
+def _rccl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["ACT_GEMM_AUTOTUNE"] = "0"
+    os.environ["ACT_OVERLAP_TEACHER"] = "1"
+    os.environ["ACT_OVERLAP_DW"] = "1"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert dist.get_backend() == "nccl"
+    import act_amd.kernels as K
+    import act_amd.models.act as AM
+    assert K.OVERLAP_DW and AM._OVERLAP_TEACHER              # the three-stream schedule is what is under test
+    from act_amd.tools.runner_pretrain import wrap_ddp
+    ns = argparse.Namespace(local_rank=rank, use_gpu=True)
+    model = _model(dev)
+    ddp = wrap_ddp(model, ns)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and ddp.gradient_as_bucket_view
+    losses, params = _trajectory(ddp, model, seed=123, data_seed=20, dev=dev)
+    # a small bucket cap: many buckets -> many stream-ordered all-reduces interleaved with the auxiliary-stream weight gradients
+    model3 = _model(dev)
+    ddp3 = torch.nn.parallel.DistributedDataParallel(model3, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True,
+                                                     bucket_cap_mb=0.05)
+    losses3, params3 = _trajectory(ddp3, model3, seed=123, data_seed=20, dev=dev)
+    # the logged-loss reduction of the runner (utils/dist_utils.py:41-48) through RCCL
+    from act_amd.utils import dist_utils
+    red = dist_utils.reduce_tensor(losses.to(dev), argparse.Namespace(world_size=world))
+    torch.cuda.synchronize()
+    torch.save({"losses": losses, "params": params, "losses3": losses3, "params3": params3, "reduced": red.cpu()},
+               os.path.join(out_dir, f"n{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_product_model_under_rccl_ddp_world1_is_bit_identical(tmp_path):
+    """backend='nccl' (RCCL) at world size 1: RCCL's all-reduce is stream-ordered (its own stream, ordered against the compute streams by
+    events only), unlike gloo's host-staged copy which serialises everything -- so this is the single-GPU form of the race between DDP's
+    bucket hooks and auxiliary streams 0 (teacher prefetch) and 1 (weight gradients).  4 pipelined AdamW steps through wrap_ddp must equal
+    the _Single run bit for bit, with the default 25 MB buckets and with 50 KB buckets (reference: tools/runner_pretrain.py:84-93,159-167)."""
+    assert torch.cuda.is_available()
+    from act_amd.tools.runner_pretrain import _Single
+    dev = torch.device("cuda:0")
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "n0.pt")
+    with _fixed_gemm_configs():
+        model = _model(dev)
+        losses, params = _trajectory(_Single(model), model, seed=123, data_seed=20, dev=dev)
+    assert len(set(losses.tolist())) == STEPS
+    for tag in ("", "3"):
+        assert torch.equal(r["losses" + tag], losses), (tag, r["losses" + tag], losses)
+        for n, p in params.items():
+            assert torch.equal(r["params" + tag][n], p), (tag, n)
+    assert torch.equal(r["reduced"], losses)
