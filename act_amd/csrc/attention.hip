@@ -731,7 +731,337 @@ __global__ __launch_bounds__(256) void attn_small_bwd_kernel(const float* __rest
     }
 }
 
+
+// =================================================================================== register-resident kernels for ANY sequence length (round 3)
+// One wave owns a 32-row block of one (cloud, head) and streams the other side through in 32-row tiles.  No LDS, no barrier: every operand
+// goes from global memory (L1 / L2 hits: a (cloud, head) pair's K, V, Q, dO are 16-32 KB each) straight into the register form its MFMA wants --
+//   "row form"  lane (row = lane&31, half = lane>>5) holds X[row][half*HD/2 .. +HD/2)   (A or B operand of a head-dimension reduction: the
+//               reduction index of an MFMA is a free permutation as long as A and B agree, so the two halves split the head dimension)
+//   "col form"  lane (c = lane&31, half) holds X[f(r, half)][dt*32 + c], f(r, half) = (r&3) + 8*(r>>2) + 4*half   (A operand of a reduction over
+//               rows: row f(r, half) is exactly the row the C/D register r of that half-wave belongs to, so P / dS / dS^t are B operands
+//               straight from their accumulator registers)
+// Forward: S^t = K Q^t (lane = one query: softmax in registers + one lane^32 exchange), O^t += V^t P^t with an online softmax per 32-key tile.
+// Backward, two roles in ONE launch (no workspace, no ordering between them; both recompute P from the saved log-sum-exp):
+//   dQ role   (one wave per 32 queries):  S^t, dP^t = V dO^t, dS^t = P^t (dP^t - D) scale, dQ^t += K^t dS^t            96 MFMAs per 32x32 tile pair
+//   dK/dV role (one wave per 32 keys):    S = Q K^t, dP = dO V^t, dV^t += dO^t P, dK^t += Q^t dS                         128 MFMAs per tile pair
+// (160 would do with a shared S / dP; the price of the 224 is what buys a barrier-free, LDS-free, occupancy-2 kernel whose MFMA pipe stays
+// busy -- the workgroup-per-pair kernel above sits at 14 % MFMA utilisation behind its five barriers per tile pair.)
+// Keys come from two row segments (S0 prefix rows of kv0, then the S1 rows of the packed qkv1), as in the kernels above.
+struct AttnRegArgs {
+    const float* q;  const float* k0; const float* v0; const float* k1; const float* v1;      // head 0 of row 0 of each operand
+    const float* out; const float* dout; const float* lse;                                    // backward only
+    float* dq; float* dk0; float* dv0; float* dk1; float* dv1;                                // backward outputs (same strides as the inputs)
+    float* o; float* lse_out;                                                                 // forward outputs
+    long long q_bs, kv0_bs, kv1_bs;      // per-cloud strides (floats)
+    int ldq, ld0, ld1;                   // row strides (floats)
+    int B, H, Sq, S0, S1;
+    float scale;
+};
+#define ATT_F(r, half) (((r) & 3) + 8 * ((r) >> 2) + 4 * (half))
+
+// Tails without clamps: the LAST 32-row tile of a side is shifted back to end exactly at the last row (rows S-32 .. S-1, all valid) and the
+// rows it shares with the previous tile are masked out of P (keys) or simply not stored (owned rows).  So every tile is a full tile inside ONE
+// segment (host-side condition: S0 % 32 == 0, S1 >= 32, Sq >= 32), every row address is a wave-uniform base + a 32-bit lane offset, and a
+// col-form fetch is a plain run of global_load_dword with SGPR bases.
+struct AttSeg { const float* base; int ld; };                           // rows t0 .. t0+31 of a two-segment operand (wave-uniform)
+__device__ __forceinline__ AttSeg att_seg_tile(const float* __restrict__ p0, int ld0, const float* __restrict__ p1, int ld1, int S0, int t0) {
+    AttSeg g;
+    if (t0 >= S0) { g.base = p1 + (size_t)(t0 - S0) * ld1; g.ld = ld1; } else { g.base = p0 + (size_t)t0 * ld0; g.ld = ld0; }
+    return g;
+}
+template <int HD>
+__device__ __forceinline__ void att_load_row_form(const AttSeg g, int row, int half, float* x) {              // lane's own row of the tile
+    const unsigned off = (unsigned)(row * g.ld + half * (HD / 2));
+#pragma unroll
+    for (int i = 0; i < HD / 8; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(g.base + off + 4 * i);
+        x[4 * i] = t.x; x[4 * i + 1] = t.y; x[4 * i + 2] = t.z; x[4 * i + 3] = t.w;
+    }
+}
+template <int HD>
+__device__ __forceinline__ void att_load_col_form(const AttSeg g, int c, int half, float (*x)[HD / 32]) {
+    const unsigned lane_off = (unsigned)(4 * half * g.ld + c);           // per-lane part; the row part below is wave-uniform
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* rb = g.base + (size_t)ATT_F(r, 0) * g.ld;
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt) x[r][dt] = rb[lane_off + dt * 32];
+    }
+}
+// store an accumulator pair in the o-layout (acc[dt][r] = X^t[d = dt*32 + f(r, half)][row = lane&31]) as row-major X[row][d], scaled
+template <int HD>
+__device__ __forceinline__ void att_store_o(float* __restrict__ rowp, int half, const f32x16* acc, float mul) {
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 t;
+            t.x = acc[dt][g * 4 + 0] * mul; t.y = acc[dt][g * 4 + 1] * mul; t.z = acc[dt][g * 4 + 2] * mul; t.w = acc[dt][g * 4 + 3] * mul;
+            *reinterpret_cast<float4*>(rowp + dt * 32 + 8 * g + 4 * half) = t;
+        }
+}
+// (wave-uniform work-item decomposition; 32-bit divisions expand to VALU code, so the results are pinned back into SGPRs)
+__device__ __forceinline__ void att_item(unsigned item, int ntiles, int H, int& tile, int& b, int& h) {
+    tile = __builtin_amdgcn_readfirstlane((int)(item % (unsigned)ntiles));
+    const unsigned pr = item / (unsigned)ntiles;
+    b = __builtin_amdgcn_readfirstlane((int)(pr / (unsigned)H));
+    h = __builtin_amdgcn_readfirstlane((int)(pr % (unsigned)H));
+}
+
+// Fetch placement (measured on the Stage-I prefix shape, 128 clouds x 12 heads x (64 q x 128 k), and on S = 512): every fragment is fetched
+// right where it is consumed and the co-resident waves of the SIMD cover the latency.  Issuing the fetches one MFMA burst early (software
+// pipelining: +32 ... +64 registers, one wave per SIMD fewer) was 15-25 % SLOWER, and parking coalesced 16-byte loads in a wave-private LDS
+// slab to pick both fragment forms out of it (8 instead of 40 global loads per tile) was 70-90 % slower: at these sizes the call moves about as
+// many HBM bytes as it has matrix work (Stage-I shape: 150 MB = 25 us at 6 TB/s against 20.5 us of MFMA issue; with every in-loop fetch removed
+// the forward still takes 44.8 us, i.e. the Q / O prologue and epilogue bursts of a single resident round of waves do not overlap the matrix
+// work), so what counts is waves in flight, not the instruction stream of one wave.
+template <int HD>
+__global__ __launch_bounds__(256, 3) void attn_fwd_reg_kernel(const AttnRegArgs a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int nqt = (a.Sq + 31) >> 5, Sk = a.S0 + a.S1;
+    const unsigned item = blockIdx.x * 4u + (unsigned)wave;
+    if (item >= (unsigned)(a.B * a.H * nqt)) return;
+    int qt, b, h;
+    att_item(item, nqt, a.H, qt, b, h);
+    const int q0n = qt * 32, q0 = min(q0n, a.Sq - 32);                  // nominal / shifted first query of this wave
+    const float* k0 = a.k0 + (size_t)b * a.kv0_bs + h * HD; const float* v0 = a.v0 + (size_t)b * a.kv0_bs + h * HD;
+    const float* k1 = a.k1 + (size_t)b * a.kv1_bs + h * HD; const float* v1 = a.v1 + (size_t)b * a.kv1_bs + h * HD;
+
+    float qreg[HD / 2];
+    att_load_row_form<HD>(AttSeg{a.q + (size_t)b * a.q_bs + (size_t)q0 * a.ldq + h * HD, a.ldq}, ql, half, qreg);
+    f32x16 o[HD / 32];
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m = -3.0e38f, l = 0.f;
+    const float scale = a.scale;
+
+    for (int t0n = 0; t0n < Sk; t0n += 32) {
+        const int t0 = min(t0n, Sk - 32);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            float kf[HD / 2];
+            att_load_row_form<HD>(att_seg_tile(k0, a.ld0, k1, a.ld1, a.S0, t0), ql, half, kf);
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qreg[s], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);                              // the V fragment re-uses the K fragment's registers: its loads are in flight
+        float vf[16][HD / 32];                                          // during the softmax; the other waves of the SIMD own the MFMA pipe meanwhile
+        att_load_col_form<HD>(att_seg_tile(v0, a.ld0, v1, a.ld1, a.S0, t0), ql, half, vf);
+        float mc = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = (t0 + ATT_F(r, half) >= t0n) ? acc[r] : -3.0e38f;     // rows shared with the previous tile are masked
+            acc[r] = v;
+            mc = fmaxf(mc, v);
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 32));
+        const float mn = fmaxf(m, mc);
+        const float alpha = __expf(scale * (m - mn));                   // 0 on the first tile (m = -huge)
+        m = mn;
+        float lc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __expf(scale * (acc[r] - m));               // masked keys: exp(-huge) == 0
+            acc[r] = p;
+            lc += p;
+        }
+        lc += __shfl_xor(lc, 32);
+        l = l * alpha + lc;
+        if (t0n > 0) {
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r][dt], acc[r], o[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int q = q0 + ql;
+    if (q >= q0n) {
+        att_store_o<HD>(a.o + ((size_t)b * a.Sq + q) * (a.H * HD) + h * HD, half, o, 1.0f / l);
+        if (a.lse_out && half == 0) a.lse_out[((size_t)b * a.H + h) * a.Sq + q] = scale * m + __logf(l);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_bwd_reg_kernel(const AttnRegArgs a, int n_dq_blocks) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int Sk = a.S0 + a.S1, D = a.H * HD;
+    const int nqt = (a.Sq + 31) >> 5, nkt = (Sk + 31) >> 5;
+    const float scale = a.scale;
+    if ((int)blockIdx.x < n_dq_blocks) {
+        // ------------------------------------------------------------------ dQ role: this wave owns 32 queries
+        const unsigned item = blockIdx.x * 4u + (unsigned)wave;
+        if (item >= (unsigned)(a.B * a.H * nqt)) return;
+        int qt, b, h;
+        att_item(item, nqt, a.H, qt, b, h);
+        const int q0n = qt * 32, q0 = min(q0n, a.Sq - 32);
+        const float* k0 = a.k0 + (size_t)b * a.kv0_bs + h * HD; const float* v0 = a.v0 + (size_t)b * a.kv0_bs + h * HD;
+        const float* k1 = a.k1 + (size_t)b * a.kv1_bs + h * HD; const float* v1 = a.v1 + (size_t)b * a.kv1_bs + h * HD;
+        float qreg[HD / 2], dor[HD / 2];
+        att_load_row_form<HD>(AttSeg{a.q + (size_t)b * a.q_bs + (size_t)q0 * a.ldq + h * HD, a.ldq}, ql, half, qreg);
+        att_load_row_form<HD>(AttSeg{a.dout + ((size_t)b * a.Sq + q0) * D + h * HD, D}, ql, half, dor);
+        float dlt;
+        {
+            float orow[HD / 2];
+            att_load_row_form<HD>(AttSeg{a.out + ((size_t)b * a.Sq + q0) * D + h * HD, D}, ql, half, orow);
+            float part = 0.f;
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s) part += dor[s] * orow[s];
+            dlt = part + __shfl_xor(part, 32);                          // D[q] = sum_d dO[q][d] O[q][d]
+        }
+        const float lq = a.lse[((size_t)b * a.H + h) * a.Sq + q0 + ql];
+        f32x16 dq[HD / 32];
+#pragma unroll
+        for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+        for (int t0n = 0; t0n < Sk; t0n += 32) {
+            const int t0 = min(t0n, Sk - 32);
+            f32x16 st, dpt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+            const AttSeg kg = att_seg_tile(k0, a.ld0, k1, a.ld1, a.S0, t0);
+            {
+                float kf[HD / 2], vf[HD / 2];
+                att_load_row_form<HD>(kg, ql, half, kf);
+                att_load_row_form<HD>(att_seg_tile(v0, a.ld0, v1, a.ld1, a.S0, t0), ql, half, vf);
+#pragma unroll
+                for (int s = 0; s < HD / 2; ++s) {
+                    st  = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qreg[s], st, 0, 0, 0);
+                    dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s], dor[s], dpt, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                          // K in col form re-uses the fragment registers; in flight during the dS arithmetic
+            float kc[16][HD / 32];
+            att_load_col_form<HD>(kg, ql, half, kc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = (t0 + ATT_F(r, half) >= t0n) ? __expf(scale * st[r] - lq) : 0.f;
+                st[r] = p * (dpt[r] - dlt) * scale;                     // dS^t[key = f(r, half)][query = ql]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int dt = 0; dt < HD / 32; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[r][dt], st[r], dq[dt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int q = q0 + ql;
+        if (q >= q0n) att_store_o<HD>(a.dq + (size_t)b * a.q_bs + (size_t)q * a.ldq + h * HD, half, dq, 1.0f);
+        return;
+    }
+    // ---------------------------------------------------------------------- dK / dV role: this wave owns 32 keys
+    const unsigned item = (blockIdx.x - (unsigned)n_dq_blocks) * 4u + (unsigned)wave;
+    if (item >= (unsigned)(a.B * a.H * nkt)) return;
+    int kt, b, h;
+    att_item(item, nkt, a.H, kt, b, h);
+    const int k0n = kt * 32, k0s = min(k0n, Sk - 32);
+    float kreg[HD / 2], vreg[HD / 2];
+    att_load_row_form<HD>(att_seg_tile(a.k0 + (size_t)b * a.kv0_bs + h * HD, a.ld0, a.k1 + (size_t)b * a.kv1_bs + h * HD, a.ld1, a.S0, k0s), ql, half, kreg);
+    att_load_row_form<HD>(att_seg_tile(a.v0 + (size_t)b * a.kv0_bs + h * HD, a.ld0, a.v1 + (size_t)b * a.kv1_bs + h * HD, a.ld1, a.S0, k0s), ql, half, vreg);
+    const float* qb = a.q + (size_t)b * a.q_bs + h * HD;
+    const float* ob = a.out + (size_t)b * a.Sq * D + h * HD;
+    const float* gb = a.dout + (size_t)b * a.Sq * D + h * HD;
+    const float* lb = a.lse + ((size_t)b * a.H + h) * a.Sq;
+    f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+    for (int dt = 0; dt < HD / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+    for (int u0n = 0; u0n < a.Sq; u0n += 32) {
+        const int u0 = min(u0n, a.Sq - 32);
+        const AttSeg qg{qb + (size_t)u0 * a.ldq, a.ldq}, gg{gb + (size_t)u0 * D, D};
+        float dlt, lq = lb[u0 + ql];
+        f32x16 sa, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+        {
+            float gf[HD / 2];
+            att_load_row_form<HD>(gg, ql, half, gf);
+            {
+                float orow[HD / 2];
+                att_load_row_form<HD>(AttSeg{ob + (size_t)u0 * D, D}, ql, half, orow);
+                float part = 0.f;
+#pragma unroll
+                for (int s = 0; s < HD / 2; ++s) part += gf[s] * orow[s];
+                dlt = part + __shfl_xor(part, 32);                      // lane (ql, *) holds D and lse of query u0 + ql
+            }
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[s], vreg[s], dp, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            float qf[HD / 2];
+            att_load_row_form<HD>(qg, ql, half, qf);
+#pragma unroll
+            for (int s = 0; s < HD / 2; ++s) sa = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[s], kreg[s], sa, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float gc[16][HD / 32];
+        att_load_col_form<HD>(gg, ql, half, gc);                        // dO, col form
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int src = ATT_F(r, half);                             // register r belongs to query u0 + f(r, half): fetch its lse and D
+            const float lr = __shfl(lq, src), dr = __shfl(dlt, src);
+            const float p = (u0 + src >= u0n) ? __expf(scale * sa[r] - lr) : 0.f;      // queries shared with the previous tile are masked
+            sa[r] = p;
+            dp[r] = p * (dp[r] - dr) * scale;                           // dS[query = f(r, half)][key = ql]
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[r][dt], sa[r], dv[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        att_load_col_form<HD>(qg, ql, half, gc);                        // Q, col form
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int dt = 0; dt < HD / 32; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[r][dt], dp[r], dk[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int key = k0s + ql;
+    if (key >= k0n) {
+        float* dkp = key < a.S0 ? a.dk0 + (size_t)b * a.kv0_bs + (size_t)key * a.ld0 + h * HD : a.dk1 + (size_t)b * a.kv1_bs + (size_t)(key - a.S0) * a.ld1 + h * HD;
+        float* dvp = key < a.S0 ? a.dv0 + (size_t)b * a.kv0_bs + (size_t)key * a.ld0 + h * HD : a.dv1 + (size_t)b * a.kv1_bs + (size_t)(key - a.S0) * a.ld1 + h * HD;
+        att_store_o<HD>(dkp, half, dk, 1.0f);
+        att_store_o<HD>(dvp, half, dv, 1.0f);
+    }
+}
+
 static const bool g_attn_small = [] { const char* e = getenv("ACT_ATTN_SMALL"); return !(e && e[0] == '0'); }();      // dev A/B knob
+
+static const bool g_attn_reg = [] { const char* e = getenv("ACT_ATTN_REG"); return !(e && e[0] == '0'); }();          // dev A/B knob: 0 = LDS-staged kernels
+// the register-resident kernels want full 32-row tiles inside one key segment (see the tail rule above)
+static inline bool attn_reg_ok(int Sq, int S0, int S1) { return g_attn_reg && Sq >= 32 && S1 >= 32 && (S0 % 32) == 0; }
+// forward: the LDS-staged kernel (K / V of a pair shared by the waves of a workgroup) is the faster one on 8 of 10 measured shapes; the
+// register-resident forward stays selectable for A/B runs (ACT_ATTN_FWD_REG=1)
+static const bool g_attn_fwd_reg = [] { const char* e = getenv("ACT_ATTN_FWD_REG"); return e && e[0] == '1'; }();
+
+static int launch_attn_fwd_reg(const AttnRegArgs& a, int head_dim, hipStream_t s) {
+    const long long items = (long long)a.B * a.H * ((a.Sq + 31) / 32);
+    const unsigned grid = (unsigned)((items + 3) / 4);
+    if (head_dim == 64) hipLaunchKernelGGL(attn_fwd_reg_kernel<64>, dim3(grid), dim3(256), 0, s, a);
+    else                hipLaunchKernelGGL(attn_fwd_reg_kernel<32>, dim3(grid), dim3(256), 0, s, a);
+    ACT_LAUNCH_CHECK();
+    return 0;
+}
+static int launch_attn_bwd_reg(const AttnRegArgs& a, int head_dim, hipStream_t s) {
+    const long long pairs = (long long)a.B * a.H;
+    const unsigned ndq = (unsigned)((pairs * ((a.Sq + 31) / 32) + 3) / 4), ndkv = (unsigned)((pairs * ((a.S0 + a.S1 + 31) / 32) + 3) / 4);
+    // the heavier dK / dV items (128 MFMAs per tile pair) are dispatched first? no: dQ blocks first -- their stores are the ones a following
+    // GEMM (dn1 = dqkv . W) waits for in full anyway; the order only shapes the tail
+    if (head_dim == 64) hipLaunchKernelGGL(attn_bwd_reg_kernel<64>, dim3(ndq + ndkv), dim3(256), 0, s, a, (int)ndq);
+    else                hipLaunchKernelGGL(attn_bwd_reg_kernel<32>, dim3(ndq + ndkv), dim3(256), 0, s, a, (int)ndq);
+    ACT_LAUNCH_CHECK();
+    return 0;
+}
 
 template <int HD>
 static int launch_attn_bwd_mfma_t(const AttnBwdArgs& a, hipStream_t s) {
@@ -795,6 +1125,13 @@ extern "C" int act_attention_fwd_f32(const float* qkv, float* out, float* lse, i
         ACT_LAUNCH_CHECK();
         return 0;
     }
+    if (g_attn_fwd_reg && attn_reg_ok(S, 0, S)) {
+        AttnRegArgs r{};
+        r.q = qkv; r.k0 = qkv; r.v0 = qkv; r.k1 = qkv + D; r.v1 = qkv + 2 * D;
+        r.q_bs = (long long)S * 3 * D; r.kv0_bs = 0; r.kv1_bs = r.q_bs; r.ldq = 3 * D; r.ld0 = 0; r.ld1 = 3 * D;
+        r.B = B; r.H = H; r.Sq = S; r.S0 = 0; r.S1 = S; r.scale = scale; r.o = out; r.lse_out = lse;
+        return launch_attn_fwd_reg(r, head_dim, s);
+    }
     AttnFwdArgs a;
     a.q = qkv; a.k0 = nullptr; a.v0 = nullptr; a.k1 = qkv + D; a.v1 = qkv + 2 * D;
     a.q_bs = (long long)S * 3 * D; a.kv0_bs = 0; a.kv1_bs = a.q_bs; a.ldq = 3 * D; a.ld0 = 0; a.ld1 = 3 * D;
@@ -813,6 +1150,13 @@ extern "C" int act_attention_fwd_prefix_f32(const float* kv0, int S0, const floa
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_ATTN_FWD, s, 4.0 * B * H * (double)Sq * (S0 + Sq) * head_dim, 4.0 * B * (double)H * head_dim * (4.0 * Sq + 2.0 * S0));
     const int D = H * head_dim;
+    if (g_attn_fwd_reg && attn_reg_ok(Sq, S0, Sq)) {
+        AttnRegArgs r{};
+        r.q = qkv1; r.k0 = kv0; r.v0 = kv0 + D; r.k1 = qkv1 + D; r.v1 = qkv1 + 2 * D;
+        r.q_bs = (long long)Sq * 3 * D; r.kv0_bs = (long long)S0 * 2 * D; r.kv1_bs = r.q_bs; r.ldq = 3 * D; r.ld0 = 2 * D; r.ld1 = 3 * D;
+        r.B = B; r.H = H; r.Sq = Sq; r.S0 = S0; r.S1 = Sq; r.scale = scale; r.o = out; r.lse_out = lse;
+        return launch_attn_fwd_reg(r, head_dim, s);
+    }
     AttnFwdArgs a;
     a.q = qkv1; a.k0 = kv0; a.v0 = kv0 + D; a.k1 = qkv1 + D; a.v1 = qkv1 + 2 * D;
     a.q_bs = (long long)Sq * 3 * D; a.kv0_bs = (long long)S0 * 2 * D; a.kv1_bs = a.q_bs; a.ldq = 3 * D; a.ld0 = 2 * D; a.ld1 = 3 * D;
@@ -834,6 +1178,17 @@ extern "C" int act_attention_bwd_f32(const float* qkv, const float* out, const f
         else                hipLaunchKernelGGL(attn_small_bwd_kernel<32>, dim3(grid), dim3(256), 0, s, qkv, out, dout, lse, dqkv, B, S, H, scale);
         ACT_LAUNCH_CHECK();
         return 0;
+    }
+    if (!use_valu && attn_reg_ok(S, 0, S)) {
+        hipStream_t s = (hipStream_t)stream;
+        ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)S * S * head_dim, 28.0 * B * S * (double)H * head_dim);
+        const int D = H * head_dim;
+        AttnRegArgs r{};
+        r.q = qkv; r.k0 = qkv; r.v0 = qkv; r.k1 = qkv + D; r.v1 = qkv + 2 * D; r.out = out; r.dout = dout; r.lse = lse;
+        r.dq = dqkv; r.dk0 = dqkv; r.dv0 = dqkv; r.dk1 = dqkv + D; r.dv1 = dqkv + 2 * D;
+        r.q_bs = (long long)S * 3 * D; r.kv0_bs = 0; r.kv1_bs = r.q_bs; r.ldq = 3 * D; r.ld0 = 0; r.ld1 = 3 * D;
+        r.B = B; r.H = H; r.Sq = S; r.S0 = 0; r.S1 = S; r.scale = scale;
+        return launch_attn_bwd_reg(r, head_dim, s);
     }
     if (!use_valu) {
         hipStream_t s = (hipStream_t)stream;
@@ -867,6 +1222,16 @@ extern "C" int act_attention_bwd_prefix_f32(const float* kv0, int S0, const floa
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_ATTN_BWD, s, 10.0 * B * H * (double)Sq * (S0 + Sq) * head_dim,
                     4.0 * B * (double)H * head_dim * (8.0 * Sq + 4.0 * S0));
+    if (attn_reg_ok(Sq, S0, Sq)) {
+        const int D = H * head_dim;
+        AttnRegArgs r{};
+        r.q = qkv1; r.k0 = S0 > 0 ? kv0 : qkv1; r.v0 = S0 > 0 ? kv0 + D : qkv1; r.k1 = qkv1 + D; r.v1 = qkv1 + 2 * D;
+        r.out = out; r.dout = dout; r.lse = lse;
+        r.dq = dqkv1; r.dk0 = S0 > 0 ? dkv0 : dqkv1; r.dv0 = S0 > 0 ? dkv0 + D : dqkv1; r.dk1 = dqkv1 + D; r.dv1 = dqkv1 + 2 * D;
+        r.q_bs = (long long)Sq * 3 * D; r.kv0_bs = (long long)S0 * 2 * D; r.kv1_bs = r.q_bs; r.ldq = 3 * D; r.ld0 = 2 * D; r.ld1 = 3 * D;
+        r.B = B; r.H = H; r.Sq = Sq; r.S0 = S0; r.S1 = Sq; r.scale = scale;
+        return launch_attn_bwd_reg(r, head_dim, s);
+    }
     AttnBwdArgs a;
     a.kv0 = kv0; a.qkv1 = qkv1; a.out = out; a.dout = dout; a.lse = lse; a.dkv0 = dkv0; a.dqkv1 = dqkv1;
     a.B = B; a.S0 = S0; a.Sq = Sq; a.H = H; a.scale = scale;

@@ -179,8 +179,9 @@ if os.environ.get("ACT_GEMM_TUNE_SAVE"):
     _atexit.register(_dump_tuned)
 
 
-def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
-    """time every (tile id, split-K) candidate for this product -> (best config, best ms per launch)."""
+def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1, trace=None):
+    """time every (tile id, split-K) candidate for this product -> (best config, best ms per launch); ``trace`` (a list) receives every
+    (tile, splits, ms) measured."""
     cands = []
     for tile, (bm, bn) in ((1, (128, 128)), (2, (128, 64)), (3, (64, 64))):
         nb = -(-M // bm) * -(-N // bn)
@@ -236,6 +237,8 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1):
             ev[1].record()
             ev[1].synchronize()
             t = min(t, ev[0].elapsed_time(ev[1]) / reps)
+        if trace is not None:
+            trace.append((tile, sp, t))
         if t < best_t:
             best, best_t = (tile, sp), t
     return best, best_t

@@ -7,7 +7,8 @@ import act_amd.kernels as K
 from gemm_bench import timeit
 
 for name, (B, S0, Sq, H) in {"stage1 prompt-prefix": (128, 64, 64, 12), "finetune S=65": (32, 0, 65, 6), "student enc S=14": (128, 0, 14, 6), "S=16": (128, 0, 16, 6), "S=7": (32, 0, 7, 2),
-                             "student dec S=64": (128, 0, 64, 6), "S=128": (128, 0, 128, 12), "stress S=512": (32, 0, 512, 12)}.items():
+                             "student dec S=64": (128, 0, 64, 6), "S=128": (128, 0, 128, 12), "stress S=512": (32, 0, 512, 12),
+                             "stress enc S=104": (32, 0, 104, 12), "stress teacher 64+512": (32, 64, 512, 12)}.items():
     hd = 64
     qkv = torch.randn(B * Sq, 3 * H * hd, device="cuda"); do = torch.randn(B * Sq, H * hd, device="cuda")
     kv0 = torch.randn(B * max(S0, 1), 2 * H * hd, device="cuda")
