@@ -43,6 +43,7 @@ SIGNATURES = {
     "act_scale_translate_f32": [_vp, _vp, _vp, _i, _i, _vp],
     "act_rotate_points_f32": [_vp, _vp, _i, _i, _vp],
     "act_chamfer_fwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "act_chamfer_fwd_ex_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "act_chamfer_bwd_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
 }
 _RESTYPE = {"act_arch": ctypes.c_char_p, "act_prof_kernel_name": ctypes.c_char_p, "act_fps_scratch_floats": ctypes.c_size_t}

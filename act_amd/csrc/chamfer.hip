@@ -12,7 +12,20 @@
 
 __device__ __forceinline__ float rl(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+// Squared distance in the two roundings a maintainer can meet.  FMA = false: every product and sum rounded (the oracle convention, what a
+// build with contraction off computes).  FMA = true: the form an FMA-contracting compiler (nvcc's default -fmad=true, LLVM's fadd(fmul, fmul)
+// combine) makes of chamfer.cu:43-57's  x2*x2 + y2*y2 + z2*z2  with x2 = b - a:  fma(z2, z2, fma(x2, x2, y2*y2))  -- the left product of
+// the first sum is fused, the right one is a rounded multiply, the last product is fused again.  Same distances up to two ulps; on (near)
+// ties the strict '<' scan may then keep another index, which is the point of the switch.
+template <bool FMA>
+__device__ __forceinline__ float ch_sqdist(float bx, float by, float bz, float ax, float ay, float az) {
+    if constexpr (!FMA) return sqdist3(bx, by, bz, ax, ay, az);
+    const float dx = __fsub_rn(bx, ax), dy = __fsub_rn(by, ay), dz = __fsub_rn(bz, az);
+    return __fmaf_rn(dz, dz, __fmaf_rn(dx, dx, __fmul_rn(dy, dy)));
+}
+
 // ------------------------------------------------------------------ small: one wave per pair
+template <bool FMA>
 __global__ __launch_bounds__(256) void chamfer_small_fwd(const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                          int B, int n, int m, float* __restrict__ dist1,
                                                          float* __restrict__ dist2, int32_t* __restrict__ idx1,
@@ -25,11 +38,11 @@ __global__ __launch_bounds__(256) void chamfer_small_fwd(const float* __restrict
     if (lane < m) { const float* p = xyz2 + ((size_t)i * m + lane) * 3; bx = p[0]; by = p[1]; bz = p[2]; }
     float best1 = 0.f, best2 = 0.f; int bi1 = 0, bi2 = 0;
     for (int k = 0; k < m; ++k) {             // for every point of cloud 1: nearest in cloud 2
-        const float d = sqdist3(rl(bx, k), rl(by, k), rl(bz, k), ax, ay, az);
+        const float d = ch_sqdist<FMA>(rl(bx, k), rl(by, k), rl(bz, k), ax, ay, az);
         if (k == 0 || d < best1) { best1 = d; bi1 = k; }
     }
     for (int k = 0; k < n; ++k) {
-        const float d = sqdist3(rl(ax, k), rl(ay, k), rl(az, k), bx, by, bz);
+        const float d = ch_sqdist<FMA>(rl(ax, k), rl(ay, k), rl(az, k), bx, by, bz);
         if (k == 0 || d < best2) { best2 = d; bi2 = k; }
     }
     if (lane < n) { dist1[(size_t)i * n + lane] = best1; idx1[(size_t)i * n + lane] = bi1; }
@@ -69,6 +82,7 @@ __global__ __launch_bounds__(256) void chamfer_small_bwd(const float* __restrict
 
 // ------------------------------------------------------------------ large: LDS-tiled
 #define CH_TILE 1024
+template <bool FMA>
 __global__ __launch_bounds__(256) void chamfer_large_fwd(const float* __restrict__ a, int n, const float* __restrict__ bsrc, int m,
                                                          float* __restrict__ dist, int32_t* __restrict__ idx) {
     __shared__ float buf[CH_TILE * 3];
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(256) void chamfer_large_fwd(const float* __restrict
         __syncthreads();
         if (j < n) {
             for (int k = 0; k < cnt; ++k) {
-                const float d = sqdist3(buf[k * 3], buf[k * 3 + 1], buf[k * 3 + 2], x1, y1, z1);
+                const float d = ch_sqdist<FMA>(buf[k * 3], buf[k * 3 + 1], buf[k * 3 + 2], x1, y1, z1);
                 if ((k2 + k) == 0 || d < best) { best = d; bi = k2 + k; }
             }
         }
@@ -129,22 +143,32 @@ __global__ __launch_bounds__(256) void chamfer_large_bwd(const float* __restrict
     if (j < n) { float* o = grad_a + ((size_t)i * n + j) * 3; o[0] = rx; o[1] = ry; o[2] = rz; }
 }
 
-extern "C" int act_chamfer_fwd_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
-                                   int32_t* idx1, int32_t* idx2, act_stream_t stream) {
+extern "C" int act_chamfer_fwd_ex_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
+                                      int32_t* idx1, int32_t* idx2, int fma_contract, act_stream_t stream) {
     if (B == 0) return 0;
     if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2) return ACT_E_NULLPTR;
     if (B < 0 || n <= 0 || m <= 0 || B > 65535 * 4) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_CHAMFER_FWD, s, 0.0, (double)B * 20.0 * (n + m));      // 12(n+m) read + 8(n+m) write
     if (n <= 64 && m <= 64) {
-        hipLaunchKernelGGL(chamfer_small_fwd, dim3((B + 3) / 4), dim3(256), 0, s, xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2);
+        if (fma_contract) hipLaunchKernelGGL(chamfer_small_fwd<true>, dim3((B + 3) / 4), dim3(256), 0, s, xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2);
+        else              hipLaunchKernelGGL(chamfer_small_fwd<false>, dim3((B + 3) / 4), dim3(256), 0, s, xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2);
     } else {
         if (B > 65535) return ACT_E_BADARG;
-        hipLaunchKernelGGL(chamfer_large_fwd, dim3((n + 255) / 256, B), dim3(256), 0, s, xyz1, n, xyz2, m, dist1, idx1);
-        hipLaunchKernelGGL(chamfer_large_fwd, dim3((m + 255) / 256, B), dim3(256), 0, s, xyz2, m, xyz1, n, dist2, idx2);
+        if (fma_contract) {
+            hipLaunchKernelGGL(chamfer_large_fwd<true>, dim3((n + 255) / 256, B), dim3(256), 0, s, xyz1, n, xyz2, m, dist1, idx1);
+            hipLaunchKernelGGL(chamfer_large_fwd<true>, dim3((m + 255) / 256, B), dim3(256), 0, s, xyz2, m, xyz1, n, dist2, idx2);
+        } else {
+            hipLaunchKernelGGL(chamfer_large_fwd<false>, dim3((n + 255) / 256, B), dim3(256), 0, s, xyz1, n, xyz2, m, dist1, idx1);
+            hipLaunchKernelGGL(chamfer_large_fwd<false>, dim3((m + 255) / 256, B), dim3(256), 0, s, xyz2, m, xyz1, n, dist2, idx2);
+        }
     }
     ACT_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int act_chamfer_fwd_f32(const float* xyz1, const float* xyz2, int B, int n, int m, float* dist1, float* dist2,
+                                   int32_t* idx1, int32_t* idx2, act_stream_t stream) {
+    return act_chamfer_fwd_ex_f32(xyz1, xyz2, B, n, m, dist1, dist2, idx1, idx2, 0, stream);
 }
 
 extern "C" int act_chamfer_bwd_f32(const float* xyz1, const float* xyz2, const int32_t* idx1, const int32_t* idx2,

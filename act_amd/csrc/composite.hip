@@ -224,22 +224,44 @@ int act_block_bwd_f32(const act_block_dims_t* d, const act_block_params_t* w, co
         if (db) CK(colsum(dy, T, N, db, wws, wwsb, ss));
         return 0;
     };
+    // ... or two Linears at a time: ONE grouped launch (gemm_grouped.hip) computes both weight gradients and both bias gradients
+    // (+ one reduction launch for the K ranges) instead of 2 GEMMs + 2 split-K reductions + 4 column-sum launches.
+    static const bool grouped_env = [] { const char* e = getenv("ACT_GROUPED_DW"); return !(e && e[0] == '0'); }();
+    const bool grouped = grouped_env && g && g->fc2_w && g->fc1_w && g->proj_w && g->qkv_w && (D % 128) == 0 && (Hd % 128) == 0 && (T % 16) == 0 && wws;
+    auto wgrad2 = [&](const act_gemm_tn_problem_t* pr) -> int {
+        if (t_collect) return 0;
+        if (fork) CK(order_after(ss, s));
+        int sp = act_sgemm_tn_grouped_splits(pr, 2, T);
+        while (sp > 1 && act_sgemm_tn_grouped_workspace(pr, 2, T, sp) > wwsb) --sp;
+        return act_sgemm_tn_grouped_f32(pr, 2, T, sp, wws, wwsb, ss);
+    };
 
     const float* dy2 = dout;
     if (gate2) { RUN(act_scale_rows_f32(dout, gate2, T, D, S, sc.dy2, s)); dy2 = sc.dy2; }
-    CK(wgrad(dy2, D, sv.a, Hd, g ? g->fc2_w : nullptr, g ? g->fc2_b : nullptr));
+    if (!grouped) CK(wgrad(dy2, D, sv.a, Hd, g ? g->fc2_w : nullptr, g ? g->fc2_b : nullptr));
     act_gemm_epilogue_t e = epi0(); e.act = ACT_EPI_MUL_GELU_GRAD; e.aux = sv.hpre; e.ldaux = Hd;
     CK(gemm_nn(T, Hd, D, dy2, D, w->fc2_w, Hd, sc.dh, Hd, e, ws, wsb, s));
-    CK(wgrad(sc.dh, Hd, sv.n2, D, g ? g->fc1_w : nullptr, g ? g->fc1_b : nullptr));
+    if (grouped) {
+        const act_gemm_tn_problem_t pr[2] = {{dy2, D, sv.a, Hd, g->fc2_w, Hd, D, Hd, g->fc2_b}, {sc.dh, Hd, sv.n2, D, g->fc1_w, D, Hd, D, g->fc1_b}};
+        CK(wgrad2(pr));
+    } else {
+        CK(wgrad(sc.dh, Hd, sv.n2, D, g ? g->fc1_w : nullptr, g ? g->fc1_b : nullptr));
+    }
     CK(gemm_nn(T, D, Hd, sc.dh, Hd, w->fc1_w, D, sc.dn2, D, epi0(), ws, wsb, s));
     RUN(act_layernorm_bwd_f32(sc.dn2, sv.x1, w->norm2_w, sv.mean2, sv.rstd2, dout, sc.dx1, g ? g->norm2_w : nullptr, g ? g->norm2_b : nullptr, 0,
                              ws, wsb, T, D, s));
     const float* dy1 = sc.dx1;
     if (gate1) { RUN(act_scale_rows_f32(sc.dx1, gate1, T, D, S, sc.dy1, s)); dy1 = sc.dy1; }
-    CK(wgrad(dy1, D, sv.att, D, g ? g->proj_w : nullptr, g ? g->proj_b : nullptr));
+    if (!grouped) CK(wgrad(dy1, D, sv.att, D, g ? g->proj_w : nullptr, g ? g->proj_b : nullptr));
     CK(gemm_nn(T, D, D, dy1, D, w->proj_w, D, sc.datt, D, epi0(), ws, wsb, s));
     RUN(act_attention_bwd_f32(sv.qkv, sv.att, sc.datt, sv.lse, sc.dqkv, B, S, H, hd, attn_scale(hd), s));
-    CK(wgrad(sc.dqkv, 3 * D, sv.n1, D, g ? g->qkv_w : nullptr, (g && w->qkv_b) ? g->qkv_b : nullptr));
+    if (grouped) {
+        const act_gemm_tn_problem_t pr[2] = {{dy1, D, sv.att, D, g->proj_w, D, D, D, g->proj_b},
+                                             {sc.dqkv, 3 * D, sv.n1, D, g->qkv_w, D, 3 * D, D, w->qkv_b ? g->qkv_b : nullptr}};
+        CK(wgrad2(pr));
+    } else {
+        CK(wgrad(sc.dqkv, 3 * D, sv.n1, D, g ? g->qkv_w : nullptr, (g && w->qkv_b) ? g->qkv_b : nullptr));
+    }
     CK(gemm_nn(T, D, 3 * D, sc.dqkv, 3 * D, w->qkv_w, D, sc.dn1, D, epi0(), ws, wsb, s));
     RUN(act_layernorm_bwd_f32(sc.dn1, sv.xin, w->norm1_w, sv.mean1, sv.rstd1, sc.dx1, dx, g ? g->norm1_w : nullptr, g ? g->norm1_b : nullptr, 0,
                              ws, wsb, T, D, s));

@@ -246,19 +246,47 @@ __global__ __launch_bounds__(256, PIPE ? 3 : GEMM_MIN_WAVES) void sgemm_kernel(c
         }
 }
 
-// split-K reduction + epilogue (deterministic: fixed summation order over splits)
-__global__ void sgemm_splitk_reduce(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
-                                    const act_gemm_epilogue_t epi) {
+// split-K reduction + epilogue (deterministic: fixed summation order over splits).  VEC: four consecutive columns per thread (float4 partial
+// loads, one row / column division per four outputs) -- same sums in the same order as the scalar form, element for element.
+template <bool VEC>
+__global__ __launch_bounds__(256) void sgemm_splitk_reduce(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
+                                                           const act_gemm_epilogue_t epi) {
     const long long total = (long long)M * N;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + i];
-        const int row = (int)(i / N), col = (int)(i % N);
-        v = epilogue_apply(epi, v, row, col);
-        float* c = C + (size_t)row * ldc + col;
-        if (epi.accumulate) v += *c;
-        *c = v;
+    if constexpr (VEC) {
+        const int n4 = N >> 2;
+        const long long total4 = (long long)M * n4;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+            const int row = (int)(i / n4), col = (int)(i - (long long)row * n4) * 4;
+            const float* p = partial + (size_t)row * N + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int s = 0; s < splits; ++s) {
+                const float4 x = *reinterpret_cast<const float4*>(p + (size_t)s * total);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            v.x = epilogue_apply(epi, v.x, row, col); v.y = epilogue_apply(epi, v.y, row, col + 1);
+            v.z = epilogue_apply(epi, v.z, row, col + 2); v.w = epilogue_apply(epi, v.w, row, col + 3);
+            float4* c = reinterpret_cast<float4*>(C + (size_t)row * ldc + col);
+            if (epi.accumulate) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *c = v;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + i];
+            const int row = (int)(i / N), col = (int)(i % N);
+            v = epilogue_apply(epi, v, row, col);
+            float* c = C + (size_t)row * ldc + col;
+            if (epi.accumulate) v += *c;
+            *c = v;
+        }
     }
+}
+static void launch_splitk_reduce(const float* partial, int splits, int M, int N, float* C, int ldc, const act_gemm_epilogue_t& epi, hipStream_t s) {
+    const bool vec = (N & 3) == 0 && (ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(partial)) & 15) == 0;
+    const long long total = vec ? (long long)M * (N >> 2) : (long long)M * N;
+    long long g = (total + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
+    if (vec) hipLaunchKernelGGL(sgemm_splitk_reduce<true>, dim3((unsigned)g), dim3(256), 0, s, partial, splits, M, N, C, ldc, epi);
+    else     hipLaunchKernelGGL(sgemm_splitk_reduce<false>, dim3((unsigned)g), dim3(256), 0, s, partial, splits, M, N, C, ldc, epi);
 }
 
 // Skinny weight gradients (TN, min(M,N) <= 8, K = tokens): e.g. dW of the 3->128 first conv, of the 512->3 / 5->512 FoldingNet
@@ -376,9 +404,7 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
             else        hipLaunchKernelGGL(sgemm_tn_skinny_kernel<false>, dim3((N + 63) / 64, nparts), dim3(256), 0, s, B, ldb, N, A, lda, M, K,
                                            rpp, M, N, workspace);
             ACT_LAUNCH_CHECK();
-            const long long total = (long long)M * N;
-            long long g = (total + 255) / 256; if (g > 4096) g = 4096;
-            hipLaunchKernelGGL(sgemm_splitk_reduce, dim3((unsigned)g), dim3(256), 0, s, workspace, nparts, M, N, C, ldc, p.epi);
+            launch_splitk_reduce(workspace, nparts, M, N, C, ldc, p.epi, s);
             ACT_LAUNCH_CHECK();
             return 0;
         }
@@ -467,9 +493,7 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     }
     ACT_LAUNCH_CHECK();
     if (splits > 1) {
-        const long long total = (long long)M * N;
-        long long g = (total + 255) / 256; if (g > 4096) g = 4096;
-        hipLaunchKernelGGL(sgemm_splitk_reduce, dim3((unsigned)g), dim3(256), 0, s, workspace, splits, M, N, C, ldc, p.epi);
+        launch_splitk_reduce(workspace, splits, M, N, C, ldc, p.epi, s);
         ACT_LAUNCH_CHECK();
     }
     return 0;
@@ -559,9 +583,7 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         if (!launch_sgemm_q16_fx(p, 0, mask, dim3((unsigned)nt, 1, (unsigned)splits), s)) return ACT_E_BADARG;
         ACT_LAUNCH_CHECK();
         if (splits > 1) {
-            const long long total = (long long)M * N;
-            long long g = (total + 255) / 256; if (g > 4096) g = 4096;
-            hipLaunchKernelGGL(sgemm_splitk_reduce, dim3((unsigned)g), dim3(256), 0, s, workspace, splits, M, N, C, ldc, p.epi);
+            launch_splitk_reduce(workspace, splits, M, N, C, ldc, p.epi, s);
             ACT_LAUNCH_CHECK();
         }
         return 0;

@@ -15,6 +15,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // =============================================== FPS ==============================================
 // LDS_CLOUD is a template parameter on purpose: a runtime LDS-or-global choice compiles to FLAT loads, whose latency sits on
 // the critical path of every one of the G-1 dependent iterations.
@@ -66,6 +68,9 @@ __global__ __launch_bounds__(WAVES * 64) void fps_kernel(const float* __restrict
         // distances are >= 0 (dead / padding: -1): their bit patterns compare like signed integers, so the wave reduction
         // runs on integers and carries no float canonicalisation ops in its dependent chain
         int best = (int)0x80000000; int bj = 0;
+        // (packed fp32 -- v_pk_add_f32 / v_pk_mul_f32 on point pairs, bit-exact -- was measured here and is NOT used: 551 vs 525 us for
+        // 32 x 8192 -> 512, 1,116 vs 1,066 us for 128 x 8192 -> 1,024; the pairs cost register moves on the coordinates that stay resident
+        // for the whole launch.  The kNN distance fill, which streams its points once, does gain from it: see knn_group2_kernel.)
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
             const float d = sqdist3(px[j], py[j], pz[j], cx, cy, cz);
@@ -272,12 +277,24 @@ __global__ __launch_bounds__(256) void knn_group2_kernel(const float* __restrict
     for (int g = 0; g < NG; ++g) {
         float m = INF; int mj = 0;
 #pragma unroll
-        for (int i = 0; i < GS; ++i) {
+        for (int i = 0; i < GS; i += 2) {
+            // two points per step, on the interleaved pairs (x0,y0) (z0,x1) (y1,z1) exactly as they sit in memory: three v_pk_add_f32 + three
+            // v_pk_mul_f32 give the six squared differences (each half rounded like the scalar op), four scalar adds finish
+            // (dx*dx + dy*dy) + dz*dz per point -- 5 instead of 8 VALU issues a point, same bits as the oracle
             const int k = base + g * GS + i;
-            float v = INF;
-            if (k < N) v = sqdist3(r[k * 3 + 0], r[k * 3 + 1], r[k * 3 + 2], qx, qy, qz);
-            d[g * GS + i] = v;
-            if (v < m) { m = v; mj = i; }
+            float v0 = INF, v1 = INF;
+            if (k + 1 < N) {
+                const float* __restrict__ pp = r + (size_t)k * 3;
+                const f32x2 a = f32x2{pp[0], pp[1]} - f32x2{qx, qy}, bq = f32x2{pp[2], pp[3]} - f32x2{qz, qx}, c = f32x2{pp[4], pp[5]} - f32x2{qy, qz};
+                const f32x2 a2 = a * a, b2 = bq * bq, c2 = c * c;
+                v0 = __fadd_rn(__fadd_rn(a2[0], a2[1]), b2[0]);
+                v1 = __fadd_rn(__fadd_rn(b2[1], c2[0]), c2[1]);
+            } else if (k < N) {
+                v0 = sqdist3(r[k * 3 + 0], r[k * 3 + 1], r[k * 3 + 2], qx, qy, qz);
+            }
+            d[g * GS + i] = v0; d[g * GS + i + 1] = v1;
+            if (v0 < m) { m = v0; mj = i; }
+            if (v1 < m) { m = v1; mj = i + 1; }
         }
         gmin[g] = m; gj[g] = mj;
     }

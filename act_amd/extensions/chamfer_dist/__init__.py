@@ -1,7 +1,13 @@
 """Drop-in for ``extensions.chamfer_dist`` (extensions/chamfer_dist/__init__.py:13-84) and the
 pybind module ``chamfer`` it wraps (chamfer_cuda.cpp:12-39), backed by act_chamfer_{fwd,bwd}_f32.
 Unlike the reference, errors raise, inputs are validated, the launch is on the current stream and the
-backward is deterministic."""
+backward is deterministic.
+
+``fma_contract`` (module argument, or ACT_CHAMFER_FMA_CONTRACT=1 for every call that does not say otherwise): evaluate the squared
+distance the way an FMA-contracting build of chamfer.cu:43-57 does (nvcc's default), instead of rounding every product and sum -- the
+switch for comparing nearest-neighbour indices with outputs of a real CUDA build of the reference (cf. ``fps_skip_near_origin``)."""
+import os
+
 import torch
 
 from ... import _C
@@ -15,9 +21,12 @@ def _check(xyz1, xyz2):
         raise RuntimeError("chamfer: batch sizes differ")
 
 
+FMA_CONTRACT = os.environ.get("ACT_CHAMFER_FMA_CONTRACT", "0") == "1"
+
+
 class chamfer:          # namespace standing in for the compiled ``chamfer`` module
     @staticmethod
-    def forward(xyz1, xyz2):
+    def forward(xyz1, xyz2, fma_contract=None):
         _check(xyz1, xyz2)
         xyz1 = xyz1.contiguous(); xyz2 = xyz2.contiguous()
         B, n, _ = xyz1.shape
@@ -25,8 +34,9 @@ class chamfer:          # namespace standing in for the compiled ``chamfer`` mod
         dev = xyz1.device
         dist1 = torch.empty(B, n, dtype=torch.float32, device=dev); dist2 = torch.empty(B, m, dtype=torch.float32, device=dev)
         idx1 = torch.empty(B, n, dtype=torch.int32, device=dev); idx2 = torch.empty(B, m, dtype=torch.int32, device=dev)
-        _C.check(_C.lib.act_chamfer_fwd_f32(_C.ptr(xyz1), _C.ptr(xyz2), B, n, m, _C.ptr(dist1), _C.ptr(dist2),
-                                            _C.ptr(idx1), _C.ptr(idx2), _C.stream()), "act_chamfer_fwd_f32")
+        fma = FMA_CONTRACT if fma_contract is None else bool(fma_contract)
+        _C.check(_C.lib.act_chamfer_fwd_ex_f32(_C.ptr(xyz1), _C.ptr(xyz2), B, n, m, _C.ptr(dist1), _C.ptr(dist2),
+                                               _C.ptr(idx1), _C.ptr(idx2), int(fma), _C.stream()), "act_chamfer_fwd_ex_f32")
         return [dist1, dist2, idx1, idx2]
 
     @staticmethod
@@ -44,8 +54,8 @@ class chamfer:          # namespace standing in for the compiled ``chamfer`` mod
 
 class ChamferFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz1, xyz2):
-        dist1, dist2, idx1, idx2 = chamfer.forward(xyz1, xyz2)
+    def forward(ctx, xyz1, xyz2, fma_contract=None):
+        dist1, dist2, idx1, idx2 = chamfer.forward(xyz1, xyz2, fma_contract)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         return dist1, dist2
 
@@ -53,7 +63,7 @@ class ChamferFunction(torch.autograd.Function):
     def backward(ctx, grad_dist1, grad_dist2):
         xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
         grad_xyz1, grad_xyz2 = chamfer.backward(xyz1, xyz2, idx1, idx2, grad_dist1, grad_dist2)
-        return grad_xyz1, grad_xyz2
+        return grad_xyz1, grad_xyz2, None
 
 
 def _drop_zeros(xyz1, xyz2):
@@ -63,14 +73,15 @@ def _drop_zeros(xyz1, xyz2):
 
 
 class _ChamferBase(torch.nn.Module):
-    def __init__(self, ignore_zeros=False):
+    def __init__(self, ignore_zeros=False, fma_contract=None):
         super().__init__()
         self.ignore_zeros = ignore_zeros
+        self.fma_contract = fma_contract          # None: ACT_CHAMFER_FMA_CONTRACT decides (default off)
 
     def _dists(self, xyz1, xyz2):
         if xyz1.size(0) == 1 and self.ignore_zeros:
             xyz1, xyz2 = _drop_zeros(xyz1, xyz2)
-        return ChamferFunction.apply(xyz1, xyz2)
+        return ChamferFunction.apply(xyz1, xyz2, self.fma_contract)
 
 
 class ChamferDistanceL2(_ChamferBase):

@@ -47,6 +47,18 @@ for _n in ("act_sgemm_f32", "act_sgemm_ex_f32", "act_layernorm_fwd_f32", "act_la
 
 lib, ptr, stream, check = _C.lib, _C.ptr, _C.stream, _C.check
 
+
+class GemmTnProblem(ctypes.Structure):                 # act_gemm_tn_problem_t
+    _fields_ = [("A", _vp), ("lda", _i), ("B", _vp), ("ldb", _i), ("C", _vp), ("ldc", _i), ("M", _i), ("N", _i), ("bias_out", _vp)]
+
+
+_C._declare({"act_sgemm_tn_grouped_workspace": [ctypes.POINTER(GemmTnProblem), _i, _i, _i],
+             "act_sgemm_tn_grouped_splits": [ctypes.POINTER(GemmTnProblem), _i, _i],
+             "act_sgemm_tn_grouped_f32": [ctypes.POINTER(GemmTnProblem), _i, _i, _i, _vp, _sz, _vp]})
+_C.lib.act_sgemm_tn_grouped_workspace.restype = _sz
+for _n in ("act_sgemm_tn_grouped_workspace", "act_sgemm_tn_grouped_splits", "act_sgemm_tn_grouped_f32"):
+    _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
+
 # ---- persistent scratch (split-K partials, LN / colsum partial rows): one buffer per device ----------
 _WS = {}
 _WS_BYTES = 64 << 20
@@ -78,6 +90,7 @@ def side_stream(device, which=0):
 
 
 OVERLAP_DW = os.environ.get("ACT_OVERLAP_DW", "1") != "0"
+GROUPED_DW = os.environ.get("ACT_GROUPED_DW", "1") != "0"      # weight + bias gradients of two Linears per launch (0: one GEMM + column sum each)
 
 
 class fork_side:
@@ -151,6 +164,29 @@ def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, 
     return out
 
 
+def gemm_tn_grouped(pairs, want_bias=True, splits=0):
+    """[(dy [T,M], x [T,N]), ...] -> ([dW_p = dy_p^T . x_p  [M,N]], [db_p = column sums of dy_p  [M]]) in ONE launch (+ one reduction launch
+    for the K ranges): the weight / bias gradients of several Linears that share the token dimension (csrc/gemm_grouped.hip)."""
+    T = pairs[0][0].shape[0]
+    dev = pairs[0][0].device
+    probs = (GemmTnProblem * len(pairs))()
+    dws, dbs = [], []
+    for i, (dy, x) in enumerate(pairs):
+        if dy.shape[0] != T or x.shape[0] != T:
+            raise _C.ActHipError("gemm_tn_grouped: every operand needs the same number of rows")
+        M, N = dy.shape[1], x.shape[1]
+        dw = torch.empty(M, N, dtype=torch.float32, device=dev)
+        db = torch.empty(M, dtype=torch.float32, device=dev) if want_bias else None
+        dws.append(dw); dbs.append(db)
+        probs[i] = GemmTnProblem(_C.ptr_rows(dy).value, dy.stride(0), _C.ptr_rows(x).value, x.stride(0), dw.data_ptr(), N, M, N,
+                                 db.data_ptr() if db is not None else None)
+    if splits <= 0:
+        splits = lib.act_sgemm_tn_grouped_splits(probs, len(pairs), T)
+    ws = workspace(dev, lib.act_sgemm_tn_grouped_workspace(probs, len(pairs), T, splits))
+    check(lib.act_sgemm_tn_grouped_f32(probs, len(pairs), T, splits, ptr(ws), ws.numel() * 4, stream()), "act_sgemm_tn_grouped_f32")
+    return dws, dbs
+
+
 # ---- GEMM autotuner: the step has ~40 distinct (layout, M, N, K) shapes; each is timed once (tile shape x split-K) on first
 # use -- i.e. during the warm-up steps -- and the winner is cached, so steady-state steps never synchronise.
 _GEMM_CACHE = {}
@@ -208,6 +244,8 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1, trace=None):
             nbq = -(-M // (128 if tile == 1 else 64)) * (N // 128)
             if K >= 1024 and nbq < 2048:
                 qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
+            if K >= 512 and nbq < 128:                                # a handful of tiles: K ranges down to 128 rows, up to one round of 512 workgroups
+                qsp += [s for s in (5, 7, 9, 10, 12, 14, 16) if s not in qsp and K // s >= 128 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 512]
             if _MAX_SPLIT > 0 and K <= 8192:
                 qsp = [s for s in qsp if s <= _MAX_SPLIT]
             cands += [(12 + tile, s) for s in qsp if K % 32 == 0]                     # NN / TN: quad fragments (13: 128x128, 14: 64x128)
@@ -216,6 +254,8 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1, trace=None):
             nbq = -(-M // (128 if tile == 2 else 64)) * (N // 64)
             if K >= 1024 and nbq < 2048:
                 qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
+            if K >= 512 and nbq < 128:                                # a handful of tiles: K ranges down to 128 rows, up to one round of 512 workgroups
+                qsp += [s for s in (5, 7, 9, 10, 12, 14, 16) if s not in qsp and K // s >= 128 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 512]
             if _MAX_SPLIT > 0 and K <= 8192:
                 qsp = [s for s in qsp if s <= _MAX_SPLIT]
             cands += [(16 if tile == 2 else 15, s) for s in qsp if K % 32 == 0]
@@ -483,16 +523,38 @@ class BlockFnPerKernel(torch.autograd.Function):
                     return gemm(dy, x, False, False), (colsum(dy) if want_bias else None)
             return gemm(dy, x, False, False), (colsum(dy) if want_bias else None)
 
-        dw2, db2 = wgrad(dy2, a)
+        # two Linears at a time through the grouped launch (csrc/gemm_grouped.hip), as act_block_bwd_f32 does -- same kernels, same K-range
+        # counts, so the per-kernel path stays bit-identical to the composite one
+        T = B * S
+        grouped = tw and GROUPED_DW and D % 128 == 0 and w1.shape[0] % 128 == 0 and T % 16 == 0
+
+        def wgrad2(p0, p1, bias1=True):
+            def run():
+                dws, dbs = gemm_tn_grouped([p0, p1], want_bias=True)
+                return dws[0], dbs[0], dws[1], (dbs[1] if bias1 else None)
+            if par:
+                with fork_side(dev):
+                    return run()
+            return run()
+
+        if not grouped:
+            dw2, db2 = wgrad(dy2, a)
         dh = gemm(dy2, w2, True, False, act=EPI_MUL_GELU_GRAD, aux=hpre)
-        dw1, db1 = wgrad(dh, n2)
+        if grouped:
+            dw2, db2, dw1, db1 = wgrad2((dy2, a), (dh, n2))
+        else:
+            dw1, db1 = wgrad(dh, n2)
         dn2 = gemm(dh, w1, True, False)
         dx1, dg2, dbt2 = layernorm_bwd(dn2, x1, n2w, mean2, rstd2, dres=dx2, want_params=tw)
         dy1 = dx1 if gate1 is None else scale_rows(dx1, gate1, S)
-        dwproj, dbproj = wgrad(dy1, att)
+        if not grouped:
+            dwproj, dbproj = wgrad(dy1, att)
         datt = gemm(dy1, wproj, True, False)
         dqkv = attention_bwd(qkv, att, datt, lse, B, S, heads, hd)
-        dwqkv, dbqkv = wgrad(dqkv, n1, ctx.has_bqkv)
+        if grouped:
+            dwproj, dbproj, dwqkv, dbqkv = wgrad2((dy1, att), (dqkv, n1), ctx.has_bqkv)
+        else:
+            dwqkv, dbqkv = wgrad(dqkv, n1, ctx.has_bqkv)
         dn1 = gemm(dqkv, wqkv, True, False)
         dxin, dg1, dbt1 = layernorm_bwd(dn1, xin, n1w, mean1, rstd1, dres=dx1, want_params=tw)
         if par:

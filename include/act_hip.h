@@ -66,6 +66,12 @@ int act_rotate_points_f32(float* pc, const float* rot, int B, int N, act_stream_
 /* forward: xyz1 [B,n,3], xyz2 [B,m,3] -> dist1 [B,n], dist2 [B,m] (squared), idx1 int32 [B,n], idx2 int32 [B,m] */
 int act_chamfer_fwd_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
                         float* dist1, float* dist2, int32_t* idx1, int32_t* idx2, act_stream_t stream);
+/* same with the rounding of the distance selectable: fma_contract = 0 rounds every product and sum (act_chamfer_fwd_f32, the oracle
+ * convention); fma_contract = 1 evaluates chamfer.cu:43-57's x2*x2 + y2*y2 + z2*z2 as fma(z2, z2, fma(x2, x2, y2*y2)), the form an
+ * FMA-contracting build (nvcc's default) of the reference makes of it -- for comparing against outputs of a real CUDA build: distances agree
+ * to 2 ulps, the arg-min index may differ on (near) ties. */
+int act_chamfer_fwd_ex_f32(const float* xyz1, const float* xyz2, int B, int n, int m,
+                           float* dist1, float* dist2, int32_t* idx1, int32_t* idx2, int fma_contract, act_stream_t stream);
 /* backward: deterministic gather formulation of the reference's atomicAdd scatter */
 int act_chamfer_bwd_f32(const float* xyz1, const float* xyz2, const int32_t* idx1, const int32_t* idx2,
                         const float* grad_dist1, const float* grad_dist2, int B, int n, int m,
@@ -108,6 +114,25 @@ int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* 
 int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const act_gemm_epilogue_t* epilogue, float* workspace, size_t workspace_bytes,
                      int tile, int splits, act_stream_t stream);
+
+/* Several weight-gradient GEMMs of one module in ONE launch (csrc/gemm_grouped.hip): C_p[M_p,N_p] = A_p^T . B_p with A_p stored [K][M_p] (the
+ * output gradient dY of a Linear, lda >= M_p), B_p stored [K][N_p] (the Linear's input X), the same K (token rows) for every problem -- the
+ * dW = dY^T . X of models/act.py:25-69 for all Linears of a Transformer block -- plus, where bias_out != NULL, db_p[M_p] = column sums of A_p
+ * (the bias gradient), accumulated by the workgroups that stage A_p anyway.  M_p, N_p multiples of 128, K a multiple of 16, operands 16-byte
+ * aligned, at most 8 problems.  splits = number of K ranges (0: about two workgroups per CU, act_sgemm_tn_grouped_splits); for splits > 1 the
+ * partials go through `workspace` (act_sgemm_tn_grouped_workspace bytes) and ONE reduction launch folds them in ascending K order
+ * (deterministic).  With the same split factor C_p is bit-identical to act_sgemm_ex_f32(0, 0, ..., tile 13, splits). */
+typedef struct {
+    const float* A; int lda;
+    const float* B; int ldb;
+    float* C; int ldc;
+    int M, N;
+    float* bias_out;               /* [M] or NULL */
+} act_gemm_tn_problem_t;
+size_t act_sgemm_tn_grouped_workspace(const act_gemm_tn_problem_t* probs, int nprob, int K, int splits);
+int act_sgemm_tn_grouped_splits(const act_gemm_tn_problem_t* probs, int nprob, int K);
+int act_sgemm_tn_grouped_f32(const act_gemm_tn_problem_t* probs, int nprob, int K, int splits, float* workspace, size_t workspace_bytes,
+                             act_stream_t stream);
 
 /* GEMM with the producer / consumer passes of the mini-PointNet fused in (models/dvae.py:201-215: Conv1d -> BatchNorm1d -> ReLU -> Conv1d -> max):
  *  (1,1) forward conv:  a_scale/a_shift [K] (nullable, K <= 1024): A'[r,k] = max(0, A[r,k]*a_scale[k] + a_shift[k]) applied while A is staged --

@@ -89,11 +89,32 @@ def group_ref(xyz, num_group, group_size):
     return nb, center, fidx, kidx
 
 
-def chamfer_fwd_ref(xyz1, xyz2):
+def _chamfer_fwd_fma_c(xyz1, xyz2):
+    """the FMA-contracted distance needs a correctly rounded fused multiply-add, which numpy does not have: plain-C fmaf() of the C oracle"""
+    import ctypes
+    import os
+    import subprocess
+    d = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(d, "liboracle_point_ops.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(d, "point_ops_c.c")):
+        subprocess.check_call(["make", "-C", d, "-s"])
+    lib = ctypes.CDLL(so)
+    B, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    d1 = np.empty((B, n), F32); d2 = np.empty((B, m), F32); i1 = np.empty((B, n), np.int32); i2 = np.empty((B, m), np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.oracle_chamfer_fwd_fma_f32(P(xyz1), P(xyz2), B, n, m, P(d1), P(d2), P(i1), P(i2))
+    return d1, d2, i1, i2
+
+
+def chamfer_fwd_ref(xyz1, xyz2, fma_contract=False):
     """chamfer.forward (chamfer_cuda.cpp:12-23 / chamfer.cu:15-170):
-    -> dist1 [B,n], dist2 [B,m] (squared), idx1 int32 [B,n], idx2 int32 [B,m]."""
+    -> dist1 [B,n], dist2 [B,m] (squared), idx1 int32 [B,n], idx2 int32 [B,m].
+    fma_contract: the distance as an FMA-contracting build of chamfer.cu:43-57 rounds it, fma(z2, z2, fma(x2, x2, y2*y2))."""
     xyz1 = np.ascontiguousarray(xyz1, dtype=F32)
     xyz2 = np.ascontiguousarray(xyz2, dtype=F32)
+    if fma_contract:
+        return _chamfer_fwd_fma_c(xyz1, xyz2)
     d = _sqdist(xyz1[:, :, None, :], xyz2[:, None, :, :])           # [B,n,m]
     idx1 = np.argmin(d, axis=2).astype(np.int32)                     # first min == strict '<' scan
     idx2 = np.argmin(d, axis=1).astype(np.int32)

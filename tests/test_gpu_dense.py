@@ -796,3 +796,41 @@ def test_gemm_autotuner_times_and_registers_a_config(K):
         K.AUTOTUNE = saved
     t, s_ = ctypes.c_int(-1), ctypes.c_int(-1)
     assert K.lib.act_gemm_tune_get(1, 1, M, N, Kd, ctypes.byref(t), ctypes.byref(s_)) == 0 and (t.value, s_.value) == tuple(cfg)
+
+
+@pytest.mark.parametrize("T,dims,splits", [(1792, [(384, 1536), (1536, 384)], 0), (1792, [(384, 384), (1152, 384)], 0), (1792, [(384, 1536), (1536, 384), (384, 384), (1152, 384)], 4),
+                                           (8192, [(384, 384), (1152, 384)], 0), (256, [(128, 128)], 1), (3296, [(768, 3072), (3072, 768)], 0), (64, [(128, 256), (256, 128)], 0)])
+def test_grouped_weight_gradients_match_the_single_gemm_path(K, T, dims, splits):
+    """act_sgemm_tn_grouped_f32: the dW = dy^T . x of several Linears (+ their bias gradients) in one launch.  With the same K-range count the
+    product is BIT-IDENTICAL to the per-GEMM quad-fragment kernel (tile 13) -- same products, same order, same fixed-order fold of the K
+    ranges -- and within fp32 noise of a float64 reference; the bias gradient (another summation order than act_colsum_f32) is checked
+    against float64.  Operands are row-strided views (dqkv-style leading dimensions) for half of the problems."""
+    pairs, ref = [], []
+    for i, (M, N) in enumerate(dims):
+        dy_full = _rnd(f"gg.dy{T}{M}{N}{i}", T, M + 128 * (i % 2)).cuda(); x = _rnd(f"gg.x{T}{M}{N}{i}", T, N).cuda()
+        dy = dy_full[:, :M] if i % 2 else dy_full                       # a strided view: lda = M + 128
+        pairs.append((dy, x)); ref.append((dy.double().t() @ x.double(), dy.double().sum(0)))
+    dws, dbs = K.gemm_tn_grouped(pairs, splits=splits)
+    import ctypes
+    probs = (K.GemmTnProblem * len(dims))()
+    for i, ((dy, x), dw, db) in enumerate(zip(pairs, dws, dbs)):
+        probs[i] = K.GemmTnProblem(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dims[i][1], dims[i][0], dims[i][1], db.data_ptr())
+    used = splits if splits > 0 else K.lib.act_sgemm_tn_grouped_splits(probs, len(dims), T)
+    kps = -(-(-(-T // used)) // 32) * 32
+    used = -(-T // kps)                                                 # the K-range count after rounding the ranges to multiples of 32
+    for (dy, x), dw, db, (rw, rb) in zip(pairs, dws, dbs, ref):
+        assert _rel(dw, rw) <= 2e-5 and _rel(db, rb) <= 2e-5
+        single = K.gemm(dy, x, False, False, cfg=(13, used))
+        assert torch.equal(dw, single), (dy.shape, x.shape, used)
+    again, again_b = K.gemm_tn_grouped(pairs, splits=splits)            # deterministic
+    assert all(torch.equal(a, b) for a, b in zip(dws, again)) and all(torch.equal(a, b) for a, b in zip(dbs, again_b))
+    no_bias, none = K.gemm_tn_grouped(pairs, want_bias=False, splits=splits)
+    assert all(b is None for b in none) and all(torch.equal(a, b) for a, b in zip(dws, no_bias))
+
+
+def test_grouped_weight_gradients_reject_bad_shapes(K):
+    from act_amd._C import ActHipError
+    with pytest.raises(ActHipError):
+        K.gemm_tn_grouped([(torch.zeros(64, 100, device="cuda"), torch.zeros(64, 128, device="cuda"))])       # M % 128 != 0
+    with pytest.raises(ActHipError):
+        K.gemm_tn_grouped([(torch.zeros(64, 128, device="cuda"), torch.zeros(32, 128, device="cuda"))])       # different row counts

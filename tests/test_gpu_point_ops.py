@@ -156,6 +156,51 @@ def test_chamfer_fwd_bwd(dev, B, n, m):
     assert torch.equal(gx1, gx1b)
 
 
+def _near_tie_clouds(B, n, m, seed):
+    """query clouds + target clouds on a coarse lattice (coordinates k / 64): many exactly equal and last-bit-different distances"""
+    rs = np.random.RandomState(seed)
+    x = (rs.randint(-40, 41, (B, n, 3)) / 64.0).astype(np.float32) + (rs.randint(0, 3, (B, n, 3)) * 2.0 ** -22).astype(np.float32)
+    y = (rs.randint(-40, 41, (B, m, 3)) / 64.0).astype(np.float32) + (rs.randint(0, 3, (B, m, 3)) * 2.0 ** -22).astype(np.float32)
+    return x, y
+
+
+@pytest.mark.parametrize("B,n,m", [(64, 32, 32), (4, 64, 128), (2, 700, 1500)])
+def test_chamfer_fma_contract_mode(dev, B, n, m):
+    """fma_contract=True: the distance as an FMA-contracting build of chamfer.cu:43-57 rounds it.  Bit-exact against the plain-C fmaf()
+    restatement in both modes; the two modes agree to 2 ulps in the distances and differ ONLY there and in arg-min indices of points
+    whose two best candidates are within that distance (counted: the switch really changes something on near-tie clouds)."""
+    from act_amd.extensions.chamfer_dist import chamfer, ChamferDistanceL1
+    from oracle import point_ops as OP
+    x, y = _near_tie_clouds(B, n, m, 7 + n)
+    xt = torch.from_numpy(x).to(dev); yt = torch.from_numpy(y).to(dev)
+    plain = [t.cpu().numpy() for t in chamfer.forward(xt, yt, fma_contract=False)]
+    fused = [t.cpu().numpy() for t in chamfer.forward(xt, yt, fma_contract=True)]
+    for got, want in zip(plain, OP.chamfer_fwd_ref(x, y)):
+        assert np.array_equal(got, want)
+    for got, want in zip(fused, OP.chamfer_fwd_ref(x, y, fma_contract=True)):
+        assert np.array_equal(got, want)
+    changed = 0
+    for k in (0, 1):                                                     # distances: within two ulps of each other (5 roundings against 3)
+        a, b = plain[k], fused[k]
+        assert np.all(np.abs(a - b) <= 2 * np.spacing(np.maximum(a, b)))
+        changed += int((a != b).sum())
+    flips = int((plain[2] != fused[2]).sum() + (plain[3] != fused[3]).sum())
+    assert changed > 0 or n > 64                                         # the rounding differs somewhere on the small near-tie clouds (large clouds: nearest distances are mostly exact)
+    # every flipped index points at a candidate whose exactly rounded distance is within an ulp of the kept one
+    d = ((x[:, :, None, :].astype(np.float64) - y[:, None, :, :].astype(np.float64)) ** 2).sum(-1)
+    bi, ji = np.nonzero(plain[2] != fused[2])
+    for b_, j_ in zip(bi, ji):
+        da, db = d[b_, j_, plain[2][b_, j_]], d[b_, j_, fused[2][b_, j_]]
+        assert abs(da - db) <= 4.0 * np.spacing(np.float32(max(da, db)))
+    print(f"[chamfer fma_contract] {changed} distances and {flips} indices differ between the two roundings (B={B}, n={n}, m={m})")
+    # module argument and autograd path
+    l_plain = ChamferDistanceL1(fma_contract=False)(xt, yt); l_fused = ChamferDistanceL1(fma_contract=True)(xt, yt)
+    assert abs(l_plain.item() - l_fused.item()) <= 1e-6 * max(1.0, abs(l_plain.item()))
+    xg = xt.clone().requires_grad_(True)
+    ChamferDistanceL1(fma_contract=True)(xg, yt).backward()
+    assert torch.isfinite(xg.grad).all()
+
+
 def test_chamfer_modules_against_golden(dev):
     from act_amd.extensions.chamfer_dist import ChamferDistanceL1, ChamferDistanceL2, ChamferDistanceL2_split
     g = golden("g5_chamfer")

@@ -391,3 +391,34 @@ def test_g13_mask_ratio_zero_matches_reference():
     pd = dict(model.named_parameters())
     for n, v in zip(g["nomask_grad_names"], g["nomask_grad_norms"]):
         assert abs(pd[str(n)].grad.norm().item() - v) <= 1e-4 * max(1.0, v), n
+
+
+def test_chamfer_fma_contract_oracle_modes():
+    """the FMA-contracted restatement of chamfer.cu:43-57 (plain-C fmaf) against an exact evaluation: fma(z2, z2, fma(x2, x2, y2*y2)) with every
+    fused step rounded ONCE from the exact value (fractions), and its relation to the fully rounded convention (<= 2 ulps apart)."""
+    from fractions import Fraction
+    from oracle import point_ops as OP
+    rs = np.random.RandomState(3)
+    x = (rs.randint(-40, 41, (3, 6, 3)) / 64.0).astype(np.float32) + (rs.randint(0, 3, (3, 6, 3)) * 2.0 ** -22).astype(np.float32)
+    y = (rs.randint(-40, 41, (3, 9, 3)) / 64.0).astype(np.float32) + (rs.randint(0, 3, (3, 9, 3)) * 2.0 ** -22).astype(np.float32)
+
+    def rnd(fr):                                     # exact rational -> nearest float32, ties to even
+        c = np.float32(float(fr))
+        cands = [c, np.nextafter(c, np.float32(np.inf)), np.nextafter(c, np.float32(-np.inf))]
+        best = min(cands, key=lambda v: (abs(Fraction(float(v)) - fr), int(np.float32(v).view(np.uint32)) & 1))
+        return np.float32(best)
+
+    d1, d2, i1, i2 = OP.chamfer_fwd_ref(x, y, fma_contract=True)
+    p1 = OP.chamfer_fwd_ref(x, y)
+    for b in range(3):
+        for j in range(6):
+            best, bi = None, 0
+            for k in range(9):
+                dx, dy, dz = (np.float32(y[b, k, c] - x[b, j, c]) for c in range(3))
+                yy = np.float32(dy * dy)
+                inner = rnd(Fraction(float(dx)) * Fraction(float(dx)) + Fraction(float(yy)))
+                d = rnd(Fraction(float(dz)) * Fraction(float(dz)) + Fraction(float(inner)))
+                if best is None or d < best:
+                    best, bi = d, k
+            assert d1[b, j] == best and i1[b, j] == bi
+    assert np.all(np.abs(d1 - p1[0]) <= 2 * np.spacing(np.maximum(d1, p1[0]))) and np.all(np.abs(d2 - p1[1]) <= 2 * np.spacing(np.maximum(d2, p1[1])))
