@@ -458,6 +458,11 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
     static const int group_m_env = [] { const char* e = getenv("ACT_GEMM_GROUP_M"); return e ? atoi(e) : 8; }();
     p.group_m = group_m_env;
+    // XCD placement of the NT b128 kernels (experiment knob ACT_GEMM_XCD_ROWS = 1 | 2 | 4: r x 8/r grid of tile blocks; default 0 = row bands)
+    static const int xcd_rows_env = [] { const char* e = getenv("ACT_GEMM_XCD_ROWS"); return e ? atoi(e) : 0; }();
+    p.xcd_rows = 0;
+    if ((xcd_rows_env == 1 || xcd_rows_env == 2 || xcd_rows_env == 4) && p.tiles_m % xcd_rows_env == 0 && p.tiles_n % (8 / xcd_rows_env) == 0)
+        p.xcd_rows = xcd_rows_env;
     const long long nt = (long long)p.tiles_m * p.tiles_n;
     const int BKsel = gemm_bk();
     int kps = K;

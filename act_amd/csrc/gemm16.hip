@@ -170,9 +170,8 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int wg = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
     int tile_m, tile_n;
-    tile_coords(p, wg, tile_m, tile_n);
+    tile_of_workgroup(p, blockIdx.x, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = blockIdx.z * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);

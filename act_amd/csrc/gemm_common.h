@@ -30,6 +30,7 @@ struct GemmParams {
     act_gemm_epilogue_t epi;
     int tiles_m, tiles_n;
     int group_m;                     // tile rasterisation: GROUP_M tile rows are swept column by column (1 = plain row-major)
+    int xcd_rows;                    // 0: every XCD owns a contiguous band of the rasterised tile order; r (1, 2, 4): the 8 XCDs form an r x 8/r grid of tile blocks
 };
 
 // linear workgroup index (after the XCD remap) -> tile coordinates.  Grouped order: the tiles a (band of) CUs works on at the same
@@ -70,6 +71,24 @@ __device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, fl
 __device__ __forceinline__ int xcd_remap(int wg, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// workgroup -> tile with the XCD placement folded in.  Default (xcd_rows == 0): XCD x (= blockIdx.x % 8) owns the x-th eighth of the
+// rasterised tile order, i.e. a band of tile rows: it reads its A rows once and ALL of B.  xcd_rows = r: the XCDs form an r x (8 / r) grid of
+// tile blocks, XCD (i, j) owns tile rows [i * tm / r, ...) x tile columns [j * tn / (8 / r), ...): A is fetched 8 / r times, B r times --
+// less fabric traffic when B (the weight) is not much smaller than A.  Needs tiles_m % r == 0, tiles_n % (8 / r) == 0 (host-checked).
+__device__ __forceinline__ void tile_of_workgroup(const GemmParams& p, int bid, int& tile_m, int& tile_n) {
+    if (p.xcd_rows == 0) { tile_coords(p, xcd_remap(bid, p.tiles_m * p.tiles_n), tile_m, tile_n); return; }
+    const int xcd = bid & 7, loc = bid >> 3;
+    const int r = p.xcd_rows, c = 8 / r;
+    const int bm = p.tiles_m / r, bn = p.tiles_n / c;                   // tile block of one XCD
+    const int xi = xcd / c, xj = xcd - xi * c;
+    int lm, ln;                                                          // grouped rasterisation inside the block
+    const int gm = p.group_m > 1 ? p.group_m : 1;
+    const int per_group = gm * bn, grp = loc / per_group, first = grp * gm;
+    const int gsz = min(bm - first, gm), in_group = loc - grp * per_group;
+    lm = first + in_group % gsz; ln = in_group / gsz;
+    tile_m = xi * bm + lm; tile_n = xj * bn + ln;
 }
 
 // launcher of the 16x16x4-MFMA kernels (gemm16.hip); tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  FULL shapes only.

@@ -90,6 +90,7 @@ def side_stream(device, which=0):
 
 
 OVERLAP_DW = os.environ.get("ACT_OVERLAP_DW", "1") != "0"
+LINEAR_OVERLAP_DW = os.environ.get("ACT_LINEAR_OVERLAP_DW", "0") == "1"     # LinearFn.backward: dW / db on the auxiliary stream (measured per workload; see DESIGN)
 GROUPED_DW = os.environ.get("ACT_GROUPED_DW", "1") != "0"      # weight + bias gradients of two Linears per launch (0: one GEMM + column sum each)
 
 
@@ -372,9 +373,21 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         dy2 = _f32c(dy).reshape(-1, w.shape[0])
+        want_dw, want_db = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        # LINEAR_OVERLAP_DW (Stage-I autoencoder step, runner_autoencoder.train_step): dW / db on auxiliary stream 1 while the input gradient
+        # runs on the main stream -- two chip-filling GEMMs side by side fill each other's partial last round of workgroups; joined before
+        # returning (autograd accumulates the gradients on the main stream right away)
+        par = LINEAR_OVERLAP_DW and OVERLAP_DW and dy2.is_cuda and ctx.needs_input_grad[0] and (want_dw or want_db) and dy2.shape[0] >= 4096
+        if par:
+            with fork_side(dy2.device):
+                dw = gemm(dy2, x2, False, False) if want_dw else None
+                db = colsum(dy2) if want_db else None
+            dx = gemm(dy2, w, True, False).reshape(ctx.shp)
+            join_side(dy2.device, dw, db)
+            return dx, dw, db
         dx = gemm(dy2, w, True, False).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
-        dw = gemm(dy2, x2, False, False) if ctx.needs_input_grad[1] else None
-        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = gemm(dy2, x2, False, False) if want_dw else None
+        db = colsum(dy2) if want_db else None
         return dx, dw, db
 
 

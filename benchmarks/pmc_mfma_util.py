@@ -7,12 +7,7 @@
 """
 import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import importlib.util
-spec = importlib.util.spec_from_file_location("pt", os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_traffic.py"))
-src = open(spec.origin).read().split("CAL_KERNEL, CAL_BYTES")[0]          # reuse fold() without running the traffic main
-ns = {}
-exec(compile(src, spec.origin, "exec"), ns)
-fold = ns["fold"]
+from pmc_traffic import fold                     # kernel-name folding shared with the traffic script
 dur = {}
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):

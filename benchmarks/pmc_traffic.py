@@ -33,7 +33,7 @@ def fold(name):
     m = re.match(r"sgemm_q16_kernel<\d+, \d+, (true|false), (true|false)", n)
     if m:
         return "sgemm_nn" if m.group(1) == "true" else "sgemm_tn"
-    if n.startswith("sgemm_tn_skinny_kernel"):
+    if n.startswith("sgemm_tn_skinny_kernel") or n.startswith("sgemm_tn_grouped_kernel"):
         return "sgemm_tn"
     return re.sub(r"<.*", "", n)[:60]
 
@@ -49,27 +49,32 @@ def collect(d, counter):
     return {k: (v[0] / max(1, len(v[1])), len(v[1])) for k, v in tot.items()}
 
 
-# round 2: the BatchNorm apply is fused into the consuming GEMM, so the calibration kernel is the BatchNorm backward apply pass
-# (bn_bwd_apply_kernel: reads x and dy, writes dx, each [262144, C] fp32, C = 128 and 512 once per Stage-II step)
-# round 3: per-workload calibration bytes (argv[3] = c2 | s1 | c5): mean [rows, C] fp32 tensor size over the bn_bwd_apply launches of a step --
-# c2: mini-PointNet BN(128), BN(512) on 128*64*32 rows; s1: those two + the FoldingNet BN(512) x 2 on 128*64*32 rows; c5: 32*512*64 rows
-WORKLOAD = sys.argv[3] if len(sys.argv) > 3 else "c2"
-CAL_KERNEL = "bn_bwd_apply_kernel"
-CAL_BYTES = {"c2": 262144.0 * (128 + 512) / 2 * 4, "s1": 262144.0 * (128 + 512 + 512 + 512) / 4 * 4,
-             "c5": 1048576.0 * (128 + 512) / 2 * 4}[WORKLOAD]
-fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-kf = 2.0 * CAL_BYTES / (fetch[CAL_KERNEL][0] * 1024.0)
-kw = CAL_BYTES / (write[CAL_KERNEL][0] * 1024.0)
-out = {"workload": WORKLOAD, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
-                 "--no-cpu-baseline --no-instrument",
-       "units": "bytes per launch = counter [KiB] * 1024 * calibration factor",
-       "calibration": {"kernel": CAL_KERNEL, "known_bytes_written_per_launch": CAL_BYTES, "known_bytes_read_per_launch": 2.0 * CAL_BYTES,
-                       "fetch_factor": kf, "write_factor": kw,
-                       "cross_check": "colstats_stage1 (BatchNorm backward sums) reads x and dy = 2 x 262144 x (128 + 512) / 2 x 4 = 671,088,640 B per launch on average and writes (almost) nothing"},
-       "kernels": {}}
-for k in sorted(set(fetch) | set(write)):
-    fb = fetch.get(k, (0.0, 0))[0] * 1024.0 * kf
-    wb = write.get(k, (0.0, 0))[0] * 1024.0 * kw
-    out["kernels"][k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
-                         "launches_profiled": max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1])}
-print(json.dumps(out, indent=1, sort_keys=True))
+def main():
+    # round 2: the BatchNorm apply is fused into the consuming GEMM, so the calibration kernel is the BatchNorm backward apply pass
+    # (bn_bwd_apply_kernel: reads x and dy, writes dx, each [262144, C] fp32, C = 128 and 512 once per Stage-II step)
+    # round 3: per-workload calibration bytes (argv[3] = c2 | s1 | c5): mean [rows, C] fp32 tensor size over the bn_bwd_apply launches of a step --
+    # c2: mini-PointNet BN(128), BN(512) on 128*64*32 rows; s1: those two + the FoldingNet BN(512) x 2 on 128*64*32 rows; c5: 32*512*64 rows
+    WORKLOAD = sys.argv[3] if len(sys.argv) > 3 else "c2"
+    CAL_KERNEL = "bn_bwd_apply_kernel"
+    CAL_BYTES = {"c2": 262144.0 * (128 + 512) / 2 * 4, "s1": 262144.0 * (128 + 512 + 512 + 512) / 4 * 4,
+                 "c5": 1048576.0 * (128 + 512) / 2 * 4}[WORKLOAD]
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    kf = 2.0 * CAL_BYTES / (fetch[CAL_KERNEL][0] * 1024.0)
+    kw = CAL_BYTES / (write[CAL_KERNEL][0] * 1024.0)
+    out = {"workload": WORKLOAD, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
+                     "--no-cpu-baseline --no-instrument",
+           "units": "bytes per launch = counter [KiB] * 1024 * calibration factor",
+           "calibration": {"kernel": CAL_KERNEL, "known_bytes_written_per_launch": CAL_BYTES, "known_bytes_read_per_launch": 2.0 * CAL_BYTES,
+                           "fetch_factor": kf, "write_factor": kw,
+                           "cross_check": "colstats_stage1 (BatchNorm backward sums) reads x and dy = 2 x 262144 x (128 + 512) / 2 x 4 = 671,088,640 B per launch on average and writes (almost) nothing"},
+           "kernels": {}}
+    for k in sorted(set(fetch) | set(write)):
+        fb = fetch.get(k, (0.0, 0))[0] * 1024.0 * kf
+        wb = write.get(k, (0.0, 0))[0] * 1024.0 * kw
+        out["kernels"][k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
+                             "launches_profiled": max(fetch.get(k, (0, 0))[1], write.get(k, (0, 0))[1])}
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

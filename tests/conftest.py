@@ -3,11 +3,11 @@ import sys
 import numpy as np
 import pytest
 
-# Run-to-run determinism of the GPU suite: GEMM shapes outside the shipped table take the built-in cost model instead of the first-use
-# autotuner, whose pick depends on a few microseconds of timing (another kernel family = another fp32 summation order = other flipped
-# max / arg-min decisions in the ill-conditioned tiny graphs).  Explicit-configuration tests still exercise every kernel; the autotuner itself
-# is tested where a test switches it on (ACT_GEMM_AUTOTUNE=1 in the environment overrides this default).
-os.environ.setdefault("ACT_GEMM_AUTOTUNE", "0")
+# The GPU suite runs the PRODUCT default (ACT_GEMM_AUTOTUNE=1).  Run-to-run determinism does not come from switching the first-use autotuner
+# off but from the shipped table (act_amd/gemm_tune_gfx950.json), which lists every GEMM shape this suite and the benchmarked workloads launch
+# above the tuning threshold: a listed shape is never timed, so its launch configuration (= its fp32 summation order) is the same in every run
+# and every process.  pytest_sessionfinish below FAILS the session if a test still triggered a first-use tuning -- add the shape to the table
+# (ACT_GEMM_TUNE_SAVE=<file> dumps table + new winners at exit) instead of relying on a timing-dependent pick.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -17,6 +17,19 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """no GEMM shape of the suite may depend on a timing-based first-use pick (see the note at the top of this file)"""
+    K = sys.modules.get("act_amd.kernels")
+    if K is None or os.environ.get("ACT_GEMM_TUNE_SAVE") or os.environ.get("ACT_TESTS_ALLOW_TUNING") == "1":
+        return
+    new = getattr(K, "_NEW_TUNED", {})
+    if new and K.AUTOTUNE:
+        sys.stderr.write("\n[conftest] %d GEMM shape(s) were auto-tuned during this session (not in act_amd/gemm_tune_gfx950.json): %s\n"
+                         % (len(new), sorted(new)[:20]))
+        if exitstatus == 0:
+            session.exitstatus = 1
 
 
 def golden(name):

@@ -777,9 +777,9 @@ def test_gemm_split_k_with_uneven_splits(K, tile):
 
 
 def test_gemm_autotuner_times_and_registers_a_config(K):
-    """the first-use autotuner (off by default in this suite for run-to-run determinism, tests/conftest.py): gemm_tune times every candidate of
-    a shape, returns a valid (tile, split-K) pair whose product is correct, and _gemm_config publishes it to the C-side table that the
-    composite entry points read (act_gemm_tune_get)."""
+    """the first-use autotuner (every shape of this suite is in the shipped table, so it never runs by itself here: tests/conftest.py):
+    gemm_tune times every candidate of a shape, returns a valid (tile, split-K) pair whose product is correct, and _gemm_config publishes it
+    to the C-side table that the composite entry points read (act_gemm_tune_get)."""
     import ctypes
     M, N, Kd = 1024, 512, 1536
     a = _rnd("at.a", M, Kd).cuda(); b = _rnd("at.b", N, Kd).cuda()
@@ -796,6 +796,22 @@ def test_gemm_autotuner_times_and_registers_a_config(K):
         K.AUTOTUNE = saved
     t, s_ = ctypes.c_int(-1), ctypes.c_int(-1)
     assert K.lib.act_gemm_tune_get(1, 1, M, N, Kd, ctypes.byref(t), ctypes.byref(s_)) == 0 and (t.value, s_.value) == tuple(cfg)
+    assert K._NEW_TUNED.pop((1, 1, M, N, Kd), None) == tuple(cfg)       # (deliberate tuning: not a gap of the shipped table, see conftest.py)
+
+
+@pytest.mark.parametrize("ak,bk,M,N,Kd", [(1, 1, 1792, 384, 1536), (1, 1, 2080, 384, 768), (1, 0, 1792, 384, 1536), (1, 0, 2080, 1536, 384),
+                                          (0, 0, 384, 1536, 1792), (0, 0, 256, 128, 4000), (1, 1, 8192, 768, 3072), (1, 0, 8192, 2304, 768)])
+def test_every_autotuner_candidate_is_a_correct_kernel(K, ak, bk, M, N, Kd):
+    """every (tile id, split-K) pair gemm_tune can emit for a shape -- 32x32x2 and 16x16x4 loops, pipelined variants, NT b128 fragments, NN / TN
+    quad fragments, M tails (2,080 rows), uneven last K range (1,792 = 2 x 608 + 576) -- computes the product (float64 reference)."""
+    a = _rnd(f"cand.a{ak}{bk}{M}{Kd}", M if ak else Kd, Kd if ak else M).cuda(); b = _rnd(f"cand.b{ak}{bk}{N}{Kd}", N if bk else Kd, Kd if bk else N).cuda()
+    A2 = a.double().cpu() if ak else a.double().cpu().t(); B2 = b.double().cpu().t() if bk else b.double().cpu()
+    ref = A2 @ B2
+    tr = []
+    K.gemm_tune(a, b, bool(ak), bool(bk), M, N, Kd, K.workspace(a.device), reps=1, trace=tr)
+    assert len(tr) >= 4 and len({t for t, _, _ in tr}) >= 3, tr
+    for tile, sp, _ in tr:
+        assert _rel(K.gemm(a, b, bool(ak), bool(bk), cfg=(tile, sp)), ref) <= 2e-5, (tile, sp)
 
 
 @pytest.mark.parametrize("T,dims,splits", [(1792, [(384, 1536), (1536, 384)], 0), (1792, [(384, 384), (1152, 384)], 0), (1792, [(384, 1536), (1536, 384), (384, 384), (1152, 384)], 4),

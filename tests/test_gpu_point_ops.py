@@ -169,7 +169,7 @@ def test_chamfer_fma_contract_mode(dev, B, n, m):
     """fma_contract=True: the distance as an FMA-contracting build of chamfer.cu:43-57 rounds it.  Bit-exact against the plain-C fmaf()
     restatement in both modes; the two modes agree to 2 ulps in the distances and differ ONLY there and in arg-min indices of points
     whose two best candidates are within that distance (counted: the switch really changes something on near-tie clouds)."""
-    from act_amd.extensions.chamfer_dist import chamfer, ChamferDistanceL1
+    from act_amd.extensions.chamfer_dist import chamfer, ChamferDistanceL1, ChamferDistanceL2
     from oracle import point_ops as OP
     x, y = _near_tie_clouds(B, n, m, 7 + n)
     xt = torch.from_numpy(x).to(dev); yt = torch.from_numpy(y).to(dev)
@@ -196,9 +196,9 @@ def test_chamfer_fma_contract_mode(dev, B, n, m):
     # module argument and autograd path
     l_plain = ChamferDistanceL1(fma_contract=False)(xt, yt); l_fused = ChamferDistanceL1(fma_contract=True)(xt, yt)
     assert abs(l_plain.item() - l_fused.item()) <= 1e-6 * max(1.0, abs(l_plain.item()))
-    xg = xt.clone().requires_grad_(True)
-    ChamferDistanceL1(fma_contract=True)(xg, yt).backward()
-    assert torch.isfinite(xg.grad).all()
+    xg = xt.clone().requires_grad_(True)                                # (L2: the lattice clouds contain exact matches, where L1's sqrt has no gradient)
+    ChamferDistanceL2(fma_contract=True)(xg, yt).backward()
+    assert torch.isfinite(xg.grad).all() and xg.grad.abs().sum() > 0
 
 
 def test_chamfer_modules_against_golden(dev):
