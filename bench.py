@@ -48,7 +48,7 @@ def _time_steps(step, budget_s, max_n, min_n=2):
     return (time.time() - t0) / n, n
 
 
-def cpu_c1_reference(threads):
+def cpu_c1_reference(threads, warm=2, runs=7):
     """BASELINE configs[0] / BASELINE.md section 3 'C1': ONE batch of 4 x 1024 x 3 pc-normalised clouds -> Group (FPS 64, kNN 32) ->
     mini-PointNet Encoder(128) -> 2-layer d=128 Transformer encoder (2 heads x 64), forward, PyTorch CPU; median of 7 after 2 warm-ups."""
     from oracle import models as OM, layers as OL
@@ -60,18 +60,18 @@ def cpu_c1_reference(threads):
     pts = synthetic_clouds(4, 1024, 5, "cpu")
     t_all, t_grp = [], []
     with torch.no_grad():
-        for i in range(9):
+        for i in range(warm + runs):
             t0 = time.perf_counter()
             nb, center = grp(pts)
             t1 = time.perf_counter()
             blocks(enc(nb), pos(center), OL.Draws())
             t2 = time.perf_counter()
-            if i >= 2:
+            if i >= warm:
                 t_all.append(t2 - t0); t_grp.append(t1 - t0)
     med = sorted(t_all)[len(t_all) // 2]; medg = sorted(t_grp)[len(t_grp) // 2]
     return {"ms": 1e3 * med, "clouds_per_s": 4 / med, "group_Mpts_per_s": 4 * 1024 / medg / 1e6, "threads": threads, "runs": len(t_all),
             "sample": "configs[0]: 4 x 1024 x 3 clouds -> Group(FPS 64, kNN 32; numpy oracle) -> Encoder(128) -> 2-layer d=128 encoder, forward, "
-                      "median of 7 after 2 warm-ups"}
+                      f"median of {runs} after {warm} warm-up(s)"}
 
 
 def cpu_baseline(cfg_model, stage=2, c5=False, seconds_budget=22.0):
@@ -115,18 +115,19 @@ def cpu_baseline(cfg_model, stage=2, c5=False, seconds_budget=22.0):
     out = {"value": sweep[best]["clouds_per_s"], "unit": "clouds/s", "cores": best, "kind": "port",
            "sample": f"{sweep[best]['steps']} {what} of the pure-PyTorch CPU oracle at B={B}, N={N}, same geometry",
            "host_cores_visible": ncpu, "thread_sweep": {str(k): v for k, v in sweep.items()}}
-    if stage == 2 and not c5:
-        try:
-            out["c1_reference"] = cpu_c1_reference(few)
-            if ncpu != few:                            # BASELINE.md section 3 asks for os.cpu_count() threads: reported next to the faster setting
-                out["c1_reference_all_cores"] = cpu_c1_reference(ncpu)
-        except Exception as e:
-            out["c1_reference"] = {"failed": str(e)}
-    try:
+    torch.set_num_threads(few)
+    try:                                               # (before the all-cores run below: 256 spinning intra-op threads would starve OpenMP)
         G_, M_ = (512, 64) if c5 else (64, 32)
         out.update(cpu_group_baseline(B=32 if c5 else 128, N=N, G=G_, M=M_))
     except Exception as e:
         out["group_sample"] = f"failed: {e}"
+    if stage == 2 and not c5:
+        try:
+            out["c1_reference"] = cpu_c1_reference(few)
+            if ncpu != few:                            # BASELINE.md section 3 asks for os.cpu_count() threads: reported next to the faster setting
+                out["c1_reference_all_cores"] = cpu_c1_reference(ncpu, warm=1, runs=3)      # (6.7 s per pass on 256 oversubscribed threads)
+        except Exception as e:
+            out["c1_reference"] = {"failed": str(e)}
     torch.set_num_threads(few)
     return out
 
