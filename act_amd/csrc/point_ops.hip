@@ -256,12 +256,12 @@ __global__ __launch_bounds__(256) void knn_group_kernel(const float* __restrict_
 // a round rescans only the winner's group and folds the NG minima.  Only the winner lane is active in the refresh, so the statically unrolled
 // `if (g == gsel)` chain executes exactly one group body (the others are skipped by execz branches) and every register index stays static.
 // Selection order is unchanged: lowest distance, then lowest lane, then lowest index in the lane (strict '<' scanning upwards at both levels).
-template <int PPL>
+template <int PPL, int GS = 8>
 __global__ __launch_bounds__(256) void knn_group2_kernel(const float* __restrict__ ref, const float* __restrict__ query,
                                                          int B, int N, int Q, int K, int64_t* __restrict__ idx_out,
                                                          int idx_kq, float* __restrict__ nbr_out,
                                                          float* __restrict__ dist_out) {
-    constexpr int GS = 8, NG = PPL / GS;
+    constexpr int NG = PPL / GS;
     const int lane = threadIdx.x & 63;
     const long long qid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // b*Q + q
     if (qid >= (long long)B * Q) return;
@@ -269,32 +269,50 @@ __global__ __launch_bounds__(256) void knn_group2_kernel(const float* __restrict
     const float* __restrict__ r = ref + (size_t)b * N * 3;
     const float qx = query[qid * 3 + 0], qy = query[qid * 3 + 1], qz = query[qid * 3 + 2];
     const float INF = __int_as_float(0x7f800000);
-    const int base = lane * PPL;
+    // point layout: register element e of lane l is point  (e / 4) * 256 + 4 * l + (e % 4)  -- a lane owns 4 consecutive points (48 contiguous,
+    // 16-byte aligned bytes = three float4 loads) and the 64 lanes of one load instruction sweep 3 KB of the cloud front to back, instead of
+    // 64 private chunks 12 * PPL bytes apart (one cache line per lane and instruction: at 128 points per lane the fill, not the K selection
+    // rounds, was the larger half of the kernel).  Inside a lane ascending e is still ascending point index; ACROSS lanes it no longer is,
+    // so an exact distance tie between lanes is resolved by a second wave reduction on the point index (lowest index wins, as before).
+    const int base = 4 * lane;
+#define KNN_IDX(e) (((e) >> 2) * 256 + base + ((e) & 3))
 
     float d[PPL];
     float gmin[NG]; int gj[NG];                          // minimum of group g and its position inside the group
+    // fill: four points = three float4 loads
+    //   f0 = (x0 y0 z0 x1)  f1 = (y1 z1 x2 y2)  f2 = (z2 x3 y3 z3)
+    // and the six component pairs of two points sit in those registers exactly as packed fp32 wants them: three v_pk_add_f32 + three
+    // v_pk_mul_f32 give the six squared differences of a point pair (each half rounded like the scalar op), four scalar adds finish
+    // (dx*dx + dy*dy) + dz*dz per point -- 5 instead of 8 VALU issues and 0.75 instead of 3 load instructions a point, same bits as the oracle
+    static_assert(GS % 4 == 0, "groups of 4 or 8 points");
+    const f32x2 qxy = {qx, qy}, qzx = {qz, qx}, qyz = {qy, qz};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         float m = INF; int mj = 0;
 #pragma unroll
-        for (int i = 0; i < GS; i += 2) {
-            // two points per step, on the interleaved pairs (x0,y0) (z0,x1) (y1,z1) exactly as they sit in memory: three v_pk_add_f32 + three
-            // v_pk_mul_f32 give the six squared differences (each half rounded like the scalar op), four scalar adds finish
-            // (dx*dx + dy*dy) + dz*dz per point -- 5 instead of 8 VALU issues a point, same bits as the oracle
-            const int k = base + g * GS + i;
-            float v0 = INF, v1 = INF;
-            if (k + 1 < N) {
-                const float* __restrict__ pp = r + (size_t)k * 3;
-                const f32x2 a = f32x2{pp[0], pp[1]} - f32x2{qx, qy}, bq = f32x2{pp[2], pp[3]} - f32x2{qz, qx}, c = f32x2{pp[4], pp[5]} - f32x2{qy, qz};
-                const f32x2 a2 = a * a, b2 = bq * bq, c2 = c * c;
-                v0 = __fadd_rn(__fadd_rn(a2[0], a2[1]), b2[0]);
-                v1 = __fadd_rn(__fadd_rn(b2[1], c2[0]), c2[1]);
-            } else if (k < N) {
-                v0 = sqdist3(r[k * 3 + 0], r[k * 3 + 1], r[k * 3 + 2], qx, qy, qz);
+        for (int i = 0; i < GS; i += 4) {
+            const int k = KNN_IDX(g * GS + i);
+            float v[4] = {INF, INF, INF, INF};
+            if (k + 3 < N) {
+                const float4* __restrict__ pp = reinterpret_cast<const float4*>(r + (size_t)k * 3);
+                const float4 f0 = pp[0], f1 = pp[1], f2 = pp[2];
+                const f32x2 a = f32x2{f0.x, f0.y} - qxy, bq = f32x2{f0.z, f0.w} - qzx, c = f32x2{f1.x, f1.y} - qyz;
+                const f32x2 e = f32x2{f1.z, f1.w} - qxy, f = f32x2{f2.x, f2.y} - qzx, h = f32x2{f2.z, f2.w} - qyz;
+                const f32x2 a2 = a * a, b2 = bq * bq, c2 = c * c, e2 = e * e, f2s = f * f, h2 = h * h;
+                v[0] = __fadd_rn(__fadd_rn(a2[0], a2[1]), b2[0]);
+                v[1] = __fadd_rn(__fadd_rn(b2[1], c2[0]), c2[1]);
+                v[2] = __fadd_rn(__fadd_rn(e2[0], e2[1]), f2s[0]);
+                v[3] = __fadd_rn(__fadd_rn(f2s[1], h2[0]), h2[1]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k + u < N) v[u] = sqdist3(r[(k + u) * 3 + 0], r[(k + u) * 3 + 1], r[(k + u) * 3 + 2], qx, qy, qz);
             }
-            d[g * GS + i] = v0; d[g * GS + i + 1] = v1;
-            if (v0 < m) { m = v0; mj = i; }
-            if (v1 < m) { m = v1; mj = i + 1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                d[g * GS + i + u] = v[u];
+                if (v[u] < m) { m = v[u]; mj = i + u; }
+            }
         }
         gmin[g] = m; gj[g] = mj;
     }
@@ -304,11 +322,17 @@ __global__ __launch_bounds__(256) void knn_group2_kernel(const float* __restrict
     int my_idx = 0; float my_d = 0.f;
     for (int round = 0; round < K; ++round) {
         const float m = wave_min_f32(lmin, INF);
-        const int wl = first_lane(__ballot(lmin == m));
+        const unsigned long long tie = __ballot(lmin == m);
+        int wl = first_lane(tie);
         int lj = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g) if (g == lg) lj = g * GS + gj[g];
-        const int widx = __builtin_amdgcn_readlane(base + lj, wl);
+        const int lidx = KNN_IDX(lj);
+        int widx = __builtin_amdgcn_readlane(lidx, wl);
+        if (__builtin_popcountll(tie) > 1) {             // equal distances in several lanes (wave-uniform, rare): the lowest POINT INDEX wins
+            widx = -wave_max_i32((lmin == m) ? -lidx : (int)0x80000001, (int)0x80000001);
+            wl = first_lane(__ballot(lmin == m && lidx == widx));
+        }
         if (lane == round) { my_idx = widx; my_d = m; }
         if (lane == wl) {                                // retire the winner: rescan its group, fold the group minima
 #pragma unroll
@@ -342,6 +366,161 @@ __global__ __launch_bounds__(256) void knn_group2_kernel(const float* __restrict
         }
     }
 }
+
+#undef KNN_IDX
+
+// ---- the same selection with the lane's distances kept in a 4-ary TOURNAMENT TREE of registers --------------------------------------------
+// Retiring a winner in the two-level kernel above walks PPL / GS predicated group bodies, rescans one group and folds PPL / GS group minima:
+// a dependent chain of ~100 instructions per round at 128 points per lane, on 2 waves per SIMD -- latency, not throughput.  Here every node of
+// a fan-out-4 tree over the lane's points keeps (minimum, leaf offset of the minimum); retiring the current minimum descends ONE path
+// (4 predicated bodies per level), rescans 4 leaves and re-folds 4 children per level on the way back: 3 levels for 64 points, a top node
+// over 2 such trees for 128.  Same point layout, same selection order (strict '<' scanning upwards at every level; lane ties by point index).
+// (flat per-level register arrays with compile-time indices after unrolling: a struct-of-structs formulation of the same tree was left in
+// scratch memory by the compiler at 64 / 128 points per lane and ran 2x slower)
+// fill the 4 leaves d[0..3] of one level-1 node: the lane's 4 consecutive points starting at point k
+__device__ __forceinline__ void knn_fill4(float* __restrict__ d, int k, const float* __restrict__ r, int N, float qx, float qy, float qz) {
+    const float INF = __int_as_float(0x7f800000);
+    float v[4] = {INF, INF, INF, INF};
+    if (k + 3 < N) {
+        const float4* __restrict__ pp = reinterpret_cast<const float4*>(r + (size_t)k * 3);
+        const float4 f0 = pp[0], f1 = pp[1], f2 = pp[2];
+        const f32x2 qxy = {qx, qy}, qzx = {qz, qx}, qyz = {qy, qz};
+        const f32x2 a = f32x2{f0.x, f0.y} - qxy, bq = f32x2{f0.z, f0.w} - qzx, c = f32x2{f1.x, f1.y} - qyz;
+        const f32x2 e = f32x2{f1.z, f1.w} - qxy, f = f32x2{f2.x, f2.y} - qzx, h = f32x2{f2.z, f2.w} - qyz;
+        const f32x2 a2 = a * a, b2 = bq * bq, c2 = c * c, e2 = e * e, f2s = f * f, h2 = h * h;
+        v[0] = __fadd_rn(__fadd_rn(a2[0], a2[1]), b2[0]);
+        v[1] = __fadd_rn(__fadd_rn(b2[1], c2[0]), c2[1]);
+        v[2] = __fadd_rn(__fadd_rn(e2[0], e2[1]), f2s[0]);
+        v[3] = __fadd_rn(__fadd_rn(f2s[1], h2[0]), h2[1]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k + u < N) v[u] = sqdist3(r[(k + u) * 3 + 0], r[(k + u) * 3 + 1], r[(k + u) * 3 + 2], qx, qy, qz);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = v[u];
+}
+// (minimum, offset of the minimum) of CNT children whose own (min, offset) are cm[i], ca[i]; child i covers SPAN leaves
+#define KNN_FOLD(CNT, SPAN, cm, ca, out_m, out_a) do { float m__ = (cm)[0]; int a__ = (ca)[0]; \
+    _Pragma("unroll") for (int i__ = 1; i__ < (CNT); ++i__) if ((cm)[i__] < m__) { m__ = (cm)[i__]; a__ = i__ * (SPAN) + (ca)[i__]; } \
+    (out_m) = m__; (out_a) = a__; } while (0)
+
+template <int PPL>
+__global__ __launch_bounds__(256) void knn_tree_kernel(const float* __restrict__ ref, const float* __restrict__ query,
+                                                       int B, int N, int Q, int K, int64_t* __restrict__ idx_out,
+                                                       int idx_kq, float* __restrict__ nbr_out,
+                                                       float* __restrict__ dist_out) {
+    // levels: N1 nodes over 4 leaves; N2 nodes over 4 level-1 nodes (PPL >= 32); N3 nodes over 4 level-2 nodes (PPL = 128); the top folds
+    // the nodes of the highest level (2 or 4 of them)
+    constexpr int N1 = PPL / 4, N2 = PPL >= 32 ? PPL / 16 : 0, N3 = PPL >= 128 ? PPL / 64 : 0;
+    static_assert(PPL == 8 || PPL == 16 || PPL == 32 || PPL == 64 || PPL == 128, "points per lane");
+    const int lane = threadIdx.x & 63;
+    const long long qid = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);   // b*Q + q
+    if (qid >= (long long)B * Q) return;
+    const int b = (int)(qid / Q), q = (int)(qid % Q);
+    const float* __restrict__ r = ref + (size_t)b * N * 3;
+    const float qx = query[qid * 3 + 0], qy = query[qid * 3 + 1], qz = query[qid * 3 + 2];
+    const float INF = __int_as_float(0x7f800000);
+    const int base = 4 * lane;
+
+    float d[PPL];
+    float m1[N1]; int a1[N1];
+    float m2[N2 > 0 ? N2 : 1]; int a2[N2 > 0 ? N2 : 1];
+    float m3[N3 > 0 ? N3 : 1]; int a3[N3 > 0 ? N3 : 1];
+#pragma unroll
+    for (int n = 0; n < N1; ++n) {
+        knn_fill4(d + 4 * n, n * 256 + base, r, N, qx, qy, qz);
+        float lm = d[4 * n]; int la = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) if (d[4 * n + i] < lm) { lm = d[4 * n + i]; la = i; }
+        m1[n] = lm; a1[n] = la;
+    }
+    if constexpr (N2 > 0) {
+#pragma unroll
+        for (int n = 0; n < N2; ++n) KNN_FOLD(4, 4, m1 + 4 * n, a1 + 4 * n, m2[n], a2[n]);
+    }
+    if constexpr (N3 > 0) {
+#pragma unroll
+        for (int n = 0; n < N3; ++n) KNN_FOLD(4, 16, m2 + 4 * n, a2 + 4 * n, m3[n], a3[n]);
+    }
+    float lmin; int lat;                                                 // the lane's minimum and its register element
+    auto fold_top = [&]() {
+        if constexpr (N3 > 0)      KNN_FOLD(N3, 64, m3, a3, lmin, lat);
+        else if constexpr (N2 > 0) KNN_FOLD(N2, 16, m2, a2, lmin, lat);
+        else                       KNN_FOLD(N1, 4, m1, a1, lmin, lat);
+    };
+    fold_top();
+    int my_idx = 0; float my_d = 0.f;
+    for (int round = 0; round < K; ++round) {
+        const float m = wave_min_f32(lmin, INF);
+        const unsigned long long tie = __ballot(lmin == m);
+        int wl = first_lane(tie);
+        const int lidx = (lat >> 2) * 256 + base + (lat & 3);
+        int widx = __builtin_amdgcn_readlane(lidx, wl);
+        if (__builtin_popcountll(tie) > 1) {             // equal distances in several lanes (wave-uniform, rare): the lowest POINT INDEX wins
+            widx = -wave_max_i32((lmin == m) ? -lidx : (int)0x80000001, (int)0x80000001);
+            wl = first_lane(__ballot(lmin == m && lidx == widx));
+        }
+        if (lane == round) { my_idx = widx; my_d = m; }
+        if (lane == wl) {                                // retire leaf `lat`: one path down, 4 leaves rescanned, 4 children re-folded per level
+            const int leaf = lat & 3;
+            auto rescan = [&](int n) {                  // level-1 node n (a compile-time constant after unrolling): drop the leaf, new minimum of 4
+                float lm = INF; int la = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = (i == leaf) ? INF : d[4 * n + i];
+                    d[4 * n + i] = v;
+                    if (v < lm) { lm = v; la = i; }
+                }
+                m1[n] = lm; a1[n] = la;
+            };
+            if constexpr (N3 > 0) {                     // 128 points: 2 + 4 + 4 predicated bodies on the way down
+                const int w3 = lat >> 6, w2 = (lat >> 4) & 3, w1 = (lat >> 2) & 3;
+#pragma unroll
+                for (int n3 = 0; n3 < N3; ++n3) {
+                    if (n3 == w3) {
+#pragma unroll
+                        for (int c2 = 0; c2 < 4; ++c2) {
+                            if (c2 == w2) {
+#pragma unroll
+                                for (int c1 = 0; c1 < 4; ++c1) if (c1 == w1) rescan((n3 * 4 + c2) * 4 + c1);
+                                KNN_FOLD(4, 4, m1 + 4 * (n3 * 4 + c2), a1 + 4 * (n3 * 4 + c2), m2[n3 * 4 + c2], a2[n3 * 4 + c2]);
+                            }
+                        }
+                        KNN_FOLD(4, 16, m2 + 4 * n3, a2 + 4 * n3, m3[n3], a3[n3]);
+                    }
+                }
+            } else if constexpr (N2 > 0) {              // 32 / 64 points: N2 + 4 predicated bodies
+                const int w2 = lat >> 4, w1 = (lat >> 2) & 3;
+#pragma unroll
+                for (int n2 = 0; n2 < N2; ++n2) {
+                    if (n2 == w2) {
+#pragma unroll
+                        for (int c1 = 0; c1 < 4; ++c1) if (c1 == w1) rescan(n2 * 4 + c1);
+                        KNN_FOLD(4, 4, m1 + 4 * n2, a1 + 4 * n2, m2[n2], a2[n2]);
+                    }
+                }
+            } else {
+                const int w1 = lat >> 2;
+#pragma unroll
+                for (int n1 = 0; n1 < N1; ++n1) if (n1 == w1) rescan(n1);
+            }
+            fold_top();
+        }
+    }
+    if (lane < K) {
+        const size_t o = idx_kq ? ((size_t)b * K + lane) * Q + q : (size_t)qid * K + lane;
+        idx_out[o] = (int64_t)my_idx;
+        if (dist_out) dist_out[o] = sqrtf(my_d);
+        if (nbr_out) {
+            float* __restrict__ w = nbr_out + ((size_t)qid * K + lane) * 3;
+            w[0] = __fsub_rn(r[my_idx * 3 + 0], qx);
+            w[1] = __fsub_rn(r[my_idx * 3 + 1], qy);
+            w[2] = __fsub_rn(r[my_idx * 3 + 2], qz);
+        }
+    }
+}
+#undef KNN_FOLD
 
 // fallback for N > 8192: nothing is kept in registers; each of the K rounds rescans the lane's chunk for the
 // smallest (distance, index) pair lexicographically greater than the previous winner.
@@ -387,9 +566,30 @@ static int launch_knn(const float* ref, const float* query, int B, int N, int Q,
     const long long nq = (long long)B * Q;
     const int wpb = 4;
     static const bool two_level = [] { const char* e = getenv("ACT_KNN_TWO_LEVEL"); return !(e && e[0] == '0'); }();
+    static const int tree = [] { const char* e = getenv("ACT_KNN_TREE"); return e ? atoi(e) : 1; }();   // 1: tournament-tree kernel (PPL >= 8); 0: two-level kernel (A/B)
+    if constexpr (PPL >= 8) {
+        if (tree) {
+            hipLaunchKernelGGL(knn_tree_kernel<PPL>, dim3((unsigned)((nq + wpb - 1) / wpb)), dim3(wpb * 64), 0, s, ref, query,
+                               B, N, Q, K, idx, idx_kq, nbr, dist);
+            ACT_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if constexpr (PPL >= 64) {
         if (two_level) {
             hipLaunchKernelGGL(knn_group2_kernel<PPL>, dim3((unsigned)((nq + wpb - 1) / wpb)), dim3(wpb * 64), 0, s, ref, query,
+                               B, N, Q, K, idx, idx_kq, nbr, dist);
+            ACT_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    // 8 .. 32 points per lane (N = 512 .. 2,048): groups of 4 -- retiring a winner rescans 4 distances and folds PPL / 4 group minima instead of
+    // rescanning all PPL (the kernel is VALU-issue bound by exactly that rescan, executed by the whole wave for one active lane);
+    // ACT_KNN_TWO_LEVEL_SMALL=0 selects the one-level kernel (A/B)
+    static const bool two_level_small = [] { const char* e = getenv("ACT_KNN_TWO_LEVEL_SMALL"); return !(e && e[0] == '0'); }();
+    if constexpr (PPL >= 8 && PPL <= 32) {
+        if (two_level_small) {
+            hipLaunchKernelGGL((knn_group2_kernel<PPL, 4>), dim3((unsigned)((nq + wpb - 1) / wpb)), dim3(wpb * 64), 0, s, ref, query,
                                B, N, Q, K, idx, idx_kq, nbr, dist);
             ACT_LAUNCH_CHECK();
             return 0;
