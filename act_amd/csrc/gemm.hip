@@ -356,7 +356,7 @@ std::mutex g_tune_mu;
 std::unordered_map<TuneKey, std::pair<int, int>, TuneHash> g_tune;
 }  // namespace
 extern "C" int act_gemm_tune_set(int ak, int bk, int M, int N, int K, int tile, int splits) {
-    if (tile < 0 || tile > 18 || splits < 0) return ACT_E_BADARG;
+    if (tile < 0 || tile > 21 || splits < 0) return ACT_E_BADARG;
     std::lock_guard<std::mutex> g(g_tune_mu);
     g_tune[TuneKey{ak != 0, bk != 0, M, N, K}] = {tile, splits};
     return 0;
@@ -432,6 +432,10 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
             if (nb * sp >= 1024) break;
         }
     }
+    // tiles 20 (128x128), 21 (128x64): NT b128 kernels with 32-deep K tiles (full tiles, K per split % 32 == 0); bit-identical to 10 / 11
+    const bool nt32 = tile == 20 || tile == 21;
+    const int nt32_tile = tile - 20;
+    if (nt32) { if (!(a_kmajor && b_kmajor)) return ACT_E_BADARG; tile = tile == 20 ? 1 : 2; }
     // tiles 17 (128x128), 18 (128x64): NT b128 kernels with the software-pipelined main loop (full tiles, K per split % 32 == 0)
     const bool nt16p = tile == 17 || tile == 18;
     const int nt16p_tile = tile == 17 ? 3 : 4;
@@ -475,7 +479,10 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     const bool full = vec && (M % BM == 0) && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
     // 16x16x4 kernels also take an M tail when A is K-major (rows = tokens): rows clamped on load, guarded on store
     const bool full_mtail = vec && a_kmajor && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
-    if (nt16p) {
+    if (nt32) {
+        if (!full) return ACT_E_BADARG;
+        launch_sgemm_nt32(p, nt32_tile, grid, s);
+    } else if (nt16p) {
         if (!full) return ACT_E_BADARG;
         launch_sgemm_nt16(p, nt16p_tile, grid, s);
     } else if (q16) {

@@ -647,6 +647,133 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// NT kernel with 32-deep K tiles (round 3).  benchmarks/micro/load_path.hip: the L2 -> CU operand stream runs at 8.4 TB/s when a tile row
+// contributes 64 B per K step (BK = 16 fp32: half a cache line per row and instruction) and at 15 TB/s with 128-B rows; on the 128 x 64 tiles
+// the teacher's wide GEMMs use, three co-resident workgroups ask for 36 KB per round of 3,072 matrix-pipe cycles = 88 % of the BK = 16 rate.
+// Here a staging instruction reads 8 full 128-byte rows (thread = row tid>>3, chunk tid&7), the LDS image is two [row][16 k] halves with the
+// swizzle of sgemm_nt16_kernel, and one barrier covers 8 MFMA k-steps.  Same products in the same order as the BK = 16 kernel: bit-identical.
+// Full tiles only (M % BM == N % BN == 0, K range % 32 == 0).
+template <int BM, int BN>
+__global__ __launch_bounds__(256, BM * BN <= 128 * 64 ? 3 : 2) void sgemm_nt32_kernel(const GemmParams p) {
+    constexpr int BK = 32;
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int NA = BM / 32, NB = BN / 32;                            // staging passes of 32 rows
+    static_assert(NA == 4 && (NB == 2 || NB == 4), "128 x 128 and 128 x 64");
+    __shared__ __attribute__((aligned(16))) float As[2][2 * BM * 16];
+    __shared__ __attribute__((aligned(16))) float Bs[2][2 * BN * 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    tile_of_workgroup(p, blockIdx.x, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int ntiles = (kend - kbeg) / BK;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int srow = tid >> 3, sch = tid & 7;
+    const float* ga = p.A + (size_t)(m0 + srow) * p.lda + kbeg + sch * 4;
+    const float* gb = p.B + (size_t)(n0 + srow) * p.ldb + kbeg + sch * 4;
+    const size_t pa = (size_t)32 * p.lda, pb = (size_t)32 * p.ldb;
+    const int s_off_a = (sch >> 2) * (BM * 16) + srow * 16 + 4 * ((sch & 3) ^ ((4 - ((srow >> 2) & 3)) & 3));
+    const int s_off_b = (sch >> 2) * (BN * 16) + srow * 16 + 4 * ((sch & 3) ^ ((4 - ((srow >> 2) & 3)) & 3));
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_g = [&](int t) {
+        ra0 = *reinterpret_cast<const float4*>(ga + t * BK);
+        ra1 = *reinterpret_cast<const float4*>(ga + pa + t * BK);
+        ra2 = *reinterpret_cast<const float4*>(ga + 2 * pa + t * BK);
+        ra3 = *reinterpret_cast<const float4*>(ga + 3 * pa + t * BK);
+        rb0 = *reinterpret_cast<const float4*>(gb + t * BK);
+        rb1 = *reinterpret_cast<const float4*>(gb + pb + t * BK);
+        if constexpr (NB > 2) {
+            rb2 = *reinterpret_cast<const float4*>(gb + 2 * pb + t * BK);
+            rb3 = *reinterpret_cast<const float4*>(gb + 3 * pb + t * BK);
+        }
+    };
+    auto store_lds = [&](int buf) {
+        *reinterpret_cast<float4*>(&As[buf][s_off_a]) = ra0;
+        *reinterpret_cast<float4*>(&As[buf][s_off_a + 512]) = ra1;
+        *reinterpret_cast<float4*>(&As[buf][s_off_a + 1024]) = ra2;
+        *reinterpret_cast<float4*>(&As[buf][s_off_a + 1536]) = ra3;
+        *reinterpret_cast<float4*>(&Bs[buf][s_off_b]) = rb0;
+        *reinterpret_cast<float4*>(&Bs[buf][s_off_b + 512]) = rb1;
+        if constexpr (NB > 2) {
+            *reinterpret_cast<float4*>(&Bs[buf][s_off_b + 1024]) = rb2;
+            *reinterpret_cast<float4*>(&Bs[buf][s_off_b + 1536]) = rb3;
+        }
+    };
+    if (ntiles > 0) { load_g(0); store_lds(0); __syncthreads(); }
+    const int kl = lane >> 4, ml = lane & 15;
+    const int hsw = (4 - ((ml >> 2) & 3)) & 3;
+    const int a_off = (wm * (BM / 2) + ml) * 16 + 4 * (kl ^ hsw);
+    const int b_off = (wn * (BN / 2) + ml) * 16 + 4 * (kl ^ hsw);
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[buf][half * (BM * 16) + a_off + i * 256]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][half * (BN * 16) + b_off + j * 256]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        load_g(t + 1);
+        compute(t & 1);
+        store_lds((t & 1) ^ 1);
+        __syncthreads();
+    }
+    if (ntiles > 0) compute((ntiles - 1) & 1);
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 16 + ml;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 16 + kl * 4 + r;
+                float v = acc[i][j][r];
+                if (p.partial) {
+                    p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v = epilogue_apply(p.epi, v, row, col);
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.epi.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+void launch_sgemm_nt32(const GemmParams& p, int tile, dim3 grid, hipStream_t s) {
+    if (tile == 0) hipLaunchKernelGGL((sgemm_nt32_kernel<128, 128>), grid, dim3(256), 0, s, p);
+    else           hipLaunchKernelGGL((sgemm_nt32_kernel<128, 64>), grid, dim3(256), 0, s, p);
+}
+
 // tile: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 128x64 (1..3 NN only: A K-contiguous; 2, 3: 4 x 1 waves).  false: no such kernel.
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s) {
     if (a_kmajor && b_kmajor) return false;

@@ -95,6 +95,8 @@ __device__ __forceinline__ void tile_of_workgroup(const GemmParams& p, int bid, 
 void launch_sgemm16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
 // NT-only kernels with K-contiguous swizzled LDS image and ds_read_b128 operand fetch (gemm16.hip)
 void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s);
+// NT kernels with 32-deep K tiles (gemm16.hip): tile 0 = 128x128, 1 = 128x64; full tiles only
+void launch_sgemm_nt32(const GemmParams& p, int tile, dim3 grid, hipStream_t s);
 // quad-fragment kernels for the NN / TN layouts (gemm16.hip): tile 0 = 128x128, 1 = 64x128 (NN only); false = no such kernel
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
 // NT kernels with fused producer / consumer passes (gemm16.hip); fx_mask = FX_* bits; tile 0 = 128x128, 1 = 128x64.  false = no such kernel

@@ -109,7 +109,7 @@ int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* 
  * software-pipelined (3-stage LDS, mid-tile barrier) main loop, 7..9 = the same tiles on v_mfma_f32_16x16x4_f32,
  * 10..12 = NT-only kernels with ds_read_b128 operand fragments (aligned shapes only), 13 = 128x128 / 14 = 64x128 / 15 = 64x64 / 16 = 128x64
  * quad-fragment kernels of the NN (a_kmajor=1, b_kmajor=0) and TN (0,0; 13 only) layouts (17 = 128x128 / 18 = 128x64: NT with the software-pipelined
- * main loop, full tiles only, bit-identical to 10 / 11): ds_read_b128 along the row-contiguous operand, no transpose (0: built-in cost model), splits >= 1 = split-K factor.  Used by the host-side autotuner (act_amd/kernels.py), results are identical up to
+ * main loop, full tiles only, bit-identical to 10 / 11; 20 = 128x128 / 21 = 128x64: NT with 32-deep K tiles, full tiles only, bit-identical to 10 / 11): ds_read_b128 along the row-contiguous operand, no transpose (0: built-in cost model), splits >= 1 = split-K factor.  Used by the host-side autotuner (act_amd/kernels.py), results are identical up to
  * the fp32 summation order of split-K. */
 int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                      float* C, int ldc, const act_gemm_epilogue_t* epilogue, float* workspace, size_t workspace_bytes,

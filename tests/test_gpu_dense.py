@@ -785,7 +785,7 @@ def test_gemm_autotuner_times_and_registers_a_config(K):
     a = _rnd("at.a", M, Kd).cuda(); b = _rnd("at.b", N, Kd).cuda()
     ws = K.workspace(a.device)
     (tile, sp), ms = K.gemm_tune(a, b, True, True, M, N, Kd, ws)
-    assert 1 <= tile <= 18 and sp >= 1 and 0 < ms < 10
+    assert 1 <= tile <= 21 and sp >= 1 and 0 < ms < 10
     assert _rel(K.gemm(a, b, True, True, cfg=(tile, sp)), a.double().cpu() @ b.double().cpu().t()) <= 2e-5
     saved = K.AUTOTUNE
     K.AUTOTUNE = True
@@ -850,3 +850,14 @@ def test_grouped_weight_gradients_reject_bad_shapes(K):
         K.gemm_tn_grouped([(torch.zeros(64, 100, device="cuda"), torch.zeros(64, 128, device="cuda"))])       # M % 128 != 0
     with pytest.raises(ActHipError):
         K.gemm_tn_grouped([(torch.zeros(64, 128, device="cuda"), torch.zeros(32, 128, device="cuda"))])       # different row counts
+
+
+@pytest.mark.parametrize("M,N,Kd,sp", [(1024, 512, 768, 1), (8192, 768, 3072, 2), (256, 128, 96, 1), (512, 192, 4000, 3)])
+def test_nt_kernel_with_32_deep_k_tiles_is_bit_identical(K, M, N, Kd, sp):
+    """tiles 20 / 21 (NT, 32-deep K tiles: full 128-byte rows per staging load) execute the products of tiles 10 / 11 in the same order"""
+    a = _rnd(f"nt32.a{M}{Kd}", M, Kd).cuda(); b = _rnd(f"nt32.b{N}{Kd}", N, Kd).cuda()
+    bias = _rnd(f"nt32.bias{N}", N).cuda()
+    for t32, t16 in ((20, 10), (21, 11)):
+        if N % (128 if t32 == 20 else 64):
+            continue
+        assert torch.equal(K.gemm(a, b, True, True, bias=bias, cfg=(t32, sp)), K.gemm(a, b, True, True, bias=bias, cfg=(t16, sp))), (t32, sp)
