@@ -1104,8 +1104,14 @@ static int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t s) {
     // 64-key chunks with the online softmax halve the footprint (teacher prompt-prefix shape 64 q x 128 k: 139 -> 70 KB, 70 -> 57 us).
     const int pairs = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
     if (JT == 4 && QT <= 2 && (size_t)pairs * 2 * JT * 32 * (HD + 4) * sizeof(float) > 80 * 1024) JT = 2;
+    // round 3: from 128 keys on, ONE 32-key tile per LDS chunk -- 35 KB instead of 70 KB per workgroup = four instead of two workgroups per CU, whose
+    // staging / softmax / MFMA phases then overlap (Stage-I prefix shape 56.9 -> 51.8 us, S = 128 83 -> 76 us, stress teacher 64 + 512 320 -> 283 us;
+    // shorter sequences keep the single chunk: 64 keys 20.6 vs 21.9 us).  ACT_ATTN_JT = 1..4 forces a chunk size (A/B)
+    static const int jt_env = [] { const char* e = getenv("ACT_ATTN_JT"); return e ? atoi(e) : 0; }();
+    if (jt_env >= 1 && jt_env <= 4) { if (jt_env < JT && Sk > jt_env * 32) JT = jt_env; }
+    else if (Sk >= 128) JT = 1;
 #define C3(J, Q) if (JT == J && QT == Q) return launch_attn_fwd3<HD, J, Q>(a, s)
-    C3(1, 1); C3(2, 1); C3(2, 2); C3(3, 1); C3(3, 2); C3(3, 3); C3(4, 1); C3(4, 2); C3(4, 3); C3(4, 4);
+    C3(1, 1); C3(1, 2); C3(1, 3); C3(1, 4); C3(2, 1); C3(2, 2); C3(2, 3); C3(2, 4); C3(3, 1); C3(3, 2); C3(3, 3); C3(3, 4); C3(4, 1); C3(4, 2); C3(4, 3); C3(4, 4);
 #undef C3
     return ACT_E_BADARG;
 }
