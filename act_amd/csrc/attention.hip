@@ -780,25 +780,40 @@ __device__ __forceinline__ void att_load_row_form(const AttSeg g, int row, int h
 }
 template <int HD>
 __device__ __forceinline__ void att_load_col_form(const AttSeg g, int c, int half, float (*x)[HD / 32]) {
-    const unsigned lane_off = (unsigned)(4 * half * g.ld + c);           // per-lane part; the row part below is wave-uniform
+    // The m index of the products that consume a col form (the head dimension d of O^t, dQ^t, dK^t, dV^t) is free to be any permutation as long as
+    // the store agrees: lane c holds d = (HD/32) * c + dt, so its HD/32 values per row are CONTIGUOUS -- one dwordx2 load per row and lane pair of
+    // accumulators instead of two dword loads 128 bytes apart (global-load instructions per tile are what these kernels are short of).
+    constexpr int NDT = HD / 32;
+    const unsigned lane_off = (unsigned)(4 * half * g.ld + NDT * c);     // per-lane part; the row part below is wave-uniform
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float* rb = g.base + (size_t)ATT_F(r, 0) * g.ld;
-#pragma unroll
-        for (int dt = 0; dt < HD / 32; ++dt) x[r][dt] = rb[lane_off + dt * 32];
+        if constexpr (NDT == 2) {
+            const float2 v = *reinterpret_cast<const float2*>(rb + lane_off);
+            x[r][0] = v.x; x[r][1] = v.y;
+        } else {
+            x[r][0] = rb[lane_off];
+        }
     }
 }
-// store an accumulator pair in the o-layout (acc[dt][r] = X^t[d = dt*32 + f(r, half)][row = lane&31]) as row-major X[row][d], scaled
+// store an accumulator set in the o-layout (acc[dt][r] = X^t[d = (HD/32) * f(r, half) + dt][row = lane&31]) as row-major X[row][d], scaled
 template <int HD>
 __device__ __forceinline__ void att_store_o(float* __restrict__ rowp, int half, const f32x16* acc, float mul) {
+    constexpr int NDT = HD / 32;
 #pragma unroll
-    for (int dt = 0; dt < HD / 32; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 4; ++g) {                                        // registers 4g .. 4g+3 = rows m = 8g + 4 half + (0..3) -> NDT * 4 consecutive d
+        if constexpr (NDT == 2) {
+            float4 t0, t1;
+            t0.x = acc[0][g * 4 + 0] * mul; t0.y = acc[1][g * 4 + 0] * mul; t0.z = acc[0][g * 4 + 1] * mul; t0.w = acc[1][g * 4 + 1] * mul;
+            t1.x = acc[0][g * 4 + 2] * mul; t1.y = acc[1][g * 4 + 2] * mul; t1.z = acc[0][g * 4 + 3] * mul; t1.w = acc[1][g * 4 + 3] * mul;
+            *reinterpret_cast<float4*>(rowp + 16 * g + 8 * half) = t0;
+            *reinterpret_cast<float4*>(rowp + 16 * g + 8 * half + 4) = t1;
+        } else {
             float4 t;
-            t.x = acc[dt][g * 4 + 0] * mul; t.y = acc[dt][g * 4 + 1] * mul; t.z = acc[dt][g * 4 + 2] * mul; t.w = acc[dt][g * 4 + 3] * mul;
-            *reinterpret_cast<float4*>(rowp + dt * 32 + 8 * g + 4 * half) = t;
+            t.x = acc[0][g * 4 + 0] * mul; t.y = acc[0][g * 4 + 1] * mul; t.z = acc[0][g * 4 + 2] * mul; t.w = acc[0][g * 4 + 3] * mul;
+            *reinterpret_cast<float4*>(rowp + 8 * g + 4 * half) = t;
         }
+    }
 }
 // (wave-uniform work-item decomposition; 32-bit divisions expand to VALU code, so the results are pinned back into SGPRs)
 __device__ __forceinline__ void att_item(unsigned item, int ntiles, int H, int& tile, int& b, int& h) {
