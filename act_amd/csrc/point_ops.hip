@@ -86,13 +86,28 @@ __global__ __launch_bounds__(WAVES * 64) void fps_kernel(const float* __restrict
             const int par = it & 1;
             if (lane == 0) { s_vali[par * WAVES + wave] = wmax; s_idx[par * WAVES + wave] = widx; }
             __syncthreads();
-            int gv = s_vali[par * WAVES]; int gi = s_idx[par * WAVES];
+            if constexpr (WAVES >= 8) {
+                // 8 / 16 candidates: lane w of every wave takes wave w's (value, index) and the maximum is a 4-step DPP row reduction + ballot
+                // (lowest lane = lowest wave = lowest index on ties) instead of a dependent scan of WAVES LDS entries by every lane
+                const int v = lane < WAVES ? s_vali[par * WAVES + lane] : (int)0x80000000;
+                const int id = lane < WAVES ? s_idx[par * WAVES + lane] : 0;
+                int mx = v;
+                mx = max(mx, dpp_mov_i<0x111, 0xf>((int)0x80000000, mx));
+                mx = max(mx, dpp_mov_i<0x112, 0xf>((int)0x80000000, mx));
+                mx = max(mx, dpp_mov_i<0x114, 0xf>((int)0x80000000, mx));
+                mx = max(mx, dpp_mov_i<0x118, 0xf>((int)0x80000000, mx));
+                const int gmax = __builtin_amdgcn_readlane(mx, 15);
+                const int gl = first_lane(__ballot(v == gmax && lane < WAVES));
+                widx = __builtin_amdgcn_readlane(id, gl);
+            } else {
+                int gv = s_vali[par * WAVES]; int gi = s_idx[par * WAVES];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) {
-                const int v = s_vali[par * WAVES + w];
-                if (v > gv) { gv = v; gi = s_idx[par * WAVES + w]; }
+                for (int w = 1; w < WAVES; ++w) {
+                    const int v = s_vali[par * WAVES + w];
+                    if (v > gv) { gv = v; gi = s_idx[par * WAVES + w]; }
+                }
+                widx = gi;
             }
-            widx = gi;
         }
         old = widx;
         if (lds_cloud) { cx = s_xyz[old * 3 + 0]; cy = s_xyz[old * 3 + 1]; cz = s_xyz[old * 3 + 2]; }
@@ -180,7 +195,9 @@ extern "C" int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_o
     ActProfScope ps(KID_FPS, s, 0.0, (double)B * (12.0 * N + 4.0 * G + (centers_out ? 12.0 * G : 0.0)));
     { const char* e = getenv("ACT_FPS_CFG");          // tuning knob for N <= 1024: 1 = one wave x 16 points/lane, 2 = two waves x 8
       if (e && N <= 1024 && N > 256) { if (atoi(e) == 1) return launch_fps<1, 16>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
-                                       if (atoi(e) == 2) return launch_fps<2, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s); } }
+                                       if (atoi(e) == 2) return launch_fps<2, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+                                       if (atoi(e) == 3) return launch_fps<8, 2>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
+                                       if (atoi(e) == 4) return launch_fps<16, 1>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s); } }
     if (N <= 256)   return launch_fps<1, 4>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
     if (N <= 1024)  return launch_fps<4, 4>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
     if (N <= 2048)  return launch_fps<4, 8>(xyz, B, N, G, idx_out, centers_out, skip_near_origin, s);
