@@ -108,19 +108,44 @@ __global__ __launch_bounds__(256) void gumbel_argmax_gather_kernel(const float* 
     const int row = blockIdx.x, b = row / G;
     const int cpg = C / groups;
     float best = -3.0e38f; int bi = 0;
-    for (int c4 = threadIdx.x * 4; c4 < C; c4 += 1024) {
-        const float4 x = *reinterpret_cast<const float4*>(h + (size_t)row * C + c4);
-        const float xs[4] = {x.x, x.y, x.z, x.w};
-        uint32_t rnd[4] = {0, 0, 0, 0};
-        if (!noise) philox4x32_10((uint32_t)(c4 >> 2), (uint32_t)row, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+    // group by group (the statistics are wave-uniform scalars, no per-element division), float4 for h / gamma / beta / noise / logits
+    // (cpg % 4 == 0: a float4 never straddles two groups); same arithmetic per element as before
+    if (cpg & 3) {                                       // (channel groups that are not a multiple of 4 wide: element-wise group lookup)
+        for (int c4 = threadIdx.x * 4; c4 < C; c4 += 1024) {
+            const float4 x = *reinterpret_cast<const float4*>(h + (size_t)row * C + c4);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+            uint32_t rnd[4] = {0, 0, 0, 0};
+            if (!noise) philox4x32_10((uint32_t)(c4 >> 2), (uint32_t)row, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = c4 + u, gi = c / cpg;
-            const float v = lrelu((xs[u] - mean[b * groups + gi]) * rstd[b * groups + gi] * gamma[c] + beta[c], slope);
-            if (logits_out) logits_out[(size_t)row * C + c] = v;
-            const float gnoise = noise ? noise[(size_t)row * C + c] : gumbel_from_bits(rnd[u]);
-            const float y = (v + gnoise) * inv_tau;
-            if (y > best) { best = y; bi = c; }         // ascending c inside a thread: first maximum wins
+            for (int u = 0; u < 4; ++u) {
+                const int c = c4 + u, gi = c / cpg;
+                const float v = lrelu((xs[u] - mean[b * groups + gi]) * rstd[b * groups + gi] * gamma[c] + beta[c], slope);
+                if (logits_out) logits_out[(size_t)row * C + c] = v;
+                const float gnoise = noise ? noise[(size_t)row * C + c] : gumbel_from_bits(rnd[u]);
+                const float y = (v + gnoise) * inv_tau;
+                if (y > best) { best = y; bi = c; }
+            }
+        }
+    } else
+    for (int gi = 0; gi < groups; ++gi) {
+        const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi];
+        for (int c4 = gi * cpg + threadIdx.x * 4; c4 < (gi + 1) * cpg; c4 += 1024) {
+            const float4 x = *reinterpret_cast<const float4*>(h + (size_t)row * C + c4);
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c4), be = *reinterpret_cast<const float4*>(beta + c4);
+            const float xs[4] = {x.x, x.y, x.z, x.w}, gs[4] = {ga.x, ga.y, ga.z, ga.w}, bs[4] = {be.x, be.y, be.z, be.w};
+            uint32_t rnd[4] = {0, 0, 0, 0};
+            float ns[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!noise) philox4x32_10((uint32_t)(c4 >> 2), (uint32_t)row, 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), rnd);
+            else { const float4 nz = *reinterpret_cast<const float4*>(noise + (size_t)row * C + c4); ns[0] = nz.x; ns[1] = nz.y; ns[2] = nz.z; ns[3] = nz.w; }
+            float vs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                vs[u] = lrelu((xs[u] - mu) * rs * gs[u] + bs[u], slope);
+                const float gnoise = noise ? ns[u] : gumbel_from_bits(rnd[u]);
+                const float y = (vs[u] + gnoise) * inv_tau;
+                if (y > best) { best = y; bi = c4 + u; }    // ascending c inside a thread: first maximum wins
+            }
+            if (logits_out) *reinterpret_cast<float4*>(logits_out + (size_t)row * C + c4) = make_float4(vs[0], vs[1], vs[2], vs[3]);
         }
     }
     // block arg-max with lowest-index tie-break (torch.argmax returns the first maximum)
