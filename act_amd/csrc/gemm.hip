@@ -586,7 +586,7 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         p.tiles_m = M / 128; p.tiles_n = N / 128;
         const long long nt = (long long)p.tiles_m * p.tiles_n;
         int splits = (int)((768 + nt - 1) / nt);                       // ~3 workgroups per CU; K = rows of the batch, a few hundred thousand
-        if (splits > 64) splits = 64;
+        if (splits > 256) splits = 256;                                // (the 256 x 128 gradient of the second conv is 2 tiles: 64 ranges left half the chip idle)
         while (splits > 1 && (K / splits < 256 || (size_t)splits * M * N * sizeof(float) > workspace_bytes)) --splits;
         int kps = (K + splits - 1) / splits; kps = (kps + 31) / 32 * 32; splits = (K + kps - 1) / kps;
         if (splits > 1 && !workspace) return ACT_E_NULLPTR;
