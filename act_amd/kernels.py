@@ -61,7 +61,7 @@ for _n in ("act_sgemm_tn_grouped_workspace", "act_sgemm_tn_grouped_splits", "act
 
 # ---- persistent scratch (split-K partials, LN / colsum partial rows): one buffer per device ----------
 _WS = {}
-_WS_BYTES = 64 << 20
+_WS_BYTES = 160 << 20       # split-K / grouped-GEMM partials: 7 K ranges of the two d=768 MLP weight gradients need 132 MB (round 3; 64 MB before)
 
 
 def workspace(device, nbytes=_WS_BYTES):
