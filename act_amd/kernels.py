@@ -247,6 +247,8 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1, trace=None):
             nbq = -(-M // (128 if tile == 1 else 64)) * (N // 128)
             if K >= 1024 and nbq < 2048:
                 qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
+            if K >= 65536 and nbq <= 64:                              # weight gradients over a few hundred thousand rows on a handful of tiles
+                qsp += [s for s in (48, 64, 96, 128, 192, 256) if s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 1024]
             if K >= 512 and nbq < 128:                                # a handful of tiles: K ranges down to 128 rows, up to one round of 512 workgroups
                 qsp += [s for s in (5, 7, 9, 10, 12, 14, 16) if s not in qsp and K // s >= 128 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 512]
             if _MAX_SPLIT > 0 and K <= 8192:
@@ -257,6 +259,8 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1, trace=None):
             nbq = -(-M // (128 if tile == 2 else 64)) * (N // 64)
             if K >= 1024 and nbq < 2048:
                 qsp += [s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 256 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 8192]
+            if K >= 65536 and nbq <= 64:                              # weight gradients over a few hundred thousand rows on a handful of tiles
+                qsp += [s for s in (48, 64, 96, 128, 192, 256) if s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 1024]
             if K >= 512 and nbq < 128:                                # a handful of tiles: K ranges down to 128 rows, up to one round of 512 workgroups
                 qsp += [s for s in (5, 7, 9, 10, 12, 14, 16) if s not in qsp and K // s >= 128 and s * M * N * 4 <= ws.numel() * 4 and nbq * s <= 512]
             if _MAX_SPLIT > 0 and K <= 8192:
