@@ -73,6 +73,7 @@ _SIGS = {
     "act_gemm_tune_clear": [],
     "act_composite_collect_begin": [],
     "act_composite_collect_end": [_P(_i), _i],
+    "act_composite_shutdown": [],
     "act_scale_rows_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "act_bn_eval_affine_f32": [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp, _vp],
     "act_block_saved_floats": [_P(BlockDims)],
@@ -177,6 +178,13 @@ def reset_tuning():
     lib.act_gemm_tune_clear()
     for (ak, bk, M, N, Kd), (tile, sp) in K._GEMM_TABLE.items():
         lib.act_gemm_tune_set(ak, bk, M, N, Kd, tile, sp)
+
+
+def shutdown():
+    """destroy the fork / join events the library created for the streams seen so far (the only state it owns); synchronises the device first.
+    Later composite calls create new ones.  -> number of events destroyed"""
+    torch.cuda.synchronize()
+    return int(lib.act_composite_shutdown())
 
 
 # ---- Transformer block ------------------------------------------------------------------------------------------------

@@ -154,6 +154,15 @@ int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t
 
 extern "C" {
 
+int act_composite_shutdown(void) {
+    std::lock_guard<std::mutex> g(g_ring_mu);
+    int n = 0;
+    for (auto& kv : g_rings)
+        for (hipEvent_t e : kv.second.ev) { (void)hipEventDestroy(e); ++n; }
+    g_rings.clear();
+    return n;
+}
+
 int act_composite_collect_begin(void) {
     if (t_collect) return ACT_E_BADARG;
     t_collect = new std::vector<GemmShape>();

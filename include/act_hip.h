@@ -324,6 +324,11 @@ int act_bn_eval_affine_f32(const float* gamma, const float* beta, const float* r
  * end -> number recorded (the first `max` written to shapes [max][5]). */
 int act_composite_collect_begin(void);
 int act_composite_collect_end(int* shapes, int max);
+/* The only state the library keeps: up to 32 fork / join events (hipEventDisableTiming) per stream that ever produced work for another stream
+ * inside a composite call.  act_composite_shutdown destroys them; call it when no composite call is in flight on any host thread and the
+ * streams involved are idle (e.g. before hipDeviceReset / at interpreter exit).  Later composite calls simply create new events.  Returns
+ * the number of events destroyed. */
+int act_composite_shutdown(void);
 
 typedef struct {                     /* parameters of one pre-LN Transformer block (models/act.py:72-90; timm ViT block) */
     const float *norm1_w, *norm1_b, *qkv_w, *qkv_b /* nullable */, *proj_w, *proj_b, *norm2_w, *norm2_b,

@@ -49,6 +49,31 @@ def test_block_composite_is_bit_identical(dev, B, S, D, H, qkv_bias, train_w):
     assert res[0][1].abs().max() > 0
 
 
+def test_composite_shutdown_releases_the_fork_join_events(dev):
+    """the library's only state are the fork / join events of streams that produced work for another stream: act_composite_shutdown destroys them,
+    and a later call works (and gives the same bits) on fresh ones"""
+    import act_amd.composite as CP
+    torch.manual_seed(0)
+    B, S, D, H = 4, 14, 384, 6
+    x0 = torch.randn(B, S, D, device=dev); pos0 = 0.1 * torch.randn(B, S, D, device=dev); dout = torch.randn(B, S, D, device=dev)
+    one = torch.ones(B, device=dev)
+
+    def run():
+        ps = _params(dev, D, 4 * D, False, 1)
+        x = x0.clone().requires_grad_(True)
+        y = CP.BlockFn.apply(x, pos0, one, one, *ps, H, 1e-5, 2)          # train_w = 2: weight gradients forked to the auxiliary stream
+        y.backward(dout)
+        return [y.detach(), x.grad] + [p.grad for p in ps if p is not None]
+
+    a = run()
+    n = CP.shutdown()
+    assert n >= 1
+    assert CP.shutdown() == 0
+    b = run()
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert CP.shutdown() >= 1
+
+
 def test_prefix_block_composite_is_bit_identical(dev):
     import act_amd.kernels as K
     import act_amd.composite as CP
