@@ -390,6 +390,7 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     else { p.epi = act_gemm_epilogue_t{}; p.epi.alpha = 1.0f; }
     if (p.epi.rowscale && p.epi.rows_per_scale <= 0) return ACT_E_BADARG;
     if ((p.epi.act == ACT_EPI_MUL_GELU_GRAD || p.epi.act == ACT_EPI_MUL_RELU_MASK) && !p.epi.aux) return ACT_E_NULLPTR;
+    p.epi_vec = epilogue_is_vec(C, ldc, p.epi);
 
     const int kid = (a_kmajor && b_kmajor) ? KID_GEMM_NT : (a_kmajor ? KID_GEMM_NN : KID_GEMM_TN);
     ActProfScope ps(kid, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
@@ -533,6 +534,7 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     GemmParams p{};
     p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     if (epi_in) p.epi = *epi_in; else p.epi.alpha = 1.0f;
+    p.epi_vec = C ? epilogue_is_vec(C, ldc, p.epi) : 0;
     p.fx.a_scale = fx->a_scale; p.fx.a_shift = fx->a_shift; p.fx.b_scale = fx->b_scale; p.fx.b_shift = fx->b_shift;
     p.fx.tile_stats = fx->tile_stats; p.fx.gmax = fx->gmax; p.fx.garg = fx->garg; p.fx.group = fx->group; p.fx.store_c = fx->store_c;
     p.fx.sa_src = fx->sa_src; p.fx.sa_arg = fx->sa_arg; p.fx.ep_src = fx->ep_src; p.fx.ep_arg = fx->ep_arg;

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
 // flight across it).  Same products in the same order: results are bit-identical to the plain loop.  Needs an even number of K-tiles
 // (K per split % 32 == 0); loads past the end are clamped to the last tile and land in an LDS buffer nobody reads.  Pays on long K
 // (+3-4 % at K = 3,072, benchmarks/micro/nt_pipe.hip) and on launches with few workgroups per CU.
-template <int BM, int BN, bool MG = false, int FX = 0, bool PIPE = false>
+template <int BM, int BN, bool MG = false, int FX = 0, bool PIPE = false, int ACT = -1>
 __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SMALL : 3) void sgemm_nt16_kernel(const GemmParams p) {
     static_assert(!PIPE || (FX == 0 && !MG), "pipelined loop: plain full tiles");
     constexpr int BK = 16;
@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
     // rows 64 apart share the swizzle, so the extra loads are plain immediates on one pointer / one LDS offset per operand
     const int srow = tid >> 2, sch = tid & 3;
     const float* ga = p.A + (size_t)(MG ? min(m0 + srow, p.M - 1) : m0 + srow) * p.lda + kbeg + sch * 4;
-    const float* gb = p.B + (size_t)(n0 + srow) * p.ldb + kbeg + sch * 4;
+    // B rows are staged PERMUTED (see epilogue_rows): LDS row j*16 + m of every 16*TN-row block holds global row TN*m + j of that block
+    const int srow_b = (srow / (16 * TN)) * (16 * TN) + TN * (srow & 15) + (srow % (16 * TN)) / 16;
+    const float* gb = p.B + (size_t)(n0 + srow_b) * p.ldb + kbeg + sch * 4;
     const int s_off = srow * 16 + 4 * (sch ^ ((4 - ((srow >> 2) & 3)) & 3));
     const size_t stride_a = MG ? (size_t)(min(m0 + srow + 64, p.M - 1) - min(m0 + srow, p.M - 1)) * p.lda : (size_t)64 * p.lda;
     const size_t stride_b = (size_t)64 * p.ldb;
@@ -313,29 +315,13 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
     if (ntiles > 0) compute((ntiles - 1) & 1);
     }
 
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 16 + ml;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 16 + kl * 4 + r;
-                if (MG && row >= p.M) continue;
-                float v = acc[i][j][r];
-                if (p.partial) {
-                    p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
-                } else {
-                    v = epilogue_apply(p.epi, v, row, col);
-                    if constexpr (FX != 0) acc[i][j][r] = v;          // the fused reductions below work on the stored values
-                    if constexpr ((FX & FX_NOSTORE) == 0) {
-                        float* c = p.C + (size_t)row * p.ldc + col;
-                        if (p.epi.accumulate) v += *c;
-                        *c = v;
-                    }
-                }
-            }
-        }
+    {
+        const int wu = __builtin_amdgcn_readfirstlane(wave);
+        epilogue_rows<ACT, TM, TN, MG, FX != 0, (FX & FX_NOSTORE) == 0>(p, acc, m0 + (wu >> 1) * (BM / 2), n0 + (wu & 1) * (BN / 2), ml, kl);
+    }
+    if constexpr (FX == 0) return;
+    if (p.partial) return;
+    const int cw = wn * (BN / 2) + TN * ml;                           // + j: this lane's columns inside the tile (B rows are staged permuted)
 
     if constexpr ((FX & FX_GROUPMAX) != 0) {
         // max + first arg-max over every `group` consecutive rows (torch.max(feature, dim=2) over the points of a group,
@@ -343,7 +329,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
         const int group = p.fx.group;                                 // 32 or 64
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 16 + ml;
+            const int col = n0 + cw + j;
             float hb[2]; int hi[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                             // half of the wave's rows: blocks 2h, 2h+1
@@ -392,13 +378,13 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
             for (int i = 0; i < TM; ++i) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
             s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
             csum[j] = s;
-            if (kl == 0) red[wm * BN + wn * (BN / 2) + j * 16 + ml] = s;
+            if (kl == 0) red[wm * BN + cw + j] = s;
         }
         __syncthreads();
         float mean[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int c = wn * (BN / 2) + j * 16 + ml;
+            const int c = cw + j;
             mean[j] = (red[c] + red[BN + c]) * (1.0f / BM);
         }
         __syncthreads();
@@ -410,13 +396,13 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; q += d * d; }
             q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-            if (kl == 0) red[wm * BN + wn * (BN / 2) + j * 16 + ml] = q;
+            if (kl == 0) red[wm * BN + cw + j] = q;
         }
         __syncthreads();
         if (wm == 0 && kl == 0) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int c = wn * (BN / 2) + j * 16 + ml;
+                const int c = cw + j;
                 float* ts = p.fx.tile_stats + (size_t)tile_m * 2 * p.N + n0 + c;
                 ts[0] = mean[j];
                 ts[p.N] = red[c] + red[BN + c];
@@ -427,7 +413,10 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
 }
 
 bool launch_sgemm_nt16_fx(const GemmParams& p, int tile, int fx, dim3 grid, hipStream_t s) {
-#define FXL(BN_, MASK) hipLaunchKernelGGL((sgemm_nt16_kernel<128, BN_, false, MASK>), grid, dim3(256), 0, s, p); return true
+#define FXL(BN_, MASK) \
+    if (p.epi.act == ACT_EPI_NONE) hipLaunchKernelGGL((sgemm_nt16_kernel<128, BN_, false, MASK, false, ACT_EPI_NONE>), grid, dim3(256), 0, s, p); \
+    else                           hipLaunchKernelGGL((sgemm_nt16_kernel<128, BN_, false, MASK>), grid, dim3(256), 0, s, p); \
+    return true
     if (tile == 0) {
         if (fx == FX_COLSTATS) { FXL(128, FX_COLSTATS); }
         if (fx == (FX_AFFINE_A | FX_GROUPMAX)) { FXL(128, FX_AFFINE_A | FX_GROUPMAX); }
@@ -843,9 +832,24 @@ void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s) 
         else                hipLaunchKernelGGL((sgemm_nt16_kernel<64, 64, true>), grid, dim3(256), 0, s, p);
         return;
     }
-    if (tile == 0)      hipLaunchKernelGGL((sgemm_nt16_kernel<128, 128>), grid, dim3(256), 0, s, p);
-    else if (tile == 1) hipLaunchKernelGGL((sgemm_nt16_kernel<128, 64>), grid, dim3(256), 0, s, p);
-    else                hipLaunchKernelGGL((sgemm_nt16_kernel<64, 64>), grid, dim3(256), 0, s, p);
+    static const int spec = [] { const char* e = getenv("ACT_GEMM_EPI_SPEC"); return e ? atoi(e) : 1; }();
+    if (!spec) {
+        if (tile == 0)      hipLaunchKernelGGL((sgemm_nt16_kernel<128, 128>), grid, dim3(256), 0, s, p);
+        else if (tile == 1) hipLaunchKernelGGL((sgemm_nt16_kernel<128, 64>), grid, dim3(256), 0, s, p);
+        else                hipLaunchKernelGGL((sgemm_nt16_kernel<64, 64>), grid, dim3(256), 0, s, p);
+        return;
+    }
+#define NT16_ACT(BM_, BN_) \
+    switch (p.epi.act) { \
+        case ACT_EPI_NONE: hipLaunchKernelGGL((sgemm_nt16_kernel<BM_, BN_, false, 0, false, ACT_EPI_NONE>), grid, dim3(256), 0, s, p); break; \
+        case ACT_EPI_GELU: hipLaunchKernelGGL((sgemm_nt16_kernel<BM_, BN_, false, 0, false, ACT_EPI_GELU>), grid, dim3(256), 0, s, p); break; \
+        case ACT_EPI_RELU: hipLaunchKernelGGL((sgemm_nt16_kernel<BM_, BN_, false, 0, false, ACT_EPI_RELU>), grid, dim3(256), 0, s, p); break; \
+        default:           hipLaunchKernelGGL((sgemm_nt16_kernel<BM_, BN_>), grid, dim3(256), 0, s, p); break; \
+    }
+    if (tile == 0)      { NT16_ACT(128, 128) }
+    else if (tile == 1) { NT16_ACT(128, 64) }
+    else                { NT16_ACT(64, 64) }
+#undef NT16_ACT
 }
 
 void launch_sgemm16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s) {

@@ -30,6 +30,7 @@ struct GemmParams {
     act_gemm_epilogue_t epi;
     int tiles_m, tiles_n;
     int group_m;                     // tile rasterisation: GROUP_M tile rows are swept column by column (1 = plain row-major)
+    int epi_vec;                     // quad epilogues: C / bias / residual / aux are 16-byte aligned with leading dimensions % 4 == 0 (float4 accesses)
     int xcd_rows;                    // 0: every XCD owns a contiguous band of the rasterised tile order; r (1, 2, 4): the 8 XCDs form an r x 8/r grid of tile blocks
 };
 
@@ -51,10 +52,15 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// ACT: compile-time value of e.act (ACT_EPI_*), or -1 = decide at run time.  The run-time form inlines erff / expf for EVERY accumulator element
+// (64 per lane in a 128 x 128 tile): ~60 KB of code per kernel that the launches without an activation only jump over -- more than the
+// instruction cache two CUs share -- so the kernels are instantiated per activation and the launcher picks (see launch_sgemm_nt16).
+template <int ACT = -1>
 __device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, float v, int row, int col) {
     v *= e.alpha;
     if (e.bias) v += e.bias[col];
-    switch (e.act) {
+    const int act = ACT >= 0 ? ACT : e.act;
+    switch (act) {
         case ACT_EPI_GELU:      if (e.aux) e.aux[(size_t)row * e.ldaux + col] = v; v = gelu_f(v); break;
         case ACT_EPI_RELU:      v = fmaxf(v, 0.f); break;
         case ACT_EPI_MUL_GELU_GRAD: v *= gelu_grad_f(e.aux[(size_t)row * e.ldaux + col]); break;
@@ -66,6 +72,137 @@ __device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, fl
     return v;
 }
 
+
+// ---- vector epilogue of the NT b128 kernels.  Their B operand is staged with PERMUTED rows (LDS row j*16 + m of a wave's 16*TN-row block holds
+// global column TN*m + j), so after the MFMAs lane (ml = lane & 15, kl = lane >> 4) owns, for every row i*16 + 4*kl + r it holds, the TN CONSECUTIVE
+// columns TN*ml ... TN*ml + TN-1 (acc[i][0..TN-1][r]): one float4 (float2) per row, and the 16 lanes of a quarter-wave cover 256 (128) contiguous
+// bytes of that row.  The per-element epilogue this replaces issued, per lane and 128 x 128 tile, 64 scalar residual loads, 64 scalar stores and
+// ~20 VALU instructions of 64-bit address arithmetic per element: launches with bias + residual ran 8 % below the bare product at K = 768 and
+// 40 % below at K = 256 (benchmarks/epi_spec_bench.py).  Here every access is a vector, every address is (wave-uniform 64-bit base in SGPRs) +
+// (one 32-bit lane offset computed once), the bias is one vector per lane and tile.  Same arithmetic per element in the same order: bit-identical.
+// `vec` (wave-uniform): all pointers 16-byte aligned and all leading dimensions % 4 == 0; otherwise scalar accesses.
+inline int epilogue_is_vec(const float* C, int ldc, const act_gemm_epilogue_t& e) {
+    uintptr_t a = reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(e.bias) | reinterpret_cast<uintptr_t>(e.res) | reinterpret_cast<uintptr_t>(e.aux);
+    int ld = ldc | (e.res ? e.ldr : 0) | (e.aux ? e.ldaux : 0);
+    return (a & 15) == 0 && (ld & 3) == 0;
+}
+template <int W> struct VecOf;
+template <> struct VecOf<4> { typedef float4 type; };
+template <> struct VecOf<2> { typedef float2 type; };
+template <int W>
+__device__ __forceinline__ void ldw(float (&v)[W], const float* base, unsigned lane_bytes, bool vec) {
+    const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lane_bytes);
+    if (vec) {
+        const typename VecOf<W>::type t = *reinterpret_cast<const typename VecOf<W>::type*>(q);
+        const float* tp = reinterpret_cast<const float*>(&t);
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = tp[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = q[k];
+    }
+}
+template <int W>
+__device__ __forceinline__ void stw(float* base, unsigned lane_bytes, bool vec, const float (&v)[W]) {
+    float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + lane_bytes);
+    if (vec) {
+        typename VecOf<W>::type t;
+        float* tp = reinterpret_cast<float*>(&t);
+#pragma unroll
+        for (int k = 0; k < W; ++k) tp[k] = v[k];
+        *reinterpret_cast<typename VecOf<W>::type*>(q) = t;
+    } else {
+#pragma unroll
+        for (int k = 0; k < W; ++k) q[k] = v[k];
+    }
+}
+
+// row0 / col0: first row / column of the wave's tile (wave-uniform).  acc[i][j][r] = C[row0 + i*16 + 4*kl + r][col0 + TN*ml + j].
+// KEEP: the values as stored (before an `accumulate` read-modify-write) are written back to acc for the fused reductions; STORE: write C.
+template <int ACT, int TM, int TN, bool MG, bool KEEP, bool STORE, typename Acc>
+__device__ __forceinline__ void epilogue_rows(const GemmParams& p, Acc& acc, const int row0, const int col0, const int ml, const int kl) {
+    const act_gemm_epilogue_t& e = p.epi;
+    if (p.partial) {                                                     // split-K: raw partial sums, [split][M][N] (workspace: 16-byte aligned, N % 4 == 0)
+        float* base = p.partial + ((size_t)blockIdx.z * p.M + row0) * p.N + col0;
+        const unsigned lp = (unsigned)(4 * kl * p.N + TN * ml) * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (MG && row0 + i * 16 + 4 * kl + r >= p.M) continue;
+                float v[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+                stw<TN>(base + (size_t)(i * 16 + r) * p.N, lp, true, v);
+            }
+        return;
+    }
+    const bool vec = p.epi_vec != 0;
+    const int act = ACT >= 0 ? ACT : e.act;
+    const unsigned lc = (unsigned)(4 * kl * p.ldc + TN * ml) * 4u, lx = (unsigned)(4 * kl * e.ldaux + TN * ml) * 4u;
+    const unsigned lr = (unsigned)(4 * kl * e.ldr + TN * ml) * 4u, lb = (unsigned)(TN * ml) * 4u;
+    float b[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = 0.f;
+    if (e.bias) ldw<TN>(b, e.bias + col0, lb, vec);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rowu = row0 + i * 16 + r, row = rowu + 4 * kl;     // rowu: wave-uniform part
+            if (MG && row >= p.M) continue;
+            float v[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { v[j] = acc[i][j][r] * e.alpha; if (e.bias) v[j] += b[j]; }
+            switch (act) {
+                case ACT_EPI_GELU:
+                    if (e.aux) stw<TN>(e.aux + (size_t)rowu * e.ldaux + col0, lx, vec, v);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) v[j] = gelu_f(v[j]);
+                    break;
+                case ACT_EPI_RELU:
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) v[j] = fmaxf(v[j], 0.f);
+                    break;
+                case ACT_EPI_MUL_GELU_GRAD: {
+                    float x[TN]; ldw<TN>(x, e.aux + (size_t)rowu * e.ldaux + col0, lx, vec);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) v[j] *= gelu_grad_f(x[j]);
+                    break; }
+                case ACT_EPI_MUL_RELU_MASK: {
+                    float x[TN]; ldw<TN>(x, e.aux + (size_t)rowu * e.ldaux + col0, lx, vec);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) v[j] = x[j] > 0.f ? v[j] : 0.f;
+                    break; }
+                default: break;
+            }
+            if (e.rowscale) {
+                const float rs = e.rowscale[row / e.rows_per_scale];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] *= rs;
+            }
+            if (e.res) {
+                float q[TN];
+                if (e.res_row_div > 1) ldw<TN>(q, e.res + (size_t)(row / e.res_row_div) * e.ldr + col0, lb, vec);
+                else                   ldw<TN>(q, e.res + (size_t)rowu * e.ldr + col0, lr, vec);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] += q[j];
+            }
+            if (KEEP) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = v[j];
+            }
+            if (STORE) {
+                float* cb = p.C + (size_t)rowu * p.ldc + col0;
+                if (e.accumulate) {
+                    float q[TN]; ldw<TN>(q, cb, lc, vec);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) v[j] += q[j];
+                }
+                stw<TN>(cb, lc, vec, v);
+            }
+        }
+}
 
 // XCD-aware remap: workgroup b is dispatched to XCD b%8; give each XCD a contiguous band of tiles (own L2)
 __device__ __forceinline__ int xcd_remap(int wg, int nwg) {
