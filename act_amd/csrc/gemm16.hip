@@ -446,7 +446,7 @@ bool launch_sgemm_nt16_fx(const GemmParams& p, int tile, int fx, dim3 grid, hipS
 // FXA (max-pool backward on load): the A operand is virtual, A[r][c] = sa_arg[r/group][c] == r % group ? sa_src[r/group][c] : 0 with lda = channels:
 // the scattered gradient of torch.max(feature, dim=2) is generated while it is staged instead of being written (and read twice) as an
 // [R][C] tensor.  FXE: the same term added in the epilogue, C[r][c] += ep_arg[r/group][c] == r % group ? ep_src[r/group][c] : 0.
-template <int BM, int BN, bool A_K, bool B_K, bool MG = false, bool FXB = false, bool FXA = false, bool FXE = false>
+template <int BM, int BN, bool A_K, bool B_K, bool MG = false, bool FXB = false, bool FXA = false, bool FXE = false, int ACT = -1>
 __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
     static_assert(!FXB || !B_K, "FXB: row-contiguous B");
     static_assert(!(FXA || FXE) || (BM == 128 && !MG), "fused max-pool backward: 128-row tiles, no M tail");
@@ -588,6 +588,12 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
     // epilogue.  D layout of one 16x16 block: MFMA col = ml, MFMA row = 4*kl + reg.
     //   actual row of (block i, MFMA row r) = A_K ? wm*BM/2 + 16 i + r : wm*64 + 4 r + i
     //   actual col of (block j, MFMA col c) = B_K ? wn*BN/2 + 16 j + c : wn*64 + 4 c + j     (-> 4 consecutive columns per lane)
+    if constexpr (!B_K) {                                              // four consecutive columns per lane: vector epilogue (gemm_common.h)
+        const int wu = __builtin_amdgcn_readfirstlane(wave);
+        const int wmu = WN == 2 ? wu >> 1 : wu, wnu = WN == 2 ? wu & 1 : 0;
+        epilogue_rows<ACT, TM, TN, MG, false, true, !A_K, FXE>(p, acc, m0 + (A_K ? wmu * (BM / WM) : wmu * 64), n0 + wnu * 64, ml, kl);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -765,6 +771,14 @@ void launch_sgemm_nt32(const GemmParams& p, int tile, dim3 grid, hipStream_t s) 
 
 // tile: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 128x64 (1..3 NN only: A K-contiguous; 2, 3: 4 x 1 waves).  false: no such kernel.
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s) {
+    // kernels instantiated per activation (see epilogue_apply): none (dW, plain dX), gelu' (dX through fc2 -> GELU), relu mask (MLP heads)
+#define Q16_ACT(BM_, BN_, AK_) \
+    switch (p.epi.act) { \
+        case ACT_EPI_NONE:          hipLaunchKernelGGL((sgemm_q16_kernel<BM_, BN_, AK_, false, false, false, false, false, ACT_EPI_NONE>), grid, dim3(256), 0, s, p); break; \
+        case ACT_EPI_MUL_GELU_GRAD: hipLaunchKernelGGL((sgemm_q16_kernel<BM_, BN_, AK_, false, false, false, false, false, ACT_EPI_MUL_GELU_GRAD>), grid, dim3(256), 0, s, p); break; \
+        case ACT_EPI_MUL_RELU_MASK: hipLaunchKernelGGL((sgemm_q16_kernel<BM_, BN_, AK_, false, false, false, false, false, ACT_EPI_MUL_RELU_MASK>), grid, dim3(256), 0, s, p); break; \
+        default:                    hipLaunchKernelGGL((sgemm_q16_kernel<BM_, BN_, AK_, false>), grid, dim3(256), 0, s, p); break; \
+    }
     if (a_kmajor && b_kmajor) return false;
     if (b_kmajor) return false;                                       // (A [K][M], B [N][K]) never occurs on this path
     if (a_kmajor && (tile == 2 || tile == 3)) {
@@ -773,8 +787,8 @@ bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor,
             if (tile == 2) hipLaunchKernelGGL((sgemm_q16_kernel<64, 64, true, false, true>), grid, dim3(256), 0, s, p);
             else           hipLaunchKernelGGL((sgemm_q16_kernel<128, 64, true, false, true>), grid, dim3(256), 0, s, p);
         } else {
-            if (tile == 2) hipLaunchKernelGGL((sgemm_q16_kernel<64, 64, true, false>), grid, dim3(256), 0, s, p);
-            else           hipLaunchKernelGGL((sgemm_q16_kernel<128, 64, true, false>), grid, dim3(256), 0, s, p);
+            if (tile == 2) { Q16_ACT(64, 64, true) }
+            else           { Q16_ACT(128, 64, true) }
         }
         return true;
     }
@@ -784,18 +798,22 @@ bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor,
             if (tile == 1) hipLaunchKernelGGL((sgemm_q16_kernel<64, 128, true, false, true>), grid, dim3(256), 0, s, p);
             else           hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, true, false, true>), grid, dim3(256), 0, s, p);
         } else {
-            if (tile == 1) hipLaunchKernelGGL((sgemm_q16_kernel<64, 128, true, false>), grid, dim3(256), 0, s, p);
-            else           hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, true, false>), grid, dim3(256), 0, s, p);
+            if (tile == 1) { Q16_ACT(64, 128, true) }
+            else           { Q16_ACT(128, 128, true) }
         }
         return true;
     }
     if (tile != 0) return false;                                      // TN: dW = dY^T . X, 128x128 only
-    hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, false, false>), grid, dim3(256), 0, s, p);
+    Q16_ACT(128, 128, false)
     return true;
+#undef Q16_ACT
 }
 
 bool launch_sgemm_q16_fx(const GemmParams& p, int a_kmajor, int fx_mask, dim3 grid, hipStream_t s) {
-#define QL(AK, FB, FA, FE) hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, AK, false, false, FB, FA, FE>), grid, dim3(256), 0, s, p); return true
+#define QL(AK, FB, FA, FE) \
+    if (p.epi.act == ACT_EPI_NONE) hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, AK, false, false, FB, FA, FE, ACT_EPI_NONE>), grid, dim3(256), 0, s, p); \
+    else                           hipLaunchKernelGGL((sgemm_q16_kernel<128, 128, AK, false, false, FB, FA, FE>), grid, dim3(256), 0, s, p); \
+    return true
     if (!a_kmajor) {                                                  // TN weight gradients
         if (fx_mask == FX_AFFINE_B) { QL(false, true, false, false); }
         if (fx_mask == (FX_AFFINE_B | FX_SCATTER_A)) { QL(false, true, true, false); }

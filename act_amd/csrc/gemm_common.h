@@ -119,28 +119,32 @@ __device__ __forceinline__ void stw(float* base, unsigned lane_bytes, bool vec, 
 
 // row0 / col0: first row / column of the wave's tile (wave-uniform).  acc[i][j][r] = C[row0 + i*16 + 4*kl + r][col0 + TN*ml + j].
 // KEEP: the values as stored (before an `accumulate` read-modify-write) are written back to acc for the fused reductions; STORE: write C.
-template <int ACT, int TM, int TN, bool MG, bool KEEP, bool STORE, typename Acc>
+// ROWQ: the quad-fragment kernels' row layout when A is row-contiguous -- acc[i][..][r] is row 16*kl + 4*r + i instead of i*16 + 4*kl + r.
+// FXE (TN == 4): C[r][c] += ep_arg[r / group][c] == r % group ? ep_src[r / group][c] : 0 (max-pool backward of the mini-PointNet) after the residual.
+template <int ACT, int TM, int TN, bool MG, bool KEEP, bool STORE, bool ROWQ = false, bool FXE = false, typename Acc>
 __device__ __forceinline__ void epilogue_rows(const GemmParams& p, Acc& acc, const int row0, const int col0, const int ml, const int kl) {
     const act_gemm_epilogue_t& e = p.epi;
+    constexpr int RL = ROWQ ? 16 : 4;                                    // rows between the four lane groups kl
     if (p.partial) {                                                     // split-K: raw partial sums, [split][M][N] (workspace: 16-byte aligned, N % 4 == 0)
         float* base = p.partial + ((size_t)blockIdx.z * p.M + row0) * p.N + col0;
-        const unsigned lp = (unsigned)(4 * kl * p.N + TN * ml) * 4u;
+        const unsigned lp = (unsigned)(RL * kl * p.N + TN * ml) * 4u;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (MG && row0 + i * 16 + 4 * kl + r >= p.M) continue;
+                const int ru = ROWQ ? 4 * r + i : i * 16 + r;
+                if (MG && row0 + ru + RL * kl >= p.M) continue;
                 float v[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
-                stw<TN>(base + (size_t)(i * 16 + r) * p.N, lp, true, v);
+                stw<TN>(base + (size_t)ru * p.N, lp, true, v);
             }
         return;
     }
     const bool vec = p.epi_vec != 0;
     const int act = ACT >= 0 ? ACT : e.act;
-    const unsigned lc = (unsigned)(4 * kl * p.ldc + TN * ml) * 4u, lx = (unsigned)(4 * kl * e.ldaux + TN * ml) * 4u;
-    const unsigned lr = (unsigned)(4 * kl * e.ldr + TN * ml) * 4u, lb = (unsigned)(TN * ml) * 4u;
+    const unsigned lc = (unsigned)(RL * kl * p.ldc + TN * ml) * 4u, lx = (unsigned)(RL * kl * e.ldaux + TN * ml) * 4u;
+    const unsigned lr = (unsigned)(RL * kl * e.ldr + TN * ml) * 4u, lb = (unsigned)(TN * ml) * 4u;
     float b[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) b[j] = 0.f;
@@ -149,7 +153,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, Acc& acc, con
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int rowu = row0 + i * 16 + r, row = rowu + 4 * kl;     // rowu: wave-uniform part
+            const int rowu = row0 + (ROWQ ? 4 * r + i : i * 16 + r), row = rowu + RL * kl;     // rowu: wave-uniform part
             if (MG && row >= p.M) continue;
             float v[TN];
 #pragma unroll
@@ -187,6 +191,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, Acc& acc, con
                 else                   ldw<TN>(q, e.res + (size_t)rowu * e.ldr + col0, lr, vec);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) v[j] += q[j];
+            }
+            if constexpr (FXE) {
+                static_assert(!FXE || TN == 4, "scatter epilogue: four columns per lane");
+                const int gsh = p.fx.group == 64 ? 6 : 5;
+                const size_t o = (size_t)(row >> gsh) * p.N + col0 + TN * ml; const int pos = row & ((1 << gsh) - 1);
+                const int4 ea = *reinterpret_cast<const int4*>(p.fx.ep_arg + o);
+                const float4 ev = *reinterpret_cast<const float4*>(p.fx.ep_src + o);
+                v[0] += ea.x == pos ? ev.x : 0.f; v[1] += ea.y == pos ? ev.y : 0.f; v[2] += ea.z == pos ? ev.z : 0.f; v[3] += ea.w == pos ? ev.w : 0.f;
             }
             if (KEEP) {
 #pragma unroll
