@@ -18,6 +18,33 @@
 #include <stdlib.h>
 
 
+// epilogue of sgemm_kernel for one activation (C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)); ragged edges guarded
+template <int ACT, int BM, int BN, int TM, int TN, typename Acc>
+__device__ __forceinline__ void epilogue32(const GemmParams& p, Acc& acc, int m0, int n0, int wm, int wn, int lane) {
+    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 32 + col_l;
+            if (col >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
+                if (row >= p.M) continue;
+                float v = acc[i][j][r];
+                if (p.partial) {
+                    p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
+                } else {
+                    v = epilogue_apply<ACT>(p.epi, v, row, col);
+                    float* c = p.C + (size_t)row * p.ldc + col;
+                    if (p.epi.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+}
+
 // VEC : float4 global loads are legal (alignment, leading dimensions)      FULL: M%BM == N%BN == 0 and every K-range is a
 // multiple of BK, so the loaders carry no bounds checks at all.
 // PIPE: software-pipelined main loop for low-occupancy launches -- three LDS stages, the LDS store of tile t+1 and the
@@ -222,28 +249,13 @@ __global__ __launch_bounds__(256, PIPE ? 3 : GEMM_MIN_WAVES) void sgemm_kernel(c
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int col_l = lane & 31, row_l = 4 * (lane >> 5);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 32 + col_l;
-            if (col >= p.N) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + row_l;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r];
-                if (p.partial) {
-                    p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
-                } else {
-                    v = epilogue_apply(p.epi, v, row, col);
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if (p.epi.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
+    switch (p.partial ? ACT_EPI_NONE : p.epi.act) {                   // one uniform branch to a body specialised for the activation (see epilogue_apply)
+        case ACT_EPI_GELU:          epilogue32<ACT_EPI_GELU, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
+        case ACT_EPI_RELU:          epilogue32<ACT_EPI_RELU, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
+        case ACT_EPI_MUL_GELU_GRAD: epilogue32<ACT_EPI_MUL_GELU_GRAD, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
+        case ACT_EPI_MUL_RELU_MASK: epilogue32<ACT_EPI_MUL_RELU_MASK, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
+        default:                    epilogue32<ACT_EPI_NONE, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
+    }
 }
 
 // split-K reduction + epilogue (deterministic: fixed summation order over splits).  VEC: four consecutive columns per thread (float4 partial

@@ -115,26 +115,10 @@ __global__ __launch_bounds__(256, 4) void sgemm16_kernel(const GemmParams p) {
     }
 
     // epilogue: C/D layout of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + r
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 16 + ml;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 16 + kl * 4 + r;
-                if (MG && row >= p.M) continue;
-                float v = acc[i][j][r];
-                if (p.partial) {
-                    p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
-                } else {
-                    v = epilogue_apply(p.epi, v, row, col);
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if (p.epi.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
+    {
+        const int wu = __builtin_amdgcn_readfirstlane(wave);
+        epilogue_elems<-1, TM, TN, MG>(p, acc, m0 + (wu >> 1) * (BM / 2), n0 + (wu & 1) * (BN / 2), ml, kl);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -141,8 +141,17 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, Acc& acc, con
             }
         return;
     }
+    if constexpr (ACT < 0) {                                             // run-time activation: ONE uniform branch to a body specialised for it
+        switch (e.act) {                                                 // (not a switch per element: the executed path stays contiguous in the instruction cache)
+            case ACT_EPI_GELU:          epilogue_rows<ACT_EPI_GELU, TM, TN, MG, KEEP, STORE, ROWQ, FXE>(p, acc, row0, col0, ml, kl); return;
+            case ACT_EPI_RELU:          epilogue_rows<ACT_EPI_RELU, TM, TN, MG, KEEP, STORE, ROWQ, FXE>(p, acc, row0, col0, ml, kl); return;
+            case ACT_EPI_MUL_GELU_GRAD: epilogue_rows<ACT_EPI_MUL_GELU_GRAD, TM, TN, MG, KEEP, STORE, ROWQ, FXE>(p, acc, row0, col0, ml, kl); return;
+            case ACT_EPI_MUL_RELU_MASK: epilogue_rows<ACT_EPI_MUL_RELU_MASK, TM, TN, MG, KEEP, STORE, ROWQ, FXE>(p, acc, row0, col0, ml, kl); return;
+            default:                    epilogue_rows<ACT_EPI_NONE, TM, TN, MG, KEEP, STORE, ROWQ, FXE>(p, acc, row0, col0, ml, kl); return;
+        }
+    }
     const bool vec = p.epi_vec != 0;
-    const int act = ACT >= 0 ? ACT : e.act;
+    constexpr int act = ACT;
     const unsigned lc = (unsigned)(RL * kl * p.ldc + TN * ml) * 4u, lx = (unsigned)(RL * kl * e.ldaux + TN * ml) * 4u;
     const unsigned lr = (unsigned)(RL * kl * e.ldr + TN * ml) * 4u, lb = (unsigned)(TN * ml) * 4u;
     float b[TN];
@@ -212,6 +221,72 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams& p, Acc& acc, con
                     for (int j = 0; j < TN; ++j) v[j] += q[j];
                 }
                 stw<TN>(cb, lc, vec, v);
+            }
+        }
+}
+
+// Scalar form for the kernels whose lanes own single columns (sgemm16_kernel: acc[i][j][r] = C[row0 + i*16 + 4*kl + r][col0 + j*16 + ml]): same
+// address split (wave-uniform base + one lane offset) and the same hoisted activation branch; accesses stay 4 bytes per lane (16 lanes = 64 B).
+template <int ACT, int TM, int TN, bool MG, typename Acc>
+__device__ __forceinline__ void epilogue_elems(const GemmParams& p, Acc& acc, const int row0, const int col0, const int ml, const int kl) {
+    const act_gemm_epilogue_t& e = p.epi;
+    if (p.partial) {
+        float* base = p.partial + ((size_t)blockIdx.z * p.M + row0) * p.N + col0;
+        const unsigned lp = (unsigned)(4 * kl * p.N + ml) * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (MG && row0 + i * 16 + r + 4 * kl >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(base + (size_t)(i * 16 + r) * p.N + j * 16) + lp) = acc[i][j][r];
+            }
+        return;
+    }
+    if constexpr (ACT < 0) {
+        switch (e.act) {
+            case ACT_EPI_GELU:          epilogue_elems<ACT_EPI_GELU, TM, TN, MG>(p, acc, row0, col0, ml, kl); return;
+            case ACT_EPI_RELU:          epilogue_elems<ACT_EPI_RELU, TM, TN, MG>(p, acc, row0, col0, ml, kl); return;
+            case ACT_EPI_MUL_GELU_GRAD: epilogue_elems<ACT_EPI_MUL_GELU_GRAD, TM, TN, MG>(p, acc, row0, col0, ml, kl); return;
+            case ACT_EPI_MUL_RELU_MASK: epilogue_elems<ACT_EPI_MUL_RELU_MASK, TM, TN, MG>(p, acc, row0, col0, ml, kl); return;
+            default:                    epilogue_elems<ACT_EPI_NONE, TM, TN, MG>(p, acc, row0, col0, ml, kl); return;
+        }
+    }
+    const unsigned lc = (unsigned)(4 * kl * p.ldc + ml) * 4u, lx = (unsigned)(4 * kl * e.ldaux + ml) * 4u, lr = (unsigned)(4 * kl * e.ldr + ml) * 4u;
+    const unsigned lb = (unsigned)ml * 4u;
+    auto at = [](const float* base, unsigned lane_bytes) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lane_bytes); };
+    float b[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = e.bias ? *at(e.bias + col0 + j * 16, lb) : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rowu = row0 + i * 16 + r, row = rowu + 4 * kl;
+            if (MG && row >= p.M) continue;
+            float rs = 1.f;
+            if (e.rowscale) rs = e.rowscale[row / e.rows_per_scale];
+            const float* res_row = (e.res && e.res_row_div > 1) ? e.res + (size_t)(row / e.res_row_div) * e.ldr + col0 : nullptr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v = acc[i][j][r] * e.alpha;
+                if (e.bias) v += b[j];
+                if constexpr (ACT == ACT_EPI_GELU) {
+                    if (e.aux) *const_cast<float*>(at(e.aux + (size_t)rowu * e.ldaux + col0 + j * 16, lx)) = v;
+                    v = gelu_f(v);
+                } else if constexpr (ACT == ACT_EPI_RELU) {
+                    v = fmaxf(v, 0.f);
+                } else if constexpr (ACT == ACT_EPI_MUL_GELU_GRAD) {
+                    v *= gelu_grad_f(*at(e.aux + (size_t)rowu * e.ldaux + col0 + j * 16, lx));
+                } else if constexpr (ACT == ACT_EPI_MUL_RELU_MASK) {
+                    v = *at(e.aux + (size_t)rowu * e.ldaux + col0 + j * 16, lx) > 0.f ? v : 0.f;
+                }
+                if (e.rowscale) v *= rs;
+                if (e.res) v += res_row ? *at(res_row + j * 16, lb) : *at(e.res + (size_t)rowu * e.ldr + col0 + j * 16, lr);
+                float* c = const_cast<float*>(at(p.C + (size_t)rowu * p.ldc + col0 + j * 16, lc));
+                if (e.accumulate) v += *c;
+                *c = v;
             }
         }
 }
