@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
     constexpr int LDK = HD + 4;
     constexpr int PAIRS = (QT == 1) ? 4 : (QT == 2 ? 2 : 1);       // (cloud, head) pairs per workgroup
     constexpr int ROWS = JT * 32;
+    static_assert((ROWS * (HD / 4)) % 256 == 0, "staging: whole iterations per pair");
     extern __shared__ __attribute__((aligned(16))) float smem[];    // [PAIRS][2][ROWS][LDK]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, Sk = a.S0 + a.S1;
@@ -73,25 +74,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
 
     for (int kc = 0; kc < Sk; kc += ROWS) {
         if (kc > 0) __syncthreads();                                 // previous chunk fully consumed
-        // ---- stage this chunk of K and V for every pair of the workgroup (zero rows beyond Sk)
-        for (int idx = tid; idx < PAIRS * ROWS * (HD / 4); idx += 256) {
-            const int c4 = idx % (HD / 4);
-            const int rl = (idx / (HD / 4)) % ROWS, row = kc + rl;
-            const int p2 = idx / ((HD / 4) * ROWS);
-            const long long pr2 = pair0 + p2;
-            float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
-            if (pr2 < npairs && row < Sk) {
-                const int b2 = (int)(pr2 / H), h2 = (int)(pr2 % H);
-                if (row < a.S0) {
-                    const size_t of = (size_t)b2 * a.kv0_bs + (size_t)row * a.ld0 + h2 * HD + c4 * 4;
-                    kx = *reinterpret_cast<const float4*>(a.k0 + of); vx = *reinterpret_cast<const float4*>(a.v0 + of);
-                } else {
-                    const size_t of = (size_t)b2 * a.kv1_bs + (size_t)(row - a.S0) * a.ld1 + h2 * HD + c4 * 4;
-                    kx = *reinterpret_cast<const float4*>(a.k1 + of); vx = *reinterpret_cast<const float4*>(a.v1 + of);
+        // ---- stage this chunk of K and V for every pair of the workgroup (zero rows beyond Sk).  ROWS * HD / 4 is a multiple of 256, so all threads
+        // of an iteration work on the same pair: the (cloud, head) split is wave-uniform 32-bit arithmetic done once per pair, not a 64-bit division
+        // per staged float4
+#pragma unroll
+        for (int p2 = 0; p2 < PAIRS; ++p2) {
+            const unsigned pr2 = (unsigned)pair0 + p2;
+            const bool live = (long long)pr2 < npairs;
+            const unsigned b2 = live ? pr2 / (unsigned)H : 0u, h2 = live ? pr2 - b2 * (unsigned)H : 0u;
+            const float* k0p = a.k0 + (size_t)b2 * a.kv0_bs + h2 * HD; const float* v0p = a.v0 + (size_t)b2 * a.kv0_bs + h2 * HD;
+            const float* k1p = a.k1 + (size_t)b2 * a.kv1_bs + h2 * HD; const float* v1p = a.v1 + (size_t)b2 * a.kv1_bs + h2 * HD;
+            float* kd = smem + (size_t)(p2 * 2 + 0) * ROWS * LDK; float* vd = smem + (size_t)(p2 * 2 + 1) * ROWS * LDK;
+#pragma unroll
+            for (int it = 0; it < ROWS * (HD / 4) / 256; ++it) {
+                const int idx = tid + 256 * it;
+                const int c4 = idx % (HD / 4), rl = idx / (HD / 4), row = kc + rl;
+                float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
+                if (live && row < Sk) {
+                    if (row < a.S0) {
+                        const unsigned of = (unsigned)row * a.ld0 + c4 * 4;
+                        kx = *reinterpret_cast<const float4*>(k0p + of); vx = *reinterpret_cast<const float4*>(v0p + of);
+                    } else {
+                        const unsigned of = (unsigned)(row - a.S0) * a.ld1 + c4 * 4;
+                        kx = *reinterpret_cast<const float4*>(k1p + of); vx = *reinterpret_cast<const float4*>(v1p + of);
+                    }
                 }
+                *reinterpret_cast<float4*>(kd + rl * LDK + c4 * 4) = kx;
+                *reinterpret_cast<float4*>(vd + rl * LDK + c4 * 4) = vx;
             }
-            *reinterpret_cast<float4*>(smem + ((size_t)(p2 * 2 + 0) * ROWS + rl) * LDK + c4 * 4) = kx;
-            *reinterpret_cast<float4*>(smem + ((size_t)(p2 * 2 + 1) * ROWS + rl) * LDK + c4 * 4) = vx;
         }
         __syncthreads();
         if (!active) continue;                                       // idle waves only help staging

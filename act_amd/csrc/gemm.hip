@@ -275,8 +275,7 @@ __global__ __launch_bounds__(256) void sgemm_splitk_reduce(const float* __restri
                 const float4 x = *reinterpret_cast<const float4*>(p + (size_t)s * total);
                 v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
             }
-            v.x = epilogue_apply(epi, v.x, row, col); v.y = epilogue_apply(epi, v.y, row, col + 1);
-            v.z = epilogue_apply(epi, v.z, row, col + 2); v.w = epilogue_apply(epi, v.w, row, col + 3);
+            v = epilogue_apply4(epi, v, row, col);
             float4* c = reinterpret_cast<float4*>(C + (size_t)row * ldc + col);
             if (epi.accumulate) { const float4 o = *c; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             *c = v;
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(256) void sgemm_splitk_reduce(const float* __restri
     }
 }
 static void launch_splitk_reduce(const float* partial, int splits, int M, int N, float* C, int ldc, const act_gemm_epilogue_t& epi, hipStream_t s) {
-    const bool vec = (N & 3) == 0 && (ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(partial)) & 15) == 0;
+    const bool vec = (N & 3) == 0 && epilogue_is_vec(C, ldc, epi) && (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
     const long long total = vec ? (long long)M * (N >> 2) : (long long)M * N;
     long long g = (total + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
     if (vec) hipLaunchKernelGGL(sgemm_splitk_reduce<true>, dim3((unsigned)g), dim3(256), 0, s, partial, splits, M, N, C, ldc, epi);

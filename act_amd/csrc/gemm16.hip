@@ -585,31 +585,7 @@ __global__ __launch_bounds__(256, 3) void sgemm_q16_kernel(const GemmParams p) {
             const int r16 = kl * 4 + r;
             const int row = m0 + (A_K ? wm * (BM / WM) + i * 16 + r16 : wm * 64 + 4 * r16 + i);
             if (MG && row >= p.M) continue;
-            if constexpr (!B_K) {
-                const int col = n0 + wn * 64 + 4 * ml;
-                float4 v = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
-                if (p.partial) {
-                    *reinterpret_cast<float4*>(&p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col]) = v;
-                } else {
-                    v.x = epilogue_apply(p.epi, v.x, row, col); v.y = epilogue_apply(p.epi, v.y, row, col + 1);
-                    v.z = epilogue_apply(p.epi, v.z, row, col + 2); v.w = epilogue_apply(p.epi, v.w, row, col + 3);
-                    if constexpr (FXE) {
-                        const size_t o = (size_t)(row >> gsh) * p.N + col; const int pos = row & gmask;
-                        const int4 ea = *reinterpret_cast<const int4*>(p.fx.ep_arg + o);
-                        const float4 ev = *reinterpret_cast<const float4*>(p.fx.ep_src + o);
-                        v.x += ea.x == pos ? ev.x : 0.f; v.y += ea.y == pos ? ev.y : 0.f; v.z += ea.z == pos ? ev.z : 0.f; v.w += ea.w == pos ? ev.w : 0.f;
-                    }
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) {
-                        float4* c4 = reinterpret_cast<float4*>(c);
-                        if (p.epi.accumulate) { const float4 o = *c4; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                        *c4 = v;
-                    } else {
-                        if (p.epi.accumulate) { v.x += c[0]; v.y += c[1]; v.z += c[2]; v.w += c[3]; }
-                        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
-                    }
-                }
-            } else {
+            {                                                        // (B K-contiguous with A row-contiguous: not instantiated on this path)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = n0 + wn * (BN / WN) + j * 16 + ml;
@@ -659,8 +635,11 @@ __global__ __launch_bounds__(256, BM * BN <= 128 * 64 ? 3 : 2) void sgemm_nt32_k
 
     const int srow = tid >> 3, sch = tid & 7;
     const float* ga = p.A + (size_t)(m0 + srow) * p.lda + kbeg + sch * 4;
-    const float* gb = p.B + (size_t)(n0 + srow) * p.ldb + kbeg + sch * 4;
-    const size_t pa = (size_t)32 * p.lda, pb = (size_t)32 * p.ldb;
+    // B rows staged permuted (see epilogue_rows): LDS row srow + 32 * pass holds global row TN * (srow & 15) + (srow >> 4) + {0, 2, 64, 66}[pass] (TN = 4)
+    // or + 32 * pass (TN = 2)
+    const float* gb = p.B + (size_t)(n0 + TN * (srow & 15) + (srow >> 4)) * p.ldb + kbeg + sch * 4;
+    const size_t pa = (size_t)32 * p.lda;
+    const size_t pb1 = (size_t)(TN == 4 ? 2 : 32) * p.ldb, pb2 = (size_t)64 * p.ldb, pb3 = (size_t)66 * p.ldb;
     const int s_off_a = (sch >> 2) * (BM * 16) + srow * 16 + 4 * ((sch & 3) ^ ((4 - ((srow >> 2) & 3)) & 3));
     const int s_off_b = (sch >> 2) * (BN * 16) + srow * 16 + 4 * ((sch & 3) ^ ((4 - ((srow >> 2) & 3)) & 3));
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
@@ -671,10 +650,10 @@ __global__ __launch_bounds__(256, BM * BN <= 128 * 64 ? 3 : 2) void sgemm_nt32_k
         ra2 = *reinterpret_cast<const float4*>(ga + 2 * pa + t * BK);
         ra3 = *reinterpret_cast<const float4*>(ga + 3 * pa + t * BK);
         rb0 = *reinterpret_cast<const float4*>(gb + t * BK);
-        rb1 = *reinterpret_cast<const float4*>(gb + pb + t * BK);
+        rb1 = *reinterpret_cast<const float4*>(gb + pb1 + t * BK);
         if constexpr (NB > 2) {
-            rb2 = *reinterpret_cast<const float4*>(gb + 2 * pb + t * BK);
-            rb3 = *reinterpret_cast<const float4*>(gb + 3 * pb + t * BK);
+            rb2 = *reinterpret_cast<const float4*>(gb + pb2 + t * BK);
+            rb3 = *reinterpret_cast<const float4*>(gb + pb3 + t * BK);
         }
     };
     auto store_lds = [&](int buf) {
@@ -728,25 +707,8 @@ __global__ __launch_bounds__(256, BM * BN <= 128 * 64 ? 3 : 2) void sgemm_nt32_k
     }
     if (ntiles > 0) compute((ntiles - 1) & 1);
 
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 16 + ml;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 16 + kl * 4 + r;
-                float v = acc[i][j][r];
-                if (p.partial) {
-                    p.partial[((size_t)blockIdx.z * p.M + row) * p.N + col] = v;
-                } else {
-                    v = epilogue_apply(p.epi, v, row, col);
-                    float* c = p.C + (size_t)row * p.ldc + col;
-                    if (p.epi.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    epilogue_rows<-1, TM, TN, false, false, true>(p, acc, m0 + (wu >> 1) * (BM / 2), n0 + (wu & 1) * (BN / 2), ml, kl);
 }
 void launch_sgemm_nt32(const GemmParams& p, int tile, dim3 grid, hipStream_t s) {
     if (tile == 0) hipLaunchKernelGGL((sgemm_nt32_kernel<128, 128>), grid, dim3(256), 0, s, p);

@@ -73,6 +73,41 @@ __device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, fl
 }
 
 
+// four consecutive columns of one row at once (col % 4 == 0; bias / aux / res 16-byte aligned with leading dimensions % 4 == 0): the elementwise
+// kernels that apply the epilogue after a split-K reduction.  Same arithmetic per element as epilogue_apply, in the same order.
+template <int ACT>
+__device__ __forceinline__ float4 epilogue_apply4_act(const act_gemm_epilogue_t& e, float4 v, int row, int col) {
+    v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
+    if (e.bias) { const float4 b = *reinterpret_cast<const float4*>(e.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if constexpr (ACT == ACT_EPI_GELU) {
+        if (e.aux) *reinterpret_cast<float4*>(e.aux + (size_t)row * e.ldaux + col) = v;
+        v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w);
+    } else if constexpr (ACT == ACT_EPI_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    } else if constexpr (ACT == ACT_EPI_MUL_GELU_GRAD) {
+        const float4 x = *reinterpret_cast<const float4*>(e.aux + (size_t)row * e.ldaux + col);
+        v.x *= gelu_grad_f(x.x); v.y *= gelu_grad_f(x.y); v.z *= gelu_grad_f(x.z); v.w *= gelu_grad_f(x.w);
+    } else if constexpr (ACT == ACT_EPI_MUL_RELU_MASK) {
+        const float4 x = *reinterpret_cast<const float4*>(e.aux + (size_t)row * e.ldaux + col);
+        v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+    }
+    if (e.rowscale) { const float rs = e.rowscale[row / e.rows_per_scale]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+    if (e.res) {
+        const float4 q = *reinterpret_cast<const float4*>(e.res + (size_t)(e.res_row_div > 1 ? row / e.res_row_div : row) * e.ldr + col);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    return v;
+}
+__device__ __forceinline__ float4 epilogue_apply4(const act_gemm_epilogue_t& e, float4 v, int row, int col) {
+    switch (e.act) {
+        case ACT_EPI_GELU:          return epilogue_apply4_act<ACT_EPI_GELU>(e, v, row, col);
+        case ACT_EPI_RELU:          return epilogue_apply4_act<ACT_EPI_RELU>(e, v, row, col);
+        case ACT_EPI_MUL_GELU_GRAD: return epilogue_apply4_act<ACT_EPI_MUL_GELU_GRAD>(e, v, row, col);
+        case ACT_EPI_MUL_RELU_MASK: return epilogue_apply4_act<ACT_EPI_MUL_RELU_MASK>(e, v, row, col);
+        default:                    return epilogue_apply4_act<ACT_EPI_NONE>(e, v, row, col);
+    }
+}
+
 // ---- vector epilogue of the NT b128 kernels.  Their B operand is staged with PERMUTED rows (LDS row j*16 + m of a wave's 16*TN-row block holds
 // global column TN*m + j), so after the MFMAs lane (ml = lane & 15, kl = lane >> 4) owns, for every row i*16 + 4*kl + r it holds, the TN CONSECUTIVE
 // columns TN*ml ... TN*ml + TN-1 (acc[i][0..TN-1][r]): one float4 (float2) per row, and the 16 lanes of a quarter-wave cover 256 (128) contiguous
