@@ -861,3 +861,40 @@ def test_nt_kernel_with_32_deep_k_tiles_is_bit_identical(K, M, N, Kd, sp):
         if N % (128 if t32 == 20 else 64):
             continue
         assert torch.equal(K.gemm(a, b, True, True, bias=bias, cfg=(t32, sp)), K.gemm(a, b, True, True, bias=bias, cfg=(t16, sp))), (t32, sp)
+
+
+@pytest.mark.parametrize("tile,ak,bk", [(10, 1, 1), (11, 1, 1), (12, 1, 1), (21, 1, 1), (13, 1, 0), (14, 1, 0), (13, 0, 0), (7, 1, 0), (3, 1, 1)])
+def test_gemm_epilogue_scalar_fallback_matches_the_vector_path(K, tile, ak, bk):
+    """the vector epilogue (float4 / float2 accesses of C, bias, residual, aux: gemm_common.h::epilogue_rows) needs 16-byte aligned pointers and
+    leading dimensions % 4 == 0; anything else takes the scalar accesses of the same code.  C-ABI level: C / bias / residual / aux shifted by one
+    float inside larger allocations (odd leading dimensions), every activation -> bit-identical to the aligned launch."""
+    import ctypes
+    lib, ptr, stream = K.lib, K.ptr, K.stream
+    M, N, Kd = 256, 256, 192
+    a = _rnd(f"epi.a{tile}", *((M, Kd) if ak else (Kd, M))).cuda(); b = _rnd(f"epi.b{tile}", *((N, Kd) if bk else (Kd, N))).cuda()
+    bias = _rnd("epi.bias", N + 1).cuda(); res = _rnd("epi.res", M, N + 5).cuda(); auxin = _rnd("epi.aux", M, N + 5).cuda()
+    rs = (torch.rand(M // 32, device="cuda") + 0.5)
+    ws = K.workspace(a.device)
+
+    def run(shift, act, use_res, row_div):
+        ldo = N + 5 if shift else N + 4
+        cbuf = torch.zeros(M * ldo + 8, device="cuda"); xbuf = torch.zeros(M * ldo + 8, device="cuda")
+        xbuf[shift:shift + M * ldo].view(M, ldo)[:, :N] = auxin[:, :N]
+        rbuf = torch.zeros(M * ldo + 8, device="cuda"); rbuf[shift:shift + M * ldo].view(M, ldo)[:, :N] = res[:, :N]
+        bb = torch.zeros(N + 8, device="cuda"); bb[shift:shift + N] = bias[:N]
+        e = K.GemmEpilogue(alpha=0.5, act=act, accumulate=0, rows_per_scale=32, ldr=ldo if use_res else 0, ldaux=ldo, res_row_div=row_div,
+                           bias=bb.data_ptr() + 4 * shift, rowscale=rs.data_ptr(), res=(rbuf.data_ptr() + 4 * shift) if use_res else None,
+                           aux=xbuf.data_ptr() + 4 * shift)
+        rc = lib.act_sgemm_ex_f32(ak, bk, M, N, Kd, a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), cbuf.data_ptr() + 4 * shift, ldo,
+                                  ctypes.byref(e), ptr(ws), ws.numel() * 4, tile, 1, stream())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return cbuf[shift:shift + M * ldo].view(M, ldo)[:, :N].clone(), xbuf[shift:shift + M * ldo].view(M, ldo)[:, :N].clone()
+
+    for act in (K.EPI_NONE, K.EPI_GELU, K.EPI_RELU, K.EPI_MUL_GELU_GRAD, K.EPI_MUL_RELU_MASK):
+        for use_res, row_div in ((True, 0), (True, 32), (False, 0)):
+            c0, x0 = run(0, act, use_res, row_div)
+            c1, x1 = run(1, act, use_res, row_div)
+            assert torch.equal(c0, c1), (tile, act, use_res, row_div)
+            assert torch.equal(x0, x1)
+            assert c0.abs().max() > 0
