@@ -54,7 +54,8 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 
 // ACT: compile-time value of e.act (ACT_EPI_*), or -1 = decide at run time.  The run-time form inlines erff / expf for EVERY accumulator element
 // (64 per lane in a 128 x 128 tile): ~60 KB of code per kernel that the launches without an activation only jump over -- more than the
-// instruction cache two CUs share -- so the kernels are instantiated per activation and the launcher picks (see launch_sgemm_nt16).
+// instruction cache two CUs share -- so the vector epilogues below take ONE uniform branch to a body specialised for the activation, and the launchers of
+// the hot kernels instantiate per activation (launch_sgemm_nt16, launch_sgemm_q16).  This per-element form is left for the ragged-edge kernels.
 template <int ACT = -1>
 __device__ __forceinline__ float epilogue_apply(const act_gemm_epilogue_t& e, float v, int row, int col) {
     v *= e.alpha;

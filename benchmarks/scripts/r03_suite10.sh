@@ -1,7 +1,7 @@
 # ten consecutive runs of the GPU suite with the product default (first-use autotuner ON, complete shipped table)
 cd $GRAFT_REPO_ROOT
 : > gpurun_out/r03_suite10.txt
-for i in 1 2 3 4 5 6 7 8 9 10; do
+for i in $(seq 1 ${RUNS:-10}); do
   timeout 1500 python -m pytest tests/ -q -m gpu > gpurun_out/r03_suite10_run$i.log 2>&1
   echo "run $i rc=$? $(tail -1 gpurun_out/r03_suite10_run$i.log)" >> gpurun_out/r03_suite10.txt
   grep -E "^FAILED|auto-tuned during" gpurun_out/r03_suite10_run$i.log >> gpurun_out/r03_suite10.txt
