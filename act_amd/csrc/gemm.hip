@@ -249,13 +249,10 @@ __global__ __launch_bounds__(256, PIPE ? 3 : GEMM_MIN_WAVES) void sgemm_kernel(c
     }
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    switch (p.partial ? ACT_EPI_NONE : p.epi.act) {                   // one uniform branch to a body specialised for the activation (see epilogue_apply)
-        case ACT_EPI_GELU:          epilogue32<ACT_EPI_GELU, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
-        case ACT_EPI_RELU:          epilogue32<ACT_EPI_RELU, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
-        case ACT_EPI_MUL_GELU_GRAD: epilogue32<ACT_EPI_MUL_GELU_GRAD, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
-        case ACT_EPI_MUL_RELU_MASK: epilogue32<ACT_EPI_MUL_RELU_MASK, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
-        default:                    epilogue32<ACT_EPI_NONE, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane); break;
-    }
+    // one uniform branch: launches without activation (the common case) take a lean body, everything else the body with the run-time switch
+    // (instantiating all five activations here multiplies the compile time of this file's ~100 kernel variants by four)
+    if (p.partial || p.epi.act == ACT_EPI_NONE) epilogue32<ACT_EPI_NONE, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane);
+    else                                        epilogue32<-1, BM, BN, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // split-K reduction + epilogue (deterministic: fixed summation order over splits).  VEC: four consecutive columns per thread (float4 partial
@@ -382,11 +379,6 @@ extern "C" int act_gemm_tune_get(int ak, int bk, int M, int N, int K, int* tile,
 }
 extern "C" int act_gemm_tune_clear(void) { std::lock_guard<std::mutex> g(g_tune_mu); g_tune.clear(); return 0; }
 
-static int g_gemm_bk = 0;      // 0 = not read yet; ACT_GEMM_BK={16,32} selects the K-tile depth (tuning knob)
-static int gemm_bk() {
-    if (!g_gemm_bk) { const char* e = getenv("ACT_GEMM_BK"); g_gemm_bk = (e && atoi(e) == 32) ? 32 : GEMM_BK_DEFAULT; }
-    return g_gemm_bk;
-}
 
 extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
                                 float* C, int ldc, const act_gemm_epilogue_t* epi_in, float* workspace, size_t workspace_bytes,
@@ -480,7 +472,6 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     if ((xcd_rows_env == 1 || xcd_rows_env == 2 || xcd_rows_env == 4) && p.tiles_m % xcd_rows_env == 0 && p.tiles_n % (8 / xcd_rows_env) == 0)
         p.xcd_rows = xcd_rows_env;
     const long long nt = (long long)p.tiles_m * p.tiles_n;
-    const int BKsel = gemm_bk();
     int kps = K;
     if (splits > 1) { kps = (K + splits - 1) / splits; kps = (kps + 31) / 32 * 32; splits = (K + kps - 1) / kps; }
     p.k_per_split = kps;
@@ -506,10 +497,6 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     } else if (mi16) {
         if (!(full || full_mtail)) return ACT_E_BADARG;
         launch_sgemm16(p, BM == 128 ? (BN == 128 ? 0 : 1) : 2, a_kmajor, b_kmajor, grid, s);
-    } else if (BKsel == 32) {
-        if (BM == 128 && BN == 128) launch_variant<128, 128, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
-        else if (BM == 128)         launch_variant<128, 64, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
-        else                        launch_variant<64, 64, 32>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
     } else {
         if (BM == 128 && BN == 128) launch_variant<128, 128, 16>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);
         else if (BM == 128)         launch_variant<128, 64, 16>(p, a_kmajor, b_kmajor, vec, full, pipe, grid, s);

@@ -1,8 +1,9 @@
-// gemm_common.h -- parameter block and fused epilogue shared by the fp32 MFMA GEMM kernels (gemm.hip, gemm16.hip)
+// gemm_common.h -- parameter block and fused epilogues shared by the fp32 MFMA GEMM kernels (gemm.hip, gemm16.hip, gemm_nt16*.hip, gemm_q16*.hip)
 #pragma once
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define GEMM_BK_DEFAULT 16
 #ifndef GEMM_MIN_WAVES
@@ -353,13 +354,13 @@ __device__ __forceinline__ void tile_of_workgroup(const GemmParams& p, int bid, 
 
 // launcher of the 16x16x4-MFMA kernels (gemm16.hip); tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  FULL shapes only.
 void launch_sgemm16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
-// NT-only kernels with K-contiguous swizzled LDS image and ds_read_b128 operand fetch (gemm16.hip)
+// NT-only kernels with K-contiguous swizzled LDS image and ds_read_b128 operand fetch (gemm_nt16.hip)
 void launch_sgemm_nt16(const GemmParams& p, int tile, dim3 grid, hipStream_t s);
-// NT kernels with 32-deep K tiles (gemm16.hip): tile 0 = 128x128, 1 = 128x64; full tiles only
+// NT kernels with 32-deep K tiles (gemm_nt16.hip): tile 0 = 128x128, 1 = 128x64; full tiles only
 void launch_sgemm_nt32(const GemmParams& p, int tile, dim3 grid, hipStream_t s);
-// quad-fragment kernels for the NN / TN layouts (gemm16.hip): tile 0 = 128x128, 1 = 64x128 (NN only); false = no such kernel
+// quad-fragment kernels for the NN / TN layouts (gemm_q16.hip): tile 0 = 128x128, 1 = 64x128 (NN only); false = no such kernel
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
-// NT kernels with fused producer / consumer passes (gemm16.hip); fx_mask = FX_* bits; tile 0 = 128x128, 1 = 128x64.  false = no such kernel
+// NT kernels with fused producer / consumer passes (gemm_nt16_fx.hip); fx_mask = FX_* bits; tile 0 = 128x128, 1 = 128x64.  false = no such kernel
 bool launch_sgemm_nt16_fx(const GemmParams& p, int tile, int fx_mask, dim3 grid, hipStream_t s);
-// quad-fragment 128x128 kernels with fused passes: TN with FX_AFFINE_B (+ FX_SCATTER_A), NN with FX_SCATTER_A and / or FX_SCATTER_EPI
+// quad-fragment 128x128 kernels with fused passes (gemm_q16_fx.hip): TN with FX_AFFINE_B (+ FX_SCATTER_A), NN with FX_SCATTER_A and / or FX_SCATTER_EPI
 bool launch_sgemm_q16_fx(const GemmParams& p, int a_kmajor, int fx_mask, dim3 grid, hipStream_t s);

@@ -148,7 +148,9 @@ int act_sgemm_tn_grouped_f32(const act_gemm_tn_problem_t* probs, int nprob, int 
  *        generated while it is staged (A may be NULL, lda = C) -- for the input gradient (1,0: rows r = M, c = K) and the weight gradient
  *        (0,0: r = K, c = M) of the conv in front of the pool, so the scattered [R][C] gradient tensor never exists;  ep_src / ep_arg
  *        [M/group][N] (nullable pair, (1,0) only): C[r][c] += ep_arg[r/group][c] == r % group ? ep_src[r/group][c] : 0 in the epilogue (the
- *        second path into the tensor in front of the first pool).  group 32 | 64, M % 128 == 0, N % 128 == 0, C % 4 == 0. */
+ *        second path into the tensor in front of the first pool).  group 32 | 64, M % 128 == 0, N % 128 == 0, C % 4 == 0.
+ * The epilogue of a fused launch takes alpha / bias / rowscale / res (incl. res_row_div) / accumulate but NO activation (epi->act must be
+ * ACT_EPI_NONE, else ACT_E_BADARG): the mini-PointNet applies BatchNorm + ReLU while the NEXT layer stages its operand. */
 typedef struct {
     const float *a_scale, *a_shift, *b_scale, *b_shift;
     float*   tile_stats;
