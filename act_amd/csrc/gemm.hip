@@ -444,11 +444,11 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     const bool nt16p = tile == 17 || tile == 18;
     const int nt16p_tile = tile == 17 ? 3 : 4;
     if (nt16p) { if (!(a_kmajor && b_kmajor)) return ACT_E_BADARG; tile = tile == 17 ? 1 : 2; }
-    // tiles 13 (128x128), 14 (64x128), 15 (64x64), 16 (128x64): quad-fragment kernels of the NN / TN layouts (gemm16.hip); 14..16 NN only
+    // tiles 13 (128x128), 14 (64x128), 15 (64x64), 16 (128x64): quad-fragment kernels of the NN / TN layouts (gemm_q16.hip); 14..16 NN only
     const bool q16 = tile >= 13 && tile <= 16;
     const int q16_tile = tile - 13;
     if (q16) { if (b_kmajor || (tile != 13 && !a_kmajor)) return ACT_E_BADARG; tile = tile == 13 ? 1 : 0; }
-    const bool nt16 = tile >= 10 && tile <= 12;         // tiles 10..12 = tiles 1..3, NT-only b128-fragment kernel (gemm16.hip)
+    const bool nt16 = tile >= 10 && tile <= 12;         // tiles 10..12 = tiles 1..3, NT-only b128-fragment kernel (gemm_nt16.hip)
     if (nt16) { if (!(a_kmajor && b_kmajor)) return ACT_E_BADARG; tile -= 9; }
     const bool mi16 = tile >= 7 && tile <= 9;           // tiles 7..9 = tiles 1..3 on v_mfma_f32_16x16x4_f32 (gemm16.hip)
     if (mi16) tile -= 6;

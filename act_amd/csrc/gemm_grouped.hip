@@ -6,7 +6,7 @@
 // per block for 6.3 GFLOP.  Here the work items of all problems of a group form ONE grid -- (problem, 128x128 tile, K range) -- with the problem
 // table passed by value in the kernel arguments (no device-side table to upload: the call stays allocation- and copy-free), and ONE reduction
 // launch folds the K-range partials of every product and of every bias in a fixed order (deterministic).
-//   * main loop: the quad-fragment TN loop of sgemm_q16_kernel<128, 128, false, false> (gemm16.hip) -- same products in the same order, so with
+//   * main loop: the quad-fragment TN loop of sgemm_q16_kernel<128, 128, false, false> (gemm_q16_kernel.h) -- same products in the same order, so with
 //     the same split factor the result is bit-identical to act_sgemm_ex_f32(tile 13, splits);
 //   * db: the workgroups of tile column 0 add up the dY rows they stage anyway (the A operand passes through their registers on its way to
 //     LDS): a thread sums its k-rows of every K-tile, eight thread-rows are folded through LDS in a fixed order -> one [128] partial per
