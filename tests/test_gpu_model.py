@@ -137,8 +137,9 @@ def test_stage2_tiny_vs_oracle_all_draws_active(dev):
             assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
 
 
-def test_stage2_full_geometry_vs_oracle(dev):
-    """configs[1] geometry (N=1024, G=64, M=32, d=384 x 12, ViT-B teacher) at B=2 against the CPU oracle."""
+@pytest.mark.parametrize("B", [2, 8])
+def test_stage2_full_geometry_vs_oracle(dev, B):
+    """configs[1] geometry (N=1024, G=64, M=32, d=384 x 12, ViT-B teacher) at B = 2 and B = 8 against the CPU oracle."""
     from oracle import models as OM, layers as OL
     from act_amd.models import build_model_from_cfg
     from act_amd.utils.config import cfg_from_yaml_file
@@ -150,7 +151,7 @@ def test_stage2_full_geometry_vs_oracle(dev):
     model = build_model_from_cfg(cfg)
     model.load_state_dict(oracle.state_dict(), strict=True)
     model.to(dev).train()
-    pts = torch.from_numpy(clouds(6, 2, 1024))
+    pts = torch.from_numpy(clouds(6, B, 1024))
     rec = OL.Draws(record=True)
     lo = oracle(pts, rec); lo.backward()
     lg = model(pts.to(dev), draws=Draws(rec.table, device=dev)); lg.backward()
