@@ -364,7 +364,7 @@ std::mutex g_tune_mu;
 std::unordered_map<TuneKey, std::pair<int, int>, TuneHash> g_tune;
 }  // namespace
 extern "C" int act_gemm_tune_set(int ak, int bk, int M, int N, int K, int tile, int splits) {
-    if (tile < 0 || tile > 21 || splits < 0) return ACT_E_BADARG;
+    if (tile < 0 || (tile > 21 && (tile < 30 || tile > 32)) || splits < 0) return ACT_E_BADARG;
     std::lock_guard<std::mutex> g(g_tune_mu);
     g_tune[TuneKey{ak != 0, bk != 0, M, N, K}] = {tile, splits};
     return 0;
@@ -436,6 +436,10 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
             if (nb * sp >= 1024) break;
         }
     }
+    // tiles 30 (128x128), 31 (128x64), 32 (64x64): NT kernels with the hand-scheduled main loop (gemm_nt_asm_kernel.h); bit-identical to 10 / 11 / 12
+    const bool nta = tile >= 30 && tile <= 32;
+    const int nta_tile = tile - 30;
+    if (nta) { if (!(a_kmajor && b_kmajor)) return ACT_E_BADARG; tile -= 29; }
     // tiles 20 (128x128), 21 (128x64): NT b128 kernels with 32-deep K tiles (full tiles, K per split % 32 == 0); bit-identical to 10 / 11
     const bool nt32 = tile == 20 || tile == 21;
     const int nt32_tile = tile - 20;
@@ -482,7 +486,11 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     const bool full = vec && (M % BM == 0) && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
     // 16x16x4 kernels also take an M tail when A is K-major (rows = tokens): rows clamped on load, guarded on store
     const bool full_mtail = vec && a_kmajor && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
-    if (nt32) {
+    if (nta) {
+        if (!(full || full_mtail)) return ACT_E_BADARG;
+        if ((long long)BM * lda * 4 >= (1ll << 31) || (long long)BN * ldb * 4 >= (1ll << 31)) return ACT_E_BADARG;     // 32-bit lane offsets inside a tile
+        launch_sgemm_nt_asm(p, nta_tile, grid, s);
+    } else if (nt32) {
         if (!full) return ACT_E_BADARG;
         launch_sgemm_nt32(p, nt32_tile, grid, s);
     } else if (nt16p) {

@@ -15,6 +15,102 @@
 // tensor never exists in HBM); FX_COLSTATS leaves per-tile column (mean, sum of squared deviations) of the stored values for the
 // following BatchNorm (no statistics pass over the output); FX_GROUPMAX reduces every `group` consecutive rows to their max / first
 // arg-max (the max-pool over the points of a group) in the epilogue; FX_NOSTORE drops the C store when only that max is wanted.
+// ---- consumer passes of the fused mini-PointNet variants, after the epilogue (acc holds the values as stored: epilogue_rows<KEEP>): shared by the
+// compiler-scheduled kernel below and the hand-scheduled one (gemm_nt_asm_kernel.h).  `red`: >= 2 * BN floats of LDS no wave still reads.
+template <int BM, int BN, int FX, typename Acc>
+__device__ __forceinline__ void nt_fx_tail(const GemmParams& p, Acc& acc, float* red, const int tile_m, const int m0, const int n0,
+                                           const int wm, const int wn, const int ml, const int kl) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    const int cw = wn * (BN / 2) + TN * ml;                           // + j: this lane's columns inside the tile (B rows are staged permuted)
+
+    if constexpr ((FX & FX_GROUPMAX) != 0) {
+        // max + first arg-max over every `group` consecutive rows (torch.max(feature, dim=2) over the points of a group,
+        // models/dvae.py:211,214).  A wave owns 64 rows = two groups of 32 or one of 64: no cross-wave step.
+        const int group = p.fx.group;                                 // 32 or 64
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + cw + j;
+            float hb[2]; int hi[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                             // half of the wave's rows: blocks 2h, 2h+1
+                float best = acc[2 * h][j][0]; int bi = 4 * kl;       // local row within the half
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[2 * h + ii][j][r]; const int idx = ii * 16 + 4 * kl + r;
+                        if (v > best) { best = v; bi = idx; }         // ascending idx in-lane: strict '>' keeps the first maximum
+                    }
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {            // across the four 16-lane rows (kl): lowest index wins ties
+                    const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                hb[h] = best; hi[h] = bi;
+            }
+            if (kl == 0) {
+                if (group == 32) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const size_t g = (size_t)(m0 + wm * 64 + h * 32) / 32;
+                        p.fx.gmax[g * p.N + col] = hb[h];
+                        if (p.fx.garg) p.fx.garg[g * p.N + col] = hi[h];
+                    }
+                } else {                                              // one group of 64 rows: the first half wins ties
+                    const bool second = hb[1] > hb[0];
+                    const size_t g = (size_t)(m0 + wm * 64) / 64;
+                    p.fx.gmax[g * p.N + col] = second ? hb[1] : hb[0];
+                    if (p.fx.garg) p.fx.garg[g * p.N + col] = second ? hi[1] + 32 : hi[0];
+                }
+            }
+        }
+    }
+    if constexpr ((FX & FX_COLSTATS) != 0) {
+        // per-tile column mean and sum of squared deviations over the tile's 128 rows (two passes over the accumulators, so no
+        // E[x^2] - E[x]^2 cancellation); bn_tiles_finalize merges the tiles_m partials of a column in a fixed order
+        __syncthreads();                                              // the staging LDS is free now: [2 wm][BN] exchange buffer
+        float csum[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+            csum[j] = s;
+            if (kl == 0) red[wm * BN + cw + j] = s;
+        }
+        __syncthreads();
+        float mean[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = cw + j;
+            mean[j] = (red[c] + red[BN + c]) * (1.0f / BM);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; q += d * d; }
+            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
+            if (kl == 0) red[wm * BN + cw + j] = q;
+        }
+        __syncthreads();
+        if (wm == 0 && kl == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int c = cw + j;
+                float* ts = p.fx.tile_stats + (size_t)tile_m * 2 * p.N + n0 + c;
+                ts[0] = mean[j];
+                ts[p.N] = red[c] + red[BN + c];
+            }
+        }
+        (void)csum;
+    }
+}
+
 #ifndef NT16_OCC_SMALL
 #define NT16_OCC_SMALL 3
 #endif
@@ -187,94 +283,6 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
     }
     if constexpr (FX == 0) return;
     if (p.partial) return;
-    const int cw = wn * (BN / 2) + TN * ml;                           // + j: this lane's columns inside the tile (B rows are staged permuted)
-
-    if constexpr ((FX & FX_GROUPMAX) != 0) {
-        // max + first arg-max over every `group` consecutive rows (torch.max(feature, dim=2) over the points of a group,
-        // models/dvae.py:211,214).  A wave owns 64 rows = two groups of 32 or one of 64: no cross-wave step.
-        const int group = p.fx.group;                                 // 32 or 64
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + cw + j;
-            float hb[2]; int hi[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {                             // half of the wave's rows: blocks 2h, 2h+1
-                float best = acc[2 * h][j][0]; int bi = 4 * kl;       // local row within the half
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc[2 * h + ii][j][r]; const int idx = ii * 16 + 4 * kl + r;
-                        if (v > best) { best = v; bi = idx; }         // ascending idx in-lane: strict '>' keeps the first maximum
-                    }
-#pragma unroll
-                for (int off = 16; off <= 32; off <<= 1) {            // across the four 16-lane rows (kl): lowest index wins ties
-                    const float ov = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
-                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-                }
-                hb[h] = best; hi[h] = bi;
-            }
-            if (kl == 0) {
-                if (group == 32) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const size_t g = (size_t)(m0 + wm * 64 + h * 32) / 32;
-                        p.fx.gmax[g * p.N + col] = hb[h];
-                        if (p.fx.garg) p.fx.garg[g * p.N + col] = hi[h];
-                    }
-                } else {                                              // one group of 64 rows: the first half wins ties
-                    const bool second = hb[1] > hb[0];
-                    const size_t g = (size_t)(m0 + wm * 64) / 64;
-                    p.fx.gmax[g * p.N + col] = second ? hb[1] : hb[0];
-                    if (p.fx.garg) p.fx.garg[g * p.N + col] = second ? hi[1] + 32 : hi[0];
-                }
-            }
-        }
-    }
-    if constexpr ((FX & FX_COLSTATS) != 0) {
-        // per-tile column mean and sum of squared deviations over the tile's 128 rows (two passes over the accumulators, so no
-        // E[x^2] - E[x]^2 cancellation); bn_tiles_finalize merges the tiles_m partials of a column in a fixed order
-        __syncthreads();                                              // As is free now: [2 wm][BN] exchange buffer
-        float* red = &As[0][0];
-        float csum[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-            s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-            csum[j] = s;
-            if (kl == 0) red[wm * BN + cw + j] = s;
-        }
-        __syncthreads();
-        float mean[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int c = cw + j;
-            mean[j] = (red[c] + red[BN + c]) * (1.0f / BM);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = acc[i][j][r] - mean[j]; q += d * d; }
-            q += __shfl_xor(q, 16); q += __shfl_xor(q, 32);
-            if (kl == 0) red[wm * BN + cw + j] = q;
-        }
-        __syncthreads();
-        if (wm == 0 && kl == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int c = cw + j;
-                float* ts = p.fx.tile_stats + (size_t)tile_m * 2 * p.N + n0 + c;
-                ts[0] = mean[j];
-                ts[p.N] = red[c] + red[BN + c];
-            }
-        }
-        (void)csum;
-    }
+    nt_fx_tail<BM, BN, FX>(p, acc, &As[0][0], tile_m, m0, n0, wm, wn, ml, kl);
 }
 

@@ -211,7 +211,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    parts = [HEADER, gen_function(4, 4), "", gen_function(4, 2), ""]
+    parts = [HEADER, gen_function(4, 4), "",
+             gen_function(4, 2, opt=dict(w_step=1, l_step=1)), "",
+             gen_function(2, 2, opt=dict(r1_step=1, w_step=1, l_step=1, tail=6)), ""]
     with open(os.path.join(here, "gemm_nt_asm_loop.h"), "w") as f:
         f.write("\n".join(parts))
 

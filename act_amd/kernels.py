@@ -238,6 +238,7 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1, trace=None):
             cands += [(tile + 6, s) for s in sp_list if K % 32 == 0]                  # v_mfma_f32_16x16x4_f32 main loop
             if ak and bk:
                 cands += [(tile + 9, s) for s in sp_list if K % 32 == 0]              # NT: K-contiguous LDS image, b128 fragments
+                cands += [(29 + tile, s) for s in sp_list if K % 32 == 0]             # NT: the hand-scheduled main loop (30: 128x128, 31: 128x64, 32: 64x64)
                 if tile in (1, 2) and M % bm == 0:                                            # ... with 32-deep K tiles (20: 128x128, 21: 128x64): full 128-byte rows per load
                     cands += [(19 + tile, s) for s in sp_list if K % 32 == 0]
                 if tile == 1 and M % bm == 0 and K >= 1536:                                   # ... with the software-pipelined main loop (17: 128x128; 18 = 128x64

@@ -863,7 +863,37 @@ def test_nt_kernel_with_32_deep_k_tiles_is_bit_identical(K, M, N, Kd, sp):
         assert torch.equal(K.gemm(a, b, True, True, bias=bias, cfg=(t32, sp)), K.gemm(a, b, True, True, bias=bias, cfg=(t16, sp))), (t32, sp)
 
 
-@pytest.mark.parametrize("tile,ak,bk", [(10, 1, 1), (11, 1, 1), (12, 1, 1), (21, 1, 1), (13, 1, 0), (14, 1, 0), (13, 0, 0), (7, 1, 0), (3, 1, 1)])
+@pytest.mark.parametrize("tile,base", [(30, 10), (31, 11), (32, 12)])
+def test_nt_hand_scheduled_loop_is_bit_identical(K, tile, base):
+    """tiles 30 / 31 / 32 (gemm_nt_asm_kernel.h: the K loop as one hand-scheduled asm statement, 32-deep K tiles) execute the products of tiles
+    10 / 11 / 12 in the same order: bit-identical for 1, 2, 3 (tail paths), 4, 5 ... 96 K-tiles, with split-K, with an M tail (rows clamped on
+    load, guarded on store), with every fused epilogue and on row-strided operands."""
+    for (M, N, Kd) in [(256, 256, 32), (256, 128, 64), (128, 256, 96), (384, 128, 128), (256, 256, 160), (512, 384, 1024), (1024, 768, 3072),
+                       (2080, 384, 384), (65, 128, 192), (1792, 1152, 384)]:
+        a = _rnd(f"nta.a{M}.{Kd}", M, Kd).cuda(); b = _rnd(f"nta.b{N}.{Kd}", N, Kd).cuda()
+        for sp in (1, 2, 3):
+            if Kd // sp < 32:
+                continue
+            assert torch.equal(K.gemm(a, b, True, True, cfg=(tile, sp)), K.gemm(a, b, True, True, cfg=(base, sp))), (tile, M, N, Kd, sp)
+        bias = _rnd(f"nta.bias{N}", N).cuda(); res = _rnd(f"nta.res{M}.{N}", M, N).cuda()
+        for act in (K.EPI_NONE, K.EPI_GELU, K.EPI_RELU):
+            assert torch.equal(K.gemm(a, b, True, True, bias=bias, res=res, act=act, cfg=(tile, 1)),
+                               K.gemm(a, b, True, True, bias=bias, res=res, act=act, cfg=(base, 1))), (tile, M, N, Kd, act)
+    a = _rnd("nta.a", 512, 1024).cuda(); b = _rnd("nta.b", 384, 1024).cuda()
+    assert _rel(K.gemm(a, b, True, True, cfg=(tile, 1)), a.double().cpu() @ b.double().cpu().t()) <= 2e-5
+    wide_a = _rnd("nta.wa", 512, 1024 + 64).cuda(); wide_b = _rnd("nta.wb", 384, 1024 + 32).cuda()       # row-strided views (lda != K)
+    assert torch.equal(K.gemm(wide_a[:, 32:32 + 1024], wide_b[:, :1024], True, True, cfg=(tile, 1)),
+                       K.gemm(wide_a[:, 32:32 + 1024], wide_b[:, :1024], True, True, cfg=(base, 1)))
+    guard = torch.full((2080 + 64, 384), 7.0, device="cuda")                                             # the M tail never writes past row M
+    K.gemm(_rnd("nta.a2080.384", 2080, 384).cuda(), _rnd("nta.b384.384", 384, 384).cuda(), True, True, out=guard[:2080], cfg=(tile, 1))
+    assert torch.all(guard[2080:] == 7.0)
+    with pytest.raises(Exception):                         # K ranges must be multiples of 32
+        K.gemm(_rnd("nta.t", 256, 48).cuda(), _rnd("nta.u", 128, 48).cuda(), True, True, cfg=(tile, 1))
+    with pytest.raises(Exception):                         # NT only
+        K.gemm(a, b.t().contiguous(), True, False, cfg=(tile, 1))
+
+
+@pytest.mark.parametrize("tile,ak,bk", [(10, 1, 1), (11, 1, 1), (12, 1, 1), (21, 1, 1), (30, 1, 1), (31, 1, 1), (32, 1, 1), (13, 1, 0), (14, 1, 0), (13, 0, 0), (7, 1, 0), (3, 1, 1)])
 def test_gemm_epilogue_scalar_fallback_matches_the_vector_path(K, tile, ak, bk):
     """the vector epilogue (float4 / float2 accesses of C, bias, residual, aux: gemm_common.h::epilogue_rows) needs 16-byte aligned pointers and
     leading dimensions % 4 == 0; anything else takes the scalar accesses of the same code.  C-ABI level: C / bias / residual / aux shifted by one
