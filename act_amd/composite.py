@@ -71,6 +71,7 @@ _SIGS = {
     "act_gemm_tune_set": [_i] * 7,
     "act_gemm_tune_get": [_i] * 5 + [_P(_i), _P(_i)],
     "act_gemm_tune_clear": [],
+    "act_gemm_fx_asm": [_i],
     "act_composite_collect_begin": [],
     "act_composite_collect_end": [_P(_i), _i],
     "act_composite_shutdown": [],
@@ -143,7 +144,7 @@ def _tune_shape(ak, bk, M, N, Kd, device):
             return False
         a = torch.randn((M, Kd) if ak else (Kd, M), dtype=torch.float32, device=device)
         b = torch.randn((N, Kd) if bk else (Kd, N), dtype=torch.float32, device=device)
-        cfg, _ = K.gemm_tune(a, b, ak, bk, M, N, Kd, K.workspace(device))
+        cfg = K.first_use_config(a, b, ak, bk, M, N, Kd, K.workspace(device))
         K._NEW_TUNED[key[:5]] = cfg
     K._GEMM_CACHE[key] = cfg
     lib.act_gemm_tune_set(ak, bk, M, N, Kd, int(cfg[0]), int(cfg[1]))

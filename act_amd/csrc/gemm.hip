@@ -527,6 +527,14 @@ extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, co
 }
 
 
+// the fused NT launches CAN run on the hand-scheduled main loop (K % 32 == 0; bit-identical: tests/test_gpu_dense.py).  Default OFF: measured in the
+// Stage-II step (profiles/r04_fx_asm_ab.txt) conv4 (K = 512, affine + group max) 804 -> 800 us, but conv3 (K = 256, column statistics) 673 -> 723 us and
+// conv2 (K = 128) 195 -> 227 us -- with 4-8 K tiles per output tile the launch is prologue / epilogue bound and three 32 KB workgroups per CU overlap
+// those better than two 64-72 KB ones.  act_gemm_fx_asm(1) / ACT_GEMM_FX_ASM=1 selects them.
+#include <atomic>
+static std::atomic<int> g_fx_asm{[] { const char* e = getenv("ACT_GEMM_FX_ASM"); return e ? atoi(e) : 0; }()};
+extern "C" int act_gemm_fx_asm(int on) { return on < 0 ? g_fx_asm.load() : g_fx_asm.exchange(on != 0); }
+
 // ---- GEMM with fused producer / consumer passes (mini-PointNet, see GemmFx in gemm_common.h) ---------------------------------------
 extern "C" size_t act_sgemm_fx_tile_stats_floats(int M, int N) { return (size_t)((M + 127) / 128) * 2 * N; }
 
@@ -571,7 +579,9 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         const int tile = (N % 128 == 0) ? 0 : 1, BN = tile == 0 ? 128 : 64;
         p.tiles_m = M / 128; p.tiles_n = N / BN; p.k_per_split = K; p.partial = nullptr;
         ActProfScope ps(KID_GEMM_NT, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + ((mask & FX_NOSTORE) ? 0.0 : (double)M * N)));
-        if (!launch_sgemm_nt16_fx(p, tile, mask, dim3((unsigned)(p.tiles_m * p.tiles_n)), s)) return ACT_E_BADARG;
+        // hand-scheduled main loop when every K tile is 32 deep (ACT_GEMM_FX_ASM=0: the compiler-scheduled kernels, for A/B runs); same bits either way
+        const dim3 fgrid((unsigned)(p.tiles_m * p.tiles_n));
+        if (!(g_fx_asm.load() && launch_sgemm_nt_asm_fx(p, tile, mask, fgrid, s)) && !launch_sgemm_nt16_fx(p, tile, mask, fgrid, s)) return ACT_E_BADARG;
         ACT_LAUNCH_CHECK();
         return 0;
     }

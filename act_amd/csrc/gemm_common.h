@@ -364,5 +364,7 @@ void launch_sgemm_nt_asm(const GemmParams& p, int tile, dim3 grid, hipStream_t s
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
 // NT kernels with fused producer / consumer passes (gemm_nt16_fx.hip); fx_mask = FX_* bits; tile 0 = 128x128, 1 = 128x64.  false = no such kernel
 bool launch_sgemm_nt16_fx(const GemmParams& p, int tile, int fx_mask, dim3 grid, hipStream_t s);
+// ... the same on the hand-scheduled main loop (gemm_nt_asm_fx.hip; additionally K % 32 == 0): bit-identical to launch_sgemm_nt16_fx
+bool launch_sgemm_nt_asm_fx(const GemmParams& p, int tile, int fx_mask, dim3 grid, hipStream_t s);
 // quad-fragment 128x128 kernels with fused passes (gemm_q16_fx.hip): TN with FX_AFFINE_B (+ FX_SCATTER_A), NN with FX_SCATTER_A and / or FX_SCATTER_EPI
 bool launch_sgemm_q16_fx(const GemmParams& p, int a_kmajor, int fx_mask, dim3 grid, hipStream_t s);

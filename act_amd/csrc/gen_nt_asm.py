@@ -23,7 +23,7 @@ S_A, S_B, S_CNT = 60, 62, 64          # pinned SGPRs: A base (pair), B base (pai
 
 
 class Regs:
-    def __init__(self, TM, TN):
+    def __init__(self, TM, TN, affine=False):
         self.TM, self.TN = TM, TN
         n = 0
         self.acc = n; n += TM * TN * 4
@@ -39,6 +39,11 @@ class Regs:
         self.wbb = n; n += 1
         self.ra = n; n += 1
         self.rb = n; n += 1
+        self.sc = self.sh = self.sx = -1
+        if affine:                       # A-side affine map: scale / shift of this thread's four k (one float4 each per K tile), their LDS address
+            self.sc = n; n += 4
+            self.sh = n; n += 4
+            self.sx = n; n += 1
         self.total = n
 
 
@@ -47,7 +52,8 @@ def vr(base, n=4):
 
 
 def gen_loop(TM, TN, opt):
-    R = Regs(TM, TN)
+    affine = bool(opt.get("affine"))
+    R = Regs(TM, TN, affine)
     NM = TM * TN
     BM, BN = 32 * TM, 32 * TN
     A_KG = BM * 64                      # bytes of one 16-deep A sub-tile
@@ -111,15 +117,32 @@ def gen_loop(TM, TN, opt):
         emit(f"; ---- iteration: stage {stage}, {kind}")
         # phase A
         fa = {}
-        place(fa, reads(1, stage, 1), opt["r1_start"], opt["r1_step"])
+        k = place(fa, reads(1, stage, 1), opt["r1_start"], opt["r1_step"])
+        if affine and kind != "last":    # scale / shift of the four k this thread stages in tile t+1 (sx points at them), then sx -> tile t+2
+            place(fa, [f"ds_read_b128 {vr(R.sc)}, v{R.sx}", f"ds_read_b128 {vr(R.sh)}, v{R.sx} offset:4096", f"v_add_u32 v{R.sx}, 128, v{R.sx}"], k, 1)
         emit("s_waitcnt lgkmcnt(0)")
         phase(0, fa)
         # phase B
         fb = {}
         if kind != "last":
             w = writes(stage ^ 1)
-            items = [["s_waitcnt vmcnt(0)", w[0]]] + [[x] for x in w[1:]]
-            k = place(fb, items, opt["w_start"], opt["w_step"])
+            if affine:                   # A' = max(0, A * scale + shift) on the staging registers (v_fma_f32 + v_max_f32: what hipcc emits for the compiler loop), B untouched
+                wa, wbw = w[:TM], w[TM:]
+                ops = []
+                for i in range(TM):
+                    regs = [R.sa + 4 * i + c for c in range(4)]
+                    ops += [f"v_fma_f32 v{r}, v{r}, v{R.sc + c}, v{R.sh + c}" for c, r in enumerate(regs)]
+                    ops += [f"v_max_f32_e32 v{r}, 0, v{r}" for r in regs]
+                    if i < len(wbw): ops.append(wbw[i])
+                    ops.append(wa[i])
+                ops += wbw[TM:]
+                per = opt.get("affine_per_gap", 2)
+                items = [ops[q:q + per] for q in range(0, len(ops), per)]
+                items[0] = ["s_waitcnt vmcnt(0)"] + items[0]
+                k = place(fb, items, opt["w_start"], 1)
+            else:
+                items = [["s_waitcnt vmcnt(0)", w[0]]] + [[x] for x in w[1:]]
+                k = place(fb, items, opt["w_start"], opt["w_step"])
             if kind == "full":
                 l = loads()
                 k = place(fb, [advance() + [l[0]]] + [[x] for x in l[1:]], k, opt["l_step"])
@@ -176,12 +199,13 @@ def gen_function(TM, TN, suffix="", opt=None):
     o = dict(DEFAULT_OPT)
     if opt: o.update(opt)
     R, lines = gen_loop(TM, TN, o)
+    affine = bool(o.get("affine"))
     name = f"nt_asm_loop_{TM}x{TN}{suffix}"
     vt = {1: "unsigned", 2: "u32x2", 4: "u32x4"}
     text = []
     text.append(f"// wave tile {16 * TM} x {16 * TN} (workgroup {32 * TM} x {32 * TN}), {R.total} VGPRs, LDS {2 * (32 * TM + 32 * TN) * 128} B; schedule {o}")
     text.append(f"__device__ __forceinline__ void {name}(f32x4 (&acc)[{TM}][{TN}], const float* pa, const float* pb, int ntiles,")
-    text.append(f"        {vt[TM]} offa, {vt[TN]} offb, unsigned wbase_a, unsigned wbase_b, unsigned rbase_a, unsigned rbase_b) {{")
+    text.append(f"        {vt[TM]} offa, {vt[TN]} offb, unsigned wbase_a, unsigned wbase_b, unsigned rbase_a, unsigned rbase_b" + (", unsigned sx" if affine else "") + ") {")
     text.append("    asm volatile(")
     for l in lines:
         text.append(f'        "{l}\\n"')
@@ -191,11 +215,12 @@ def gen_function(TM, TN, suffix="", opt=None):
             c = R.acc + 4 * (i * TN + j)
             outs.append(f'"={{v[{c}:{c + 3}]}}"(acc[{i}][{j}])')
     ios = [f'"+{{s[{S_A}:{S_A + 1}]}}"(pa)', f'"+{{s[{S_B}:{S_B + 1}]}}"(pb)', f'"+{{s{S_CNT}}}"(ntiles)']
+    if affine: ios.append(f'"+{{v{R.sx}}}"(sx)')
     text.append("        : " + ", ".join(outs) + ",")
     text.append("          " + ", ".join(ios))
     ins = [f'"{{{vr(R.offa, TM)}}}"(offa)', f'"{{{vr(R.offb, TN)}}}"(offb)', f'"{{v{R.wb}}}"(wbase_a)', f'"{{v{R.wbb}}}"(wbase_b)', f'"{{v{R.ra}}}"(rbase_a)', f'"{{v{R.rb}}}"(rbase_b)']
     text.append("        : " + ", ".join(ins))
-    clob = [f'"v{r}"' for r in range(R.fa[0], R.offa)]
+    clob = [f'"v{r}"' for r in range(R.fa[0], R.offa)] + ([f'"v{r}"' for r in range(R.sc, R.sx)] if affine else [])
     text.append("        : " + ", ".join(clob) + ', "scc", "memory");')
     text.append("}")
     return "\n".join(text)
@@ -213,7 +238,9 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     parts = [HEADER, gen_function(4, 4), "",
              gen_function(4, 2, opt=dict(w_step=1, l_step=1)), "",
-             gen_function(2, 2, opt=dict(r1_step=1, w_step=1, l_step=1, tail=6)), ""]
+             gen_function(2, 2, opt=dict(r1_step=1, w_step=1, l_step=1, tail=6)), "",
+             gen_function(4, 4, "_affine", opt=dict(affine=1, l_step=1)), "",
+             gen_function(4, 2, "_affine", opt=dict(affine=1, l_step=1, affine_per_gap=3)), ""]
     with open(os.path.join(here, "gemm_nt_asm_loop.h"), "w") as f:
         f.write("\n".join(parts))
 

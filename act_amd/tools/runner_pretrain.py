@@ -62,17 +62,18 @@ class _Single(nn.Module):
 
 
 class _Announced:
-    """the batch that the previous train_step already augmented (in place) and announced to the teacher prefetch: a weak reference
-    plus the tensor version right after the augmentation, so the same tensor handed back as ``points`` is not augmented twice"""
-    ref, version = None, -1
+    """the batch that the previous train_step on THIS model already augmented (in place) and announced to the teacher prefetch: a weak
+    reference plus the tensor version right after the augmentation, kept on the model object (two models trained in one process do not
+    see each other's batches), so the same tensor handed back as ``points`` is not augmented twice"""
 
-    @classmethod
-    def mark(cls, t):
-        cls.ref, cls.version = weakref.ref(t), t._version
+    @staticmethod
+    def mark(model, t):
+        model.__dict__["_act_announced"] = (weakref.ref(t), t._version)
 
-    @classmethod
-    def is_marked(cls, t):
-        return cls.ref is not None and cls.ref() is t and cls.version == t._version
+    @staticmethod
+    def is_marked(model, t):
+        ref, version = model.__dict__.get("_act_announced", (None, -1))
+        return ref is not None and ref() is t and version == t._version
 
 
 def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, draws=None, next_points=None):
@@ -81,7 +82,8 @@ def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, 
     ``next_points`` (optional): the NEXT batch.  It is augmented here and announced to the model, which starts its grouping and
     frozen-teacher forward on the auxiliary stream while this batch's backward runs; pass that same tensor as ``points`` of the
     next call (it is not augmented twice)."""
-    if augment and not _Announced.is_marked(points):
+    inner = base_model.module if hasattr(base_model, "module") else base_model
+    if augment and not _Announced.is_marked(inner, points):
         points = train_transforms(points)
     loss = base_model(points, draws=draws) if draws is not None else base_model(points)
     if isinstance(loss, tuple):                      # ACT_PointBERT returns (moco, dvae, cutmix): summed (tools/runner_pretrain.py:140-142)
@@ -89,8 +91,7 @@ def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, 
     if next_points is not None:
         if augment:
             next_points = train_transforms(next_points)
-            _Announced.mark(next_points)
-        inner = base_model.module if hasattr(base_model, "module") else base_model
+            _Announced.mark(inner, next_points)
         if hasattr(inner, "prefetch_teacher"):
             inner.prefetch_teacher(next_points)
     loss.backward()

@@ -155,6 +155,30 @@ def cpu_group_baseline(B=128, N=1024, G=64, M=32, reps=3):
             "group_sample": f"Group(FPS {G} + kNN {M}) on {B} x {N} clouds, plain-C oracle, OpenMP over clouds ({os.cpu_count()} host cores visible)"}
 
 
+def other_workloads(timeout_s=150):
+    """python bench.py --stage 1 / --config c5 (10 / 6 timed steps, no instrumented pass, no CPU baseline) -> {name: {clouds_per_s, ms_per_step,
+    final_loss, steps, workload}}; a failure is reported in place of the numbers, never raised."""
+    import subprocess
+    res = {}
+    for name, extra in (("stage1", ["--stage", "1", "--steps", "10", "--warmup", "3"]), ("c5", ["--config", "c5", "--steps", "6", "--warmup", "2"])):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--no-instrument", "--no-other-workloads"] + extra
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                res[name] = {"failed": (r.stderr or r.stdout)[-300:], "wall_s": time.time() - t0}
+                continue
+            d = json.loads(line[-1])
+            res[name] = {"clouds_per_s": d["value"], "ms_per_step": d["ms_per_step"], "final_loss": d["config"]["final_loss"], "steps": d["steps"],
+                         "warmup": d["warmup"], "clouds_per_gpu": d["config"]["clouds_per_gpu"], "metric": d["metric"],
+                         "workload": d["config"]["workload"], "wall_s": time.time() - t0}
+        except Exception as e:
+            res[name] = {"failed": str(e)[-300:], "wall_s": time.time() - t0}
+    return res
+
+
 _NEXT = None
 
 
@@ -173,6 +197,8 @@ def main():
                          "(N=8192 pts, 512 groups x 64 nbrs, 24-layer d=768 student, B=32/GPU) -- stage 2 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the short configs[2] (Stage I) and configs[4] (C5 stress) timings that the default single-GPU run appends as other_workloads")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -433,6 +459,11 @@ def main():
         knn_b = (12.0 * N + 12.0 * G_ + 20.0 * G_ * M_) * B         # 54,016 (C2) / 759,808 (C5)
         out["group_fps_knn"] = {"Mpts_per_s": B * N / (gms * 1e-3) / 1e6, "ms": gms,
                                 "alg_GBs": (fps_b + knn_b) / (gms * 1e-3) / 1e9, "frac_hbm": (fps_b + knn_b) / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+
+    # ---- BASELINE configs[2] (Stage I, B=128) and configs[4] (C5 stress, B=32): short timings of the same bench in child processes, after the
+    # headline's timed region (this process is idle meanwhile) -- so the driver's own line carries them, not only profiles/.  ~20 s each.
+    if rank == 0 and world == 1 and args.stage == 2 and not c5 and args.batch == 128 and not args.no_other_workloads:
+        out["other_workloads"] = other_workloads()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.stage in (1, 2):
         try:

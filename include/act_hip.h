@@ -163,6 +163,9 @@ typedef struct {
     const int32_t* ep_arg;
 } act_gemm_fx_t;
 size_t act_sgemm_fx_tile_stats_floats(int M, int N);
+/* The (1,1) fused launches with K % 32 == 0 can run on the hand-scheduled main loop (csrc/gemm_nt_asm_kernel.h), bit-identical to the compiler-scheduled
+ * kernels.  on = 0 / 1 selects (returns the previous setting), on < 0 queries; initial value: env ACT_GEMM_FX_ASM (default 0: not faster at K <= 512). */
+int act_gemm_fx_asm(int on);
 int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                      const act_gemm_epilogue_t* epilogue, const act_gemm_fx_t* fx, float* workspace, size_t workspace_bytes, act_stream_t stream);
 /* BatchNorm (train mode) statistics from those tile partials: mean, rstd, scale = gamma*rstd, shift = beta - mean*scale, running stats updated

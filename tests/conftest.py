@@ -3,11 +3,10 @@ import sys
 import numpy as np
 import pytest
 
-# The GPU suite runs the PRODUCT default (ACT_GEMM_AUTOTUNE=1).  Run-to-run determinism does not come from switching the first-use autotuner
-# off but from the shipped table (act_amd/gemm_tune_gfx950.json), which lists every GEMM shape this suite and the benchmarked workloads launch
-# above the tuning threshold: a listed shape is never timed, so its launch configuration (= its fp32 summation order) is the same in every run
-# and every process.  pytest_sessionfinish below FAILS the session if a test still triggered a first-use tuning -- add the shape to the table
-# (ACT_GEMM_TUNE_SAVE=<file> dumps table + new winners at exit) instead of relying on a timing-dependent pick.
+# The GPU suite runs the PRODUCT default (ACT_GEMM_AUTOTUNE=1): shipped table (act_amd/gemm_tune_gfx950.json) first, and for a shape that is not
+# listed a first-use timing over candidates that are bit-identical to each other (kernels.stable_candidates: one tile family, one shape-determined
+# split-K; tests/test_gpu_dense.py::test_first_use_tuning_cannot_change_a_result_bit).  No result of the suite depends on a stopwatch, listed or not;
+# the end of the session only REPORTS the shapes that were tuned (add them to the table to skip their first-use timing).
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
@@ -20,16 +19,14 @@ def pytest_configure(config):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """no GEMM shape of the suite may depend on a timing-based first-use pick (see the note at the top of this file)"""
+    """report (never fail on) the GEMM shapes that were tuned on first use: their results are bit-stable by construction (see the note above)"""
     K = sys.modules.get("act_amd.kernels")
-    if K is None or os.environ.get("ACT_GEMM_TUNE_SAVE") or os.environ.get("ACT_TESTS_ALLOW_TUNING") == "1":
+    if K is None or os.environ.get("ACT_GEMM_TUNE_SAVE"):
         return
     new = getattr(K, "_NEW_TUNED", {})
     if new and K.AUTOTUNE:
-        sys.stderr.write("\n[conftest] %d GEMM shape(s) were auto-tuned during this session (not in act_amd/gemm_tune_gfx950.json): %s\n"
+        sys.stderr.write("\n[conftest] %d GEMM shape(s) not in act_amd/gemm_tune_gfx950.json were tuned on first use (bit-stable candidates only): %s\n"
                          % (len(new), sorted(new)[:20]))
-        if exitstatus == 0:
-            session.exitstatus = 1
 
 
 def golden(name):

@@ -266,10 +266,11 @@ def _rccl_worker(rank, world, port, out_dir):
 
 
 def test_product_model_under_rccl_ddp_world1_is_bit_identical(tmp_path):
-    """backend='nccl' (RCCL) at world size 1: RCCL's all-reduce is stream-ordered (its own stream, ordered against the compute streams by
-    events only), unlike gloo's host-staged copy which serialises everything -- so this is the single-GPU form of the race between DDP's
-    bucket hooks and auxiliary streams 0 (teacher prefetch) and 1 (weight gradients).  4 pipelined AdamW steps through wrap_ddp must equal
-    the _Single run bit for bit, with the default 25 MB buckets and with 50 KB buckets (reference: tools/runner_pretrain.py:84-93,159-167)."""
+    """backend='nccl' (RCCL) at world size 1: process-group initialisation over RCCL, the bucket views, the hook plumbing of wrap_ddp and the
+    runner's loss reduction.  It does NOT exercise stream ordering: RCCL launches no kernel for a one-rank in-place all-reduce (profiles/README.md),
+    so nothing reads a bucket here -- the test that does is test_ddp_buckets_are_final_when_a_stream_ordered_reader_takes_them below.
+    4 pipelined AdamW steps through wrap_ddp must equal the _Single run bit for bit, with the default 25 MB buckets and with 50 KB buckets
+    (reference: tools/runner_pretrain.py:84-93,159-167)."""
     assert torch.cuda.is_available()
     from act_amd.tools.runner_pretrain import _Single
     dev = torch.device("cuda:0")
@@ -285,3 +286,97 @@ def test_product_model_under_rccl_ddp_world1_is_bit_identical(tmp_path):
         for n, p in params.items():
             assert torch.equal(r["params" + tag][n], p), (tag, n)
     assert torch.equal(r["reduced"], losses)
+
+
+# ---- a comm hook that READS every bucket the way RCCL would: on its own stream, ordered after the hook's current stream by ONE event ----------------
+def _hook_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["ACT_GEMM_AUTOTUNE"] = "0"
+    os.environ["ACT_OVERLAP_TEACHER"] = "1"
+    os.environ["ACT_OVERLAP_DW"] = "1"
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import act_amd.kernels as K
+    import act_amd.models.act as AM
+    assert K.OVERLAP_DW and AM._OVERLAP_TEACHER              # auxiliary stream 0 (teacher prefetch) and 1 (weight gradients) are live
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import train_step
+    report = {}
+    for tag, cap in (("25mb", 25), ("50kb", 0.05)):
+        model = _model(dev)
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True,
+                                                         bucket_cap_mb=cap, find_unused_parameters=False)
+        side = torch.cuda.Stream()
+        taken = []                                           # (step, bucket index, parameter names, device copy made on `side`)
+        names = {id(p): n for n, p in model.named_parameters()}
+        step_no = [0]
+
+        def hook(state, bucket):
+            buf = bucket.buffer()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())           # what RCCL does: its stream waits for the stream the hook runs on -- and for nothing else
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                snap = buf.clone()
+            taken.append((step_no[0], bucket.index(), [names[id(p)] for p in bucket.parameters()], snap))
+            fut = torch.futures.Future()
+            fut.set_result(buf)
+            return fut
+
+        ddp.register_comm_hook(None, hook)
+        cfg = _cfg()
+        opt, _ = builder.build_opti_sche(ddp, cfg)
+        finals = {}
+
+        def before_step(optimizer, args, kwargs):            # every stream drained: these ARE the final gradients of the step
+            torch.cuda.synchronize()
+            finals[step_no[0]] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+        opt.register_step_pre_hook(before_step)
+        torch.manual_seed(123)
+        pts = _batches(20, dev)
+        losses = []
+        for i in range(STEPS):
+            step_no[0] = i
+            nxt = pts[i + 1] if i + 1 < STEPS else None
+            losses.append(train_step(ddp, opt, pts[i], cfg, next_points=nxt))
+        torch.cuda.synchronize()
+        bad, nb = [], 0
+        for step, idx, pnames, snap in taken:
+            want = torch.cat([finals[step][n].reshape(-1) for n in pnames])
+            nb += 1
+            if snap.numel() != want.numel() or not torch.equal(snap, want):
+                bad.append((step, idx, pnames[:3]))
+        report[tag] = {"buckets": nb, "bad": bad, "steps": sorted(finals), "losses": torch.stack(losses).cpu(),
+                       "params": {n: p.detach().clone().cpu() for n, p in model.named_parameters()}}
+    torch.save(report, os.path.join(out_dir, "hook.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_buckets_are_final_when_a_stream_ordered_reader_takes_them(tmp_path):
+    """The hazard the world-1 RCCL test cannot observe.  DDP hands a gradient bucket to its communication hook as soon as autograd has produced
+    the bucket's last gradient; RCCL then reads the bucket on ITS stream, ordered after the hook's current stream by one event.  The student's
+    weight-gradient GEMMs run on auxiliary stream 1 and the teacher prefetch on auxiliary stream 0 -- if a block's backward returned before
+    joining stream 1, the reader would see a stale bucket.  Here the hook is that reader: a device copy of bucket.buffer() on a side stream behind
+    one event, the bucket returned unchanged.  Over 4 pipelined AdamW steps (ACT_OVERLAP_TEACHER=1, ACT_OVERLAP_DW=1), with 25 MB and with
+    50 KB buckets, every copy must equal the step's final gradients (taken after a device-wide synchronise, before optimizer.step) bit for bit,
+    and the trajectory must equal the _Single run (reference: tools/runner_pretrain.py:84-93, utils/dist_utils.py:9-24)."""
+    assert torch.cuda.is_available()
+    from act_amd.tools.runner_pretrain import _Single
+    dev = torch.device("cuda:0")
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_hook_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "hook.pt")
+    with _fixed_gemm_configs():
+        model = _model(dev)
+        losses, params = _trajectory(_Single(model), model, seed=123, data_seed=20, dev=dev)
+    for tag in ("25mb", "50kb"):
+        assert r[tag]["steps"] == list(range(STEPS))
+        assert r[tag]["buckets"] >= STEPS and not r[tag]["bad"], (tag, r[tag]["buckets"], r[tag]["bad"][:5])
+        assert torch.equal(r[tag]["losses"], losses), tag
+        for n, p in params.items():
+            assert torch.equal(r[tag]["params"][n], p), (tag, n)
+    assert r["50kb"]["buckets"] > r["25mb"]["buckets"]              # the small cap really produced more buckets per step

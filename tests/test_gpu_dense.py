@@ -785,7 +785,7 @@ def test_gemm_autotuner_times_and_registers_a_config(K):
     a = _rnd("at.a", M, Kd).cuda(); b = _rnd("at.b", N, Kd).cuda()
     ws = K.workspace(a.device)
     (tile, sp), ms = K.gemm_tune(a, b, True, True, M, N, Kd, ws)
-    assert 1 <= tile <= 21 and sp >= 1 and 0 < ms < 10
+    assert 1 <= tile <= 32 and sp >= 1 and 0 < ms < 10
     assert _rel(K.gemm(a, b, True, True, cfg=(tile, sp)), a.double().cpu() @ b.double().cpu().t()) <= 2e-5
     saved = K.AUTOTUNE
     K.AUTOTUNE = True
@@ -893,6 +893,57 @@ def test_nt_hand_scheduled_loop_is_bit_identical(K, tile, base):
         K.gemm(a, b.t().contiguous(), True, False, cfg=(tile, 1))
 
 
+@pytest.mark.parametrize("R,N,Kd,group", [(1024, 256, 128, 32), (512, 384, 512, 32), (768, 192, 256, 64), (256, 512, 1024, 32), (384, 128, 32, 64), (256, 64, 96, 32)])
+def test_fused_nt_launches_on_the_hand_scheduled_loop_are_bit_identical(K, R, N, Kd, group):
+    """act_sgemm_fx_f32 (1,1): column statistics, A-side affine + ReLU on load, group max (+ arg-max), with and without the C store -- the launches
+    on the hand-scheduled main loop (default) against the compiler-scheduled kernels (act_gemm_fx_asm(0)) bit for bit, and against float64."""
+    import ctypes
+    import act_amd.composite as CP
+    a = _rnd(f"fxa.a{R}.{Kd}", R, Kd).cuda(); w = _rnd(f"fxa.w{N}.{Kd}", N, Kd).cuda()
+    bias = _rnd(f"fxa.b{N}", N).cuda()
+    sc = (_rnd(f"fxa.sc{Kd}", Kd).cuda() * 0.5 + 1.0); sh = _rnd(f"fxa.sh{Kd}", Kd).cuda() * 0.3
+    st = K.stream()
+    epi = K.GemmEpilogue(alpha=1.0, bias=bias.data_ptr())
+
+    def run(kind, asm):
+        prev = CP.lib.act_gemm_fx_asm(asm)
+        try:
+            fx = CP.GemmFx(); out = torch.full((R, N), 3.0, device="cuda")
+            res = [out]
+            if kind == "stats":
+                ts = torch.zeros(CP.lib.act_sgemm_fx_tile_stats_floats(R, N), device="cuda"); fx.tile_stats = ts.data_ptr(); res.append(ts)
+            else:
+                fx.a_scale = sc.data_ptr(); fx.a_shift = sh.data_ptr(); fx.group = group
+                gm = torch.zeros(R // group, N, device="cuda"); ga = torch.zeros(R // group, N, dtype=torch.int32, device="cuda")
+                fx.gmax = gm.data_ptr(); fx.garg = ga.data_ptr(); fx.store_c = 1 if kind == "affine_max" else 0
+                res += [gm, ga]
+            rc = CP.lib.act_sgemm_fx_f32(1, 1, R, N, Kd, a.data_ptr(), Kd, w.data_ptr(), Kd, out.data_ptr(), N, ctypes.byref(epi), ctypes.byref(fx),
+                                         None, 0, st)
+            assert rc == 0, (kind, asm, rc)
+            torch.cuda.synchronize()
+            return res
+        finally:
+            CP.lib.act_gemm_fx_asm(prev)
+
+    for kind in ("stats", "affine_max", "affine_max_nostore"):
+        r1, r0 = run(kind, 1), run(kind, 0)
+        for x, y in zip(r1, r0):
+            assert torch.equal(x, y), (kind, R, N, Kd)
+        ad = a.double().cpu()
+        if kind != "stats":
+            ad = torch.clamp_min(ad * sc.double().cpu() + sh.double().cpu(), 0.0)
+        ref = ad @ w.double().cpu().t() + bias.double().cpu()
+        if kind == "affine_max_nostore":
+            assert torch.all(r1[0] == 3.0)                                 # C untouched
+        else:
+            assert _rel(r1[0], ref) <= 2e-5
+        if kind == "stats":
+            ts = r1[1].view(R // 128, 2, N).double().cpu(); blocks = ref.view(R // 128, 128, N)
+            assert _rel(ts[:, 0], blocks.mean(1)) <= 2e-5 and _rel(ts[:, 1], ((blocks - blocks.mean(1, keepdim=True)) ** 2).sum(1)) <= 1e-4
+        else:
+            assert _rel(r1[1], ref.view(R // group, group, N).max(1)[0]) <= 2e-5
+
+
 @pytest.mark.parametrize("tile,ak,bk", [(10, 1, 1), (11, 1, 1), (12, 1, 1), (21, 1, 1), (30, 1, 1), (31, 1, 1), (32, 1, 1), (13, 1, 0), (14, 1, 0), (13, 0, 0), (7, 1, 0), (3, 1, 1)])
 def test_gemm_epilogue_scalar_fallback_matches_the_vector_path(K, tile, ak, bk):
     """the vector epilogue (float4 / float2 accesses of C, bias, residual, aux: gemm_common.h::epilogue_rows) needs 16-byte aligned pointers and
@@ -928,3 +979,49 @@ def test_gemm_epilogue_scalar_fallback_matches_the_vector_path(K, tile, ak, bk):
             assert torch.equal(c0, c1), (tile, act, use_res, row_div)
             assert torch.equal(x0, x1)
             assert c0.abs().max() > 0
+
+
+def test_first_use_tuning_cannot_change_a_result_bit(K):
+    """Product default (ACT_GEMM_AUTOTUNE=1): a shape in no table is timed over kernels.stable_candidates only -- one tile family at one
+    shape-determined split-K -- so whichever candidate the stopwatch prefers, the result is the same.  Every candidate of an unlisted NT, NN and
+    TN shape (incl. an M tail and a split-K case) gives torch.equal outputs; tuning the shape twice with the candidate order reversed (a different
+    winner is possible) gives torch.equal products; a shape no fast family serves is not timed at all."""
+    ws = K.workspace(torch.device("cuda:0"))
+    assert K.AUTOTUNE and not K.AUTOTUNE_FULL
+    cases = [(True, True, 1344, 384, 1536), (True, True, 6144, 768, 768), (True, True, 2080, 1152, 384),
+             (True, False, 1344, 384, 1536), (True, False, 6144, 768, 768), (False, False, 384, 1536, 6144)]
+    for ak, bk, M, N, Kd in cases:
+        a = _rnd(f"st.a{M}.{Kd}", *((M, Kd) if ak else (Kd, M))).cuda(); b = _rnd(f"st.b{N}.{Kd}", *((N, Kd) if bk else (Kd, N))).cuda()
+        cands = K.stable_candidates(a, b, ak, bk, M, N, Kd, ws)
+        assert cands and len({sp for _, sp in cands}) == 1, (ak, bk, M, N, Kd, cands)
+        if ak:
+            assert len(cands) >= 3
+        outs = [K.gemm(a, b, ak, bk, cfg=c) for c in cands]
+        for c, o in zip(cands[1:], outs[1:]):
+            assert torch.equal(o, outs[0]), (ak, bk, M, N, Kd, cands[0], c)
+        ref = (a.double() if ak else a.double().t()) @ (b.double().t() if bk else b.double())
+        assert _rel(outs[0], ref) <= 2e-5
+        w1, _ = K.gemm_tune(a, b, ak, bk, M, N, Kd, ws, cands=cands)
+        w2, _ = K.gemm_tune(a, b, ak, bk, M, N, Kd, ws, cands=cands[::-1])
+        assert w1 in cands and w2 in cands and torch.equal(K.gemm(a, b, ak, bk, cfg=w1), K.gemm(a, b, ak, bk, cfg=w2))
+    assert stable_split_is_a_function_of_the_shape(K)
+    # the split-K case really splits, the wide case does not
+    assert K.stable_split(1344, 384, 1536, 1 << 30) > 1 and K.stable_split(6144, 768, 768, 1 << 30) == 1
+    # no fast family (K % 32 != 0): cost model, nothing timed
+    a = _rnd("st.odd.a", 1024, 1000).cuda(); b = _rnd("st.odd.b", 512, 1000).cuda()
+    assert K.stable_candidates(a, b, True, True, 1024, 512, 1000, ws) == [] and K.first_use_config(a, b, True, True, 1024, 512, 1000, ws) == (0, 0)
+    # end to end through the product entry: an unlisted shape is tuned on first use, cached, registered C-side, and reproducible
+    M, N, Kd = 1344, 768, 1536
+    a = _rnd("st.e2e.a", M, Kd).cuda(); b = _rnd("st.e2e.b", N, Kd).cuda()
+    assert (1, 1, M, N, Kd) not in K._GEMM_TABLE
+    K._GEMM_CACHE.pop((1, 1, M, N, Kd, 0), None)
+    c1 = K.gemm(a, b)
+    cfg1 = K._GEMM_CACHE[(1, 1, M, N, Kd, 0)]
+    K._GEMM_CACHE.pop((1, 1, M, N, Kd, 0), None)
+    c2 = K.gemm(a, b)
+    assert cfg1 in K.stable_candidates(a, b, True, True, M, N, Kd, ws) and torch.equal(c1, c2)
+    K._NEW_TUNED.pop((1, 1, M, N, Kd), None)
+
+
+def stable_split_is_a_function_of_the_shape(K):
+    return all(K.stable_split(M, N, Kd, 1 << 28) == K.stable_split(M, N, Kd, 1 << 28) for (M, N, Kd) in [(1344, 384, 1536), (64, 64, 8192)])

@@ -256,3 +256,20 @@ def test_fewshot_recipe_builds_its_datasets_from_cli_args(tmp_path):
     cfg2 = cfg_from_yaml_file("cfgs/finetune_classification/full/finetune_modelnet.yaml")
     apply_fewshot_args(argparse.Namespace(shot=-1, way=-1, fold=-1), cfg2)
     assert "shot" not in cfg2.dataset.train.others
+
+
+def test_announced_batch_mark_is_per_model():
+    """runner_pretrain.train_step must not augment twice the batch it already announced to the teacher prefetch -- and that memory belongs to the
+    model it was announced to: two models trained in one process do not see each other's batches; an in-place change of the tensor voids the mark."""
+    import torch
+    from act_amd.tools.runner_pretrain import _Announced
+    m1, m2 = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+    a, b = torch.zeros(3), torch.zeros(3)
+    assert not _Announced.is_marked(m1, a)
+    _Announced.mark(m1, a)
+    assert _Announced.is_marked(m1, a) and not _Announced.is_marked(m2, a) and not _Announced.is_marked(m1, b)
+    _Announced.mark(m2, b)
+    assert _Announced.is_marked(m1, a) and _Announced.is_marked(m2, b)
+    a.add_(1.0)                                              # a new version of the tensor is a new batch
+    assert not _Announced.is_marked(m1, a)
+    assert "_act_announced" not in m1.state_dict()
