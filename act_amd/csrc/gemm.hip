@@ -364,7 +364,7 @@ std::mutex g_tune_mu;
 std::unordered_map<TuneKey, std::pair<int, int>, TuneHash> g_tune;
 }  // namespace
 extern "C" int act_gemm_tune_set(int ak, int bk, int M, int N, int K, int tile, int splits) {
-    if (tile < 0 || (tile > 21 && (tile < 30 || tile > 32)) || splits < 0) return ACT_E_BADARG;
+    if (tile < 0 || (tile > 21 && (tile < 30 || tile > 36)) || splits < 0) return ACT_E_BADARG;
     std::lock_guard<std::mutex> g(g_tune_mu);
     g_tune[TuneKey{ak != 0, bk != 0, M, N, K}] = {tile, splits};
     return 0;
@@ -436,6 +436,11 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
             if (nb * sp >= 1024) break;
         }
     }
+    // tiles 33 (128x128), 34 (64x128), 35 (64x64), 36 (128x64): NN / TN kernels with the hand-scheduled main loop (gemm_q_asm_kernel.h); 34..36 NN only;
+    // bit-identical to 13 / 14 / 15 / 16
+    const bool qa = tile >= 33 && tile <= 36;
+    const int qa_tile = tile - 33;
+    if (qa) { if (b_kmajor || (tile != 33 && !a_kmajor)) return ACT_E_BADARG; tile -= 20; }
     // tiles 30 (128x128), 31 (128x64), 32 (64x64): NT kernels with the hand-scheduled main loop (gemm_nt_asm_kernel.h); bit-identical to 10 / 11 / 12
     const bool nta = tile >= 30 && tile <= 32;
     const int nta_tile = tile - 30;
@@ -486,7 +491,11 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     const bool full = vec && (M % BM == 0) && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
     // 16x16x4 kernels also take an M tail when A is K-major (rows = tokens): rows clamped on load, guarded on store
     const bool full_mtail = vec && a_kmajor && (N % BN == 0) && (K % 32 == 0) && (kps % 32 == 0) && K > 0;
-    if (nta) {
+    if (qa) {
+        if (!(full || full_mtail)) return ACT_E_BADARG;
+        if ((long long)(a_kmajor ? BM : 32) * lda * 4 >= (1ll << 31) || (long long)32 * ldb * 4 >= (1ll << 31)) return ACT_E_BADARG;   // 32-bit lane offsets inside a tile
+        if (!launch_sgemm_q_asm(p, qa_tile, a_kmajor, grid, s)) return ACT_E_BADARG;
+    } else if (nta) {
         if (!(full || full_mtail)) return ACT_E_BADARG;
         if ((long long)BM * lda * 4 >= (1ll << 31) || (long long)BN * ldb * 4 >= (1ll << 31)) return ACT_E_BADARG;     // 32-bit lane offsets inside a tile
         launch_sgemm_nt_asm(p, nta_tile, grid, s);

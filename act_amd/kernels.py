@@ -245,9 +245,9 @@ def stable_candidates(a, b, ak, bk, M, N, K, ws):
         fam = [(30, 128), (31, 64), (32, 64), (10, 128), (11, 64), (12, 64)]
         return [(t, sp) for t, bn in fam if N % bn == 0]
     if ak and not bk:                                         # NN: quad-fragment tiles (13: 128x128, 14: 64x128, 16: 128x64, 15: 64x64)
-        return [(t, sp) for t, bn in ((13, 128), (14, 128), (16, 64), (15, 64)) if N % bn == 0]
-    if not ak and not bk and M % 128 == 0 and N % 128 == 0:   # TN: the one quad-fragment tile
-        return [(13, sp)]
+        return [(t, sp) for t, bn in ((33, 128), (34, 128), (36, 64), (35, 64), (13, 128), (14, 128), (16, 64), (15, 64)) if N % bn == 0]
+    if not ak and not bk and M % 128 == 0 and N % 128 == 0:   # TN: the quad-fragment tile, hand-scheduled or compiler-scheduled
+        return [(33, sp), (13, sp)]
     return []
 
 
@@ -304,6 +304,7 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1, trace=None, cands=Non
             if _MAX_SPLIT > 0 and K <= 8192:
                 qsp = [s for s in qsp if s <= _MAX_SPLIT]
             cands += [(12 + tile, s) for s in qsp if K % 32 == 0]                     # NN / TN: quad fragments (13: 128x128, 14: 64x128)
+            cands += [(32 + tile, s) for s in qsp if K % 32 == 0]                     # ... on the hand-scheduled main loop (33: 128x128, 34: 64x128)
         if ak and not bk and N % 64 == 0 and K % 32 == 0 and tile in (2, 3):                  # NN, 64-column quad tiles (4 x 1 waves): 16 = 128x64, 15 = 64x64
             qsp = [1]
             nbq = -(-M // (128 if tile == 2 else 64)) * (N // 64)
@@ -316,6 +317,7 @@ def gemm_tune(a, b, ak, bk, M, N, K, ws, reps=3, rounds=1, trace=None, cands=Non
             if _MAX_SPLIT > 0 and K <= 8192:
                 qsp = [s for s in qsp if s <= _MAX_SPLIT]
             cands += [(16 if tile == 2 else 15, s) for s in qsp if K % 32 == 0]
+            cands += [(36 if tile == 2 else 35, s) for s in qsp if K % 32 == 0]       # ... hand-scheduled (36: 128x64, 35: 64x64)
     if given is not None:
         cands = list(given)
     scratch = torch.empty(M, N, dtype=torch.float32, device=a.device)

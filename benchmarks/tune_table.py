@@ -16,11 +16,11 @@ table = json.load(open(src))
 out = {}
 dev = torch.device("cuda:0")
 ws = K.workspace(dev)
-only = os.environ.get("ACT_TUNE_ONLY", "")            # "nt": re-tune the NT (1,1,...) shapes only, keep the other entries
+only = os.environ.get("ACT_TUNE_ONLY", "")            # "nt": re-tune the NT (1,1,...) shapes only, "nntn": the others only; the rest of the entries are kept
 min_flops = float(os.environ.get("ACT_TUNE_MIN_FLOPS", "0"))
 for key in table["configs"]:
     ak, bk, M, N, Kd = (int(v) for v in key.split(","))
-    if (only == "nt" and not (ak and bk)) or 2.0 * M * N * Kd < min_flops:
+    if (only == "nt" and not (ak and bk)) or (only == "nntn" and (ak and bk)) or 2.0 * M * N * Kd < min_flops:
         out[key] = table["configs"][key]
         continue
     a = torch.randn((M, Kd) if ak else (Kd, M), device=dev)

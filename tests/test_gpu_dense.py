@@ -785,7 +785,7 @@ def test_gemm_autotuner_times_and_registers_a_config(K):
     a = _rnd("at.a", M, Kd).cuda(); b = _rnd("at.b", N, Kd).cuda()
     ws = K.workspace(a.device)
     (tile, sp), ms = K.gemm_tune(a, b, True, True, M, N, Kd, ws)
-    assert 1 <= tile <= 32 and sp >= 1 and 0 < ms < 10
+    assert 1 <= tile <= 36 and sp >= 1 and 0 < ms < 10
     assert _rel(K.gemm(a, b, True, True, cfg=(tile, sp)), a.double().cpu() @ b.double().cpu().t()) <= 2e-5
     saved = K.AUTOTUNE
     K.AUTOTUNE = True
@@ -893,6 +893,43 @@ def test_nt_hand_scheduled_loop_is_bit_identical(K, tile, base):
         K.gemm(a, b.t().contiguous(), True, False, cfg=(tile, 1))
 
 
+@pytest.mark.parametrize("tile,base", [(33, 13), (34, 14), (35, 15), (36, 16)])
+def test_nn_tn_hand_scheduled_loop_is_bit_identical(K, tile, base):
+    """tiles 33..36 (gemm_q_asm_kernel.h: NN / TN on the hand-scheduled main loop, row-contiguous operands read as quad fragments) execute the
+    products of the quad-fragment tiles 13..16 in the same order: bit-identical for 1 .. 96 K-tiles, with split-K, an M tail (NN), the fused
+    epilogues of the backward pass (gelu', relu mask, bias, residual, accumulate) and row-strided operands."""
+    for (M, N, Kd) in [(256, 256, 32), (256, 128, 64), (128, 256, 96), (384, 128, 128), (256, 256, 160), (512, 384, 1024), (1024, 768, 3072),
+                       (2080, 384, 384), (65, 128, 192), (1792, 384, 1536)]:
+        a = _rnd(f"qa.a{M}.{Kd}", M, Kd).cuda(); bt = _rnd(f"qa.b{N}.{Kd}", Kd, N).cuda()
+        for sp in (1, 2, 3):
+            if Kd // sp < 32:
+                continue
+            assert torch.equal(K.gemm(a, bt, True, False, cfg=(tile, sp)), K.gemm(a, bt, True, False, cfg=(base, sp))), (tile, "nn", M, N, Kd, sp)
+            if tile == 33 and M % 128 == 0:
+                at = a.t().contiguous()
+                assert torch.equal(K.gemm(at, bt, False, False, cfg=(tile, sp)), K.gemm(at, bt, False, False, cfg=(base, sp))), (tile, "tn", M, N, Kd, sp)
+        bias = _rnd(f"qa.bias{N}", N).cuda(); res = _rnd(f"qa.res{M}.{N}", M, N).cuda(); aux = _rnd(f"qa.aux{M}.{N}", M, N).cuda()
+        for act in (K.EPI_NONE, K.EPI_MUL_GELU_GRAD, K.EPI_MUL_RELU_MASK):
+            kw = dict(bias=bias, res=res, act=act, aux=aux if act != K.EPI_NONE else None)
+            assert torch.equal(K.gemm(a, bt, True, False, cfg=(tile, 1), **kw), K.gemm(a, bt, True, False, cfg=(base, 1), **kw)), (tile, M, N, Kd, act)
+        o1 = res.clone(); o2 = res.clone()
+        K.gemm(a, bt, True, False, out=o1, accumulate=True, alpha=0.5, cfg=(tile, 1)); K.gemm(a, bt, True, False, out=o2, accumulate=True, alpha=0.5, cfg=(base, 1))
+        assert torch.equal(o1, o2)
+    a = _rnd("qa.a", 512, 1024).cuda(); bt = _rnd("qa.bt", 1024, 384).cuda()
+    assert _rel(K.gemm(a, bt, True, False, cfg=(tile, 1)), a.double().cpu() @ bt.double().cpu()) <= 2e-5
+    wide_a = _rnd("qa.wa", 512, 1024 + 64).cuda(); wide_b = _rnd("qa.wb", 1024, 384 + 128).cuda()       # row-strided views
+    assert torch.equal(K.gemm(wide_a[:, 32:32 + 1024], wide_b[:, 128:], True, False, cfg=(tile, 1)),
+                       K.gemm(wide_a[:, 32:32 + 1024], wide_b[:, 128:], True, False, cfg=(base, 1)))
+    guard = torch.full((2080 + 64, 384), 7.0, device="cuda")
+    K.gemm(_rnd("qa.a2080.384", 2080, 384).cuda(), _rnd("qa.b384.384", 384, 384).cuda(), True, False, out=guard[:2080], cfg=(tile, 1))
+    assert torch.all(guard[2080:] == 7.0)
+    with pytest.raises(Exception):                         # NT has its own kernels
+        K.gemm(a, _rnd("qa.nt", 384, 1024).cuda(), True, True, cfg=(tile, 1))
+    if tile != 33:
+        with pytest.raises(Exception):                     # TN: 128 x 128 only
+            K.gemm(a.t().contiguous(), bt, False, False, cfg=(tile, 1))
+
+
 @pytest.mark.parametrize("R,N,Kd,group", [(1024, 256, 128, 32), (512, 384, 512, 32), (768, 192, 256, 64), (256, 512, 1024, 32), (384, 128, 32, 64), (256, 64, 96, 32)])
 def test_fused_nt_launches_on_the_hand_scheduled_loop_are_bit_identical(K, R, N, Kd, group):
     """act_sgemm_fx_f32 (1,1): column statistics, A-side affine + ReLU on load, group max (+ arg-max), with and without the C store -- the launches
@@ -944,7 +981,7 @@ def test_fused_nt_launches_on_the_hand_scheduled_loop_are_bit_identical(K, R, N,
             assert _rel(r1[1], ref.view(R // group, group, N).max(1)[0]) <= 2e-5
 
 
-@pytest.mark.parametrize("tile,ak,bk", [(10, 1, 1), (11, 1, 1), (12, 1, 1), (21, 1, 1), (30, 1, 1), (31, 1, 1), (32, 1, 1), (13, 1, 0), (14, 1, 0), (13, 0, 0), (7, 1, 0), (3, 1, 1)])
+@pytest.mark.parametrize("tile,ak,bk", [(10, 1, 1), (11, 1, 1), (12, 1, 1), (21, 1, 1), (30, 1, 1), (31, 1, 1), (32, 1, 1), (33, 1, 0), (36, 1, 0), (33, 0, 0), (13, 1, 0), (14, 1, 0), (13, 0, 0), (7, 1, 0), (3, 1, 1)])
 def test_gemm_epilogue_scalar_fallback_matches_the_vector_path(K, tile, ak, bk):
     """the vector epilogue (float4 / float2 accesses of C, bias, residual, aux: gemm_common.h::epilogue_rows) needs 16-byte aligned pointers and
     leading dimensions % 4 == 0; anything else takes the scalar accesses of the same code.  C-ABI level: C / bias / residual / aux shifted by one
