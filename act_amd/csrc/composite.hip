@@ -240,6 +240,21 @@ int act_block_bwd_f32(const act_block_dims_t* d, const act_block_params_t* w, co
     auto wgrad2 = [&](const act_gemm_tn_problem_t* pr) -> int {
         if (t_collect) return 0;
         if (fork) CK(order_after(ss, s));
+        // the grouped launch wants 16-byte aligned operands and leading dimensions % 4 == 0 (a gradient or activation pointer at an odd offset inside a
+        // larger allocation): anything else takes the two single products, whose ragged-edge kernels handle any alignment (round-3 advisor finding)
+        bool ok = true;
+        for (int i = 0; i < 2; ++i)
+            ok = ok && (((reinterpret_cast<uintptr_t>(pr[i].A) | reinterpret_cast<uintptr_t>(pr[i].B) | reinterpret_cast<uintptr_t>(pr[i].C)) & 15) == 0) &&
+                 ((pr[i].lda | pr[i].ldb | pr[i].ldc) & 3) == 0;
+        if (!ok) {
+            for (int i = 0; i < 2; ++i) {
+                if (pr[i].C) CK(gemm_tn(pr[i].M, pr[i].N, T, pr[i].A, pr[i].lda, pr[i].B, pr[i].ldb, pr[i].C, pr[i].ldc, wws, wwsb, ss));
+                if (pr[i].bias_out) CK(colsum(pr[i].A, T, pr[i].M, pr[i].bias_out, wws, wwsb, ss));
+            }
+            return 0;
+        }
+        // K ranges: the count act_sgemm_tn_grouped_splits asks for, capped by the workspace the caller provided -- the host path (kernels.gemm_tn_grouped)
+        // applies the same cap (kernels._WS_BYTES) instead of growing its workspace, so both paths use the same summation order
         int sp = act_sgemm_tn_grouped_splits(pr, 2, T);
         while (sp > 1 && act_sgemm_tn_grouped_workspace(pr, 2, T, sp) > wwsb) --sp;
         return act_sgemm_tn_grouped_f32(pr, 2, T, sp, wws, wwsb, ss);

@@ -541,8 +541,9 @@ extern "C" int act_sgemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, co
 // conv2 (K = 128) 195 -> 227 us -- with 4-8 K tiles per output tile the launch is prologue / epilogue bound and three 32 KB workgroups per CU overlap
 // those better than two 64-72 KB ones.  act_gemm_fx_asm(1) / ACT_GEMM_FX_ASM=1 selects them.
 #include <atomic>
+// bit 0: the NT launches above; bit 1: the NN launch with the epilogue-side max-pool backward term (measured 574 -> 598 us in the step: also off)
 static std::atomic<int> g_fx_asm{[] { const char* e = getenv("ACT_GEMM_FX_ASM"); return e ? atoi(e) : 0; }()};
-extern "C" int act_gemm_fx_asm(int on) { return on < 0 ? g_fx_asm.load() : g_fx_asm.exchange(on != 0); }
+extern "C" int act_gemm_fx_asm(int on) { return on < 0 ? g_fx_asm.load() : g_fx_asm.exchange(on & 3); }
 
 // ---- GEMM with fused producer / consumer passes (mini-PointNet, see GemmFx in gemm_common.h) ---------------------------------------
 extern "C" size_t act_sgemm_fx_tile_stats_floats(int M, int N) { return (size_t)((M + 127) / 128) * 2 * N; }
@@ -590,7 +591,7 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         ActProfScope ps(KID_GEMM_NT, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + ((mask & FX_NOSTORE) ? 0.0 : (double)M * N)));
         // hand-scheduled main loop when every K tile is 32 deep (ACT_GEMM_FX_ASM=0: the compiler-scheduled kernels, for A/B runs); same bits either way
         const dim3 fgrid((unsigned)(p.tiles_m * p.tiles_n));
-        if (!(g_fx_asm.load() && launch_sgemm_nt_asm_fx(p, tile, mask, fgrid, s)) && !launch_sgemm_nt16_fx(p, tile, mask, fgrid, s)) return ACT_E_BADARG;
+        if (!((g_fx_asm.load() & 1) && launch_sgemm_nt_asm_fx(p, tile, mask, fgrid, s)) && !launch_sgemm_nt16_fx(p, tile, mask, fgrid, s)) return ACT_E_BADARG;
         ACT_LAUNCH_CHECK();
         return 0;
     }
@@ -600,7 +601,8 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         if ((scatter & FX_SCATTER_EPI) && ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15))) return ACT_E_BADARG;
         p.tiles_m = M / 128; p.tiles_n = N / 128; p.k_per_split = K; p.partial = nullptr;
         ActProfScope ps(KID_GEMM_NN, s, 2.0 * M * N * (double)K, 4.0 * ((double)N * K + (double)M * N));
-        if (!launch_sgemm_q16_fx(p, 1, scatter, dim3((unsigned)(p.tiles_m * p.tiles_n)), s)) return ACT_E_BADARG;
+        const dim3 qgrid((unsigned)(p.tiles_m * p.tiles_n));
+        if (!((g_fx_asm.load() & 2) && launch_sgemm_q_asm_fx(p, 1, scatter, qgrid, s)) && !launch_sgemm_q16_fx(p, 1, scatter, qgrid, s)) return ACT_E_BADARG;
         ACT_LAUNCH_CHECK();
         return 0;
     }

@@ -362,6 +362,7 @@ void launch_sgemm_nt32(const GemmParams& p, int tile, dim3 grid, hipStream_t s);
 void launch_sgemm_nt_asm(const GemmParams& p, int tile, dim3 grid, hipStream_t s);
 // NN / TN kernels with the hand-scheduled main loop (gemm_q_asm.hip): tile 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 128x64 (1..3 NN only); false = no such kernel
 bool launch_sgemm_q_asm(const GemmParams& p, int tile, int a_kmajor, dim3 grid, hipStream_t s);
+bool launch_sgemm_q_asm_fx(const GemmParams& p, int a_kmajor, int fx_mask, dim3 grid, hipStream_t s);    // ... with the epilogue-side max-pool backward term (NN, FX_SCATTER_EPI only)
 // quad-fragment kernels for the NN / TN layouts (gemm_q16.hip): tile 0 = 128x128, 1 = 64x128 (NN only); false = no such kernel
 bool launch_sgemm_q16(const GemmParams& p, int tile, int a_kmajor, int b_kmajor, dim3 grid, hipStream_t s);
 // NT kernels with fused producer / consumer passes (gemm_nt16_fx.hip); fx_mask = FX_* bits; tile 0 = 128x128, 1 = 128x64.  false = no such kernel

@@ -12,8 +12,8 @@
 //     LDS): a thread sums its k-rows of every K-tile, eight thread-rows are folded through LDS in a fixed order -> one [128] partial per
 //     (tile row, K range) -> the reduction launch adds the K ranges.
 #include "gemm_common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "gemm_nt_asm_loop.h"
+#include <stdlib.h>
 #define GG_MAXP 8
 
 struct GroupedProblem {
@@ -125,6 +125,87 @@ __global__ __launch_bounds__(256, 2) void sgemm_tn_grouped_kernel(const GroupedP
     }
 }
 
+// ---- the same work decomposition on the hand-scheduled TN main loop (gen_nt_asm.py: tn_asm_loop_4x4 / ..._asum): 32-deep K tiles, every memory
+// instruction in an MFMA gap; the bias-gradient column sums ride on the staging registers inside the loop (v_add_f32 in the gaps, chunks in ascending k:
+// the order of the compiler loop).  Same products and sums in the same order: bit-identical to sgemm_tn_grouped_kernel.  Needs every K range % 32 == 0.
+__global__ __launch_bounds__(256, 2) void sgemm_tn_grouped_asm_kernel(const GroupedParams g) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int KG = BM * 64, B_BASE = 2 * KG, STAGE = 4 * KG;                 // bytes
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int sp = blockIdx.x / g.total_tiles, tl = blockIdx.x - sp * g.total_tiles;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GG_MAXP; ++i) if (i < g.nprob && tl >= g.p[i].tile0) pi = i;
+    const float* __restrict__ A = g.p[pi].A; const float* __restrict__ B = g.p[pi].B;
+    const int lda = g.p[pi].lda, ldb = g.p[pi].ldb, M = g.p[pi].M, N = g.p[pi].N;
+    const int t = tl - g.p[pi].tile0, tiles_n = N / BN;
+    const int tile_m = t / tiles_n, tile_n = t - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = sp * g.k_per_split, kend = min(g.K, kbeg + g.k_per_split);
+    const int ntiles = (kend - kbeg) / 32;
+    const bool want_bias = g.p[pi].bias_out != nullptr && tile_n == 0;
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    // staging: thread owns float4 #(tid + 256 i) of the [32 k][128] tile of each operand: k = tid / 32 + 8 i, 4 consecutive rows at (tid % 32) * 4
+    u32x4 offa, offb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        offa[i] = (unsigned)(((tid / 32 + 8 * i) * lda + (tid % 32) * 4) * 4);
+        offb[i] = (unsigned)(((tid / 32 + 8 * i) * ldb + (tid % 32) * 4) * 4);
+    }
+    const float* pa = A + (size_t)kbeg * lda + m0;
+    const float* pb = B + (size_t)kbeg * ldb + n0;
+    const int kl = lane >> 4, ml = lane & 15;
+    f32x4 acc[4][4];
+    f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ntiles > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                    // K-tile 0 -> stage 0 (k-rows in ascending order for the bias sums)
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pa) + offa[i]);
+            if (want_bias) { bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w; }
+            *reinterpret_cast<float4*>(lds + tid * 16 + i * 4096) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(lds + B_BASE + tid * 16 + j * 4096) = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(pb) + offb[j]);
+        __syncthreads();
+        const unsigned ra = lbase + (unsigned)(((4 * kl) * BM + wm * 64 + 4 * ml) * 4), rb = lbase + (unsigned)(((4 * kl) * BN + wn * 64 + 4 * ml) * 4);
+        const unsigned wb = lbase + tid * 16;
+        if (want_bias) tn_asm_loop_4x4_asum(acc, pa, pb, ntiles, (unsigned)(32 * lda * 4), (unsigned)(32 * ldb * 4), offa, offb, wb, wb, ra, rb, bsum);
+        else           tn_asm_loop_4x4(acc, pa, pb, ntiles, (unsigned)(32 * lda * 4), (unsigned)(32 * ldb * 4), offa, offb, wb, wb, ra, rb);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float* __restrict__ dst; int ldd;
+    if (g.splits > 1) { dst = g.ws + g.p[pi].part_off + (size_t)sp * M * N; ldd = N; }
+    else              { dst = g.p[pi].C; ldd = g.p[pi].ldc; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * 64 + 4 * (kl * 4 + r) + i, col = n0 + wn * 64 + 4 * ml;
+            *reinterpret_cast<float4*>(dst + (size_t)row * ldd + col) = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+        }
+    if (want_bias) {                                                    // fold the 8 thread-rows (k mod 8) in a fixed order
+        __syncthreads();                                                // the staging LDS is free now
+        float* red = reinterpret_cast<float*>(lds);
+        *reinterpret_cast<float4*>(&red[(tid / 32) * BM + (tid % 32) * 4]) = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+        __syncthreads();
+        if (tid < BM) {
+            float v = red[tid];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) v += red[q * BM + tid];
+            if (g.splits > 1) g.ws[g.p[pi].bias_off + (size_t)sp * M + m0 + tid] = v;
+            else              g.p[pi].bias_out[m0 + tid] = v;
+        }
+    }
+}
+
 // folds the K-range partials of every product (float4 per thread, ranges in ascending order) and of every bias of the group
 __global__ __launch_bounds__(256) void sgemm_grouped_reduce_kernel(const GroupedParams g, long long total4, long long total_bias) {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -224,7 +305,13 @@ extern "C" int act_sgemm_tn_grouped_f32(const act_gemm_tn_problem_t* probs, int 
     }
     g.ws = workspace;
     ActProfScope ps(KID_GEMM_TN, s, flops, bytes);
-    hipLaunchKernelGGL(sgemm_tn_grouped_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+    // hand-scheduled main loop when every K range is a multiple of 32 rows and the 32-bit lane offsets of a K tile fit (ACT_GEMM_GROUPED_ASM=0: compiler loop)
+    static const int use_asm = [] { const char* e = getenv("ACT_GEMM_GROUPED_ASM"); return e ? atoi(e) : 1; }();
+    bool asm_ok = use_asm && (K % 32) == 0;
+    for (int i = 0; i < nprob && asm_ok; ++i)
+        if ((long long)32 * probs[i].lda * 4 >= (1ll << 31) || (long long)32 * probs[i].ldb * 4 >= (1ll << 31)) asm_ok = false;
+    if (asm_ok) hipLaunchKernelGGL(sgemm_tn_grouped_asm_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
+    else        hipLaunchKernelGGL(sgemm_tn_grouped_kernel, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, g);
     ACT_LAUNCH_CHECK();
     if (splits > 1) {
         long long blocks = (total4 + total_bias + 255) / 256; if (blocks > 2048) blocks = 2048;

@@ -31,3 +31,12 @@ bool launch_sgemm_q_asm(const GemmParams& p, int tile, int a_kmajor, dim3 grid, 
     return true;
 #undef QA_ACT
 }
+
+// fused max-pool backward: only the epilogue-side term (FX_SCATTER_EPI) exists on the hand-scheduled loop -- the on-load terms (FX_SCATTER_A, FX_AFFINE_B)
+// stay on sgemm_q16_kernel.  Same contract as launch_sgemm_q16_fx plus K % 32 == 0; bit-identical.  false = no such kernel.
+bool launch_sgemm_q_asm_fx(const GemmParams& p, int a_kmajor, int fx_mask, dim3 grid, hipStream_t s) {
+    if (p.epi.act != ACT_EPI_NONE || !a_kmajor || fx_mask != FX_SCATTER_EPI || (p.K & 31) || p.k_per_split != p.K) return false;
+    if ((long long)128 * p.lda * 4 >= (1ll << 31) || (long long)32 * p.ldb * 4 >= (1ll << 31)) return false;
+    hipLaunchKernelGGL((sgemm_q_asm_kernel<128, 128, true, false, true, ACT_EPI_NONE>), grid, dim3(256), 0, s, p);
+    return true;
+}

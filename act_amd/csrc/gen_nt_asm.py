@@ -25,9 +25,10 @@ S_A, S_B, S_CNT, S_STEP_A, S_STEP_B = 60, 62, 64, 65, 66     # pinned SGPRs: A b
 
 
 class Cfg:
-    def __init__(self, TM, TN, WM=2, WN=2, a_row=False, b_row=False, pgr=1, affine=False, **sched):
+    def __init__(self, TM, TN, WM=2, WN=2, a_row=False, b_row=False, pgr=1, affine=False, a_sum=False, **sched):
         self.TM, self.TN, self.WM, self.WN = TM, TN, WM, WN
-        self.a_row, self.b_row, self.pgr, self.affine = a_row, b_row, pgr, affine
+        self.a_row, self.b_row, self.pgr, self.affine, self.a_sum = a_row, b_row, pgr, affine, a_sum
+        assert not (affine and a_sum)
         assert not a_row or TM == 4, "row-contiguous A: 64-row wave extent"
         assert not b_row or TN == 4, "row-contiguous B: 64-column wave extent"
         assert not affine or not a_row
@@ -58,6 +59,10 @@ class Cfg:
             self.sc = n; n += 4
             self.sh = n; n += 4
             self.sx = n; n += 1
+        self.bs = -1
+        if a_sum:                        # running sums of the A values this thread stages (column sums of A = bias gradients of a weight-gradient GEMM)
+            n += n & 1
+            self.bs = n; n += 4
         self.total = n
         self.A_KG, self.B_KG = self.BM * 64, self.BN * 64
         self.B_BASE = 2 * self.A_KG
@@ -69,6 +74,7 @@ class Cfg:
         if (self.WM, self.WN) != (2, 2): s += f"_w{self.WM}x{self.WN}"
         if self.pgr != 1: s += f"_pg{self.pgr}"
         if self.affine: s += "_affine"
+        if self.a_sum: s += "_asum"
         return s
 
 
@@ -158,6 +164,16 @@ def gen_loop(c):
                 items = [ops[q:q + per] for q in range(0, len(ops), per)]
                 items[0] = [wait] + items[0]
                 k = place(fb, items, o["w_start"], 1)
+            elif c.a_sum:                # bs += A chunk, chunks in ascending k order (the order of the compiler loop), each chunk summed before its ds_write
+                ops = []
+                for i in range(c.NA):
+                    ops += [f"v_add_f32_e32 v{c.bs + q}, v{c.bs + q}, v{c.sa[sset] + 4 * i + q}" for q in range(4)]
+                    if i < len(wbw): ops.append(wbw[i])
+                    ops.append(wa[i])
+                ops += wbw[c.NA:]
+                items = [ops[q:q + 3] for q in range(0, len(ops), 3)]
+                items[0] = [wait] + items[0]
+                k = place(fb, items, o["w_start"], 1)
             else:
                 w = wa + wbw
                 k = place(fb, [[wait, w[0]]] + [[x] for x in w[1:]], o["w_start"], o["w_step"])
@@ -245,7 +261,7 @@ def gen_function(c):
     text.append(f"// {lay}; {c.WM} x {c.WN} waves, wave tile {16 * TM} x {16 * TN} (workgroup {c.BM} x {c.BN}), {c.total} VGPRs, LDS {2 * c.STAGE} B, "
                 f"global prefetch {c.pgr}; schedule {c.sched}")
     text.append(f"__device__ __forceinline__ void {c.name()}(f32x4 (&acc)[{TM}][{TN}], const float* pa, const float* pb, int ntiles, unsigned step_a, unsigned step_b,")
-    text.append(f"        {vt[c.NA]} offa, {vt[c.NB]} offb, unsigned wbase_a, unsigned wbase_b, unsigned rbase_a, unsigned rbase_b" + (", unsigned sx" if c.affine else "") + ") {")
+    text.append(f"        {vt[c.NA]} offa, {vt[c.NB]} offb, unsigned wbase_a, unsigned wbase_b, unsigned rbase_a, unsigned rbase_b" + (", unsigned sx" if c.affine else "") + (", f32x4& bsum" if c.a_sum else "") + ") {")
     text.append("    asm volatile(")
     for l in lines:
         text.append(f'        "{l}\\n"')
@@ -256,6 +272,7 @@ def gen_function(c):
             outs.append(f'"={{v[{a}:{a + 3}]}}"(acc[{i}][{j}])')
     ios = [f'"+{{s[{S_A}:{S_A + 1}]}}"(pa)', f'"+{{s[{S_B}:{S_B + 1}]}}"(pb)', f'"+{{s{S_CNT}}}"(ntiles)']
     if c.affine: ios.append(f'"+{{v{c.sx}}}"(sx)')
+    if c.a_sum: ios.append(f'"+{{v[{c.bs}:{c.bs + 3}]}}"(bsum)')
     text.append("        : " + ", ".join(outs) + ",")
     text.append("          " + ", ".join(ios))
     ins = [f'"{{s{S_STEP_A}}}"(step_a)', f'"{{s{S_STEP_B}}}"(step_b)', f'"{{{vr(c.offa, c.NA)}}}"(offa)', f'"{{{vr(c.offb, c.NB)}}}"(offb)',
@@ -283,6 +300,7 @@ VARIANTS = [
     Cfg(4, 4, b_row=True), Cfg(2, 4, b_row=True, **SMALL),                                     # NN 128x128, 64x128 (2 x 2 waves)
     Cfg(2, 4, WM=4, WN=1, b_row=True, **SMALL), Cfg(1, 4, WM=4, WN=1, b_row=True, r1_step=1, tail=6, **SMALL),   # NN 128x64, 64x64 (4 x 1 waves)
     Cfg(4, 4, a_row=True, b_row=True),                                                         # TN 128x128
+    Cfg(4, 4, a_row=True, b_row=True, a_sum=True, l_step=1),                                   # TN 128x128 + column sums of A (grouped weight gradients: bias gradient)
 ]
 
 

@@ -13,6 +13,12 @@
 //  * Distances use __fsub_rn/__fmul_rn/__fadd_rn: (dx*dx + dy*dy) + dz*dz, bit-identical to the
 //    CPU oracle, so indices are bit-exact.
 #include "common.h"
+
+// four consecutive floats at a 4-BYTE aligned address: point k of cloud b sits at ref + (b * N + k) * 3 floats, which is 16-byte aligned only when
+// (b * N + k) % 4 == 0 and ref itself is (N = 777, b = 1; an offset view).  gfx950 global loads have no alignment requirement, so this still compiles
+// to one global_load_dwordx4 -- what changes is that the compiler may no longer ASSUME 16 bytes (round-3 advisor finding).
+struct __attribute__((aligned(4))) float4_a4 { float x, y, z, w; };
+
 #include <stdlib.h>
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -311,8 +317,8 @@ __global__ __launch_bounds__(256) void knn_group2_kernel(const float* __restrict
             const int k = KNN_IDX(g * GS + i);
             float v[4] = {INF, INF, INF, INF};
             if (k + 3 < N) {
-                const float4* __restrict__ pp = reinterpret_cast<const float4*>(r + (size_t)k * 3);
-                const float4 f0 = pp[0], f1 = pp[1], f2 = pp[2];
+                const float4_a4* __restrict__ pp = reinterpret_cast<const float4_a4*>(r + (size_t)k * 3);    // 4-byte aligned only: see float4_a4
+                const float4_a4 f0 = pp[0], f1 = pp[1], f2 = pp[2];
                 const f32x2 a = f32x2{f0.x, f0.y} - qxy, bq = f32x2{f0.z, f0.w} - qzx, c = f32x2{f1.x, f1.y} - qyz;
                 const f32x2 e = f32x2{f1.z, f1.w} - qxy, f = f32x2{f2.x, f2.y} - qzx, h = f32x2{f2.z, f2.w} - qyz;
                 const f32x2 a2 = a * a, b2 = bq * bq, c2 = c * c, e2 = e * e, f2s = f * f, h2 = h * h;
@@ -399,8 +405,8 @@ __device__ __forceinline__ void knn_fill4(float* __restrict__ d, int k, const fl
     const float INF = __int_as_float(0x7f800000);
     float v[4] = {INF, INF, INF, INF};
     if (k + 3 < N) {
-        const float4* __restrict__ pp = reinterpret_cast<const float4*>(r + (size_t)k * 3);
-        const float4 f0 = pp[0], f1 = pp[1], f2 = pp[2];
+        const float4_a4* __restrict__ pp = reinterpret_cast<const float4_a4*>(r + (size_t)k * 3);    // 4-byte aligned only: see float4_a4
+        const float4_a4 f0 = pp[0], f1 = pp[1], f2 = pp[2];
         const f32x2 qxy = {qx, qy}, qzx = {qz, qx}, qyz = {qy, qz};
         const f32x2 a = f32x2{f0.x, f0.y} - qxy, bq = f32x2{f0.z, f0.w} - qzx, c = f32x2{f1.x, f1.y} - qyz;
         const f32x2 e = f32x2{f1.z, f1.w} - qxy, f = f32x2{f2.x, f2.y} - qzx, h = f32x2{f2.z, f2.w} - qyz;

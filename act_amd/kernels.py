@@ -167,13 +167,18 @@ def gemm(a, b, a_kmajor=True, b_kmajor=True, bias=None, act=EPI_NONE, aux=None, 
 
 def gemm_tn_grouped(pairs, want_bias=True, splits=0):
     """[(dy [T,M], x [T,N]), ...] -> ([dW_p = dy_p^T . x_p  [M,N]], [db_p = column sums of dy_p  [M]]) in ONE launch (+ one reduction launch
-    for the K ranges): the weight / bias gradients of several Linears that share the token dimension (csrc/gemm_grouped.hip)."""
+    for the K ranges): the weight / bias gradients of several Linears that share the token dimension (csrc/gemm_grouped.hip).
+    splits <= 0: the library's count, capped by the shared workspace (_WS_BYTES) exactly as the composite block backward caps it, so the
+    per-kernel and the composite host paths fold the same K ranges in the same order (bit-identical) for any model width."""
+    if not pairs or len(pairs) > 8:
+        raise _C.ActHipError(f"gemm_tn_grouped: 1..8 problems per launch, got {len(pairs)}")
+    pairs = [(_f32rows(dy, "dy"), _f32rows(x, "x")) for dy, x in pairs]      # fp32, unit inner stride, float4-able rows (else a contiguous copy)
     T = pairs[0][0].shape[0]
     dev = pairs[0][0].device
     probs = (GemmTnProblem * len(pairs))()
     dws, dbs = [], []
     for i, (dy, x) in enumerate(pairs):
-        if dy.shape[0] != T or x.shape[0] != T:
+        if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != T or x.shape[0] != T:
             raise _C.ActHipError("gemm_tn_grouped: every operand needs the same number of rows")
         M, N = dy.shape[1], x.shape[1]
         dw = torch.empty(M, N, dtype=torch.float32, device=dev)
@@ -181,9 +186,13 @@ def gemm_tn_grouped(pairs, want_bias=True, splits=0):
         dws.append(dw); dbs.append(db)
         probs[i] = GemmTnProblem(_C.ptr_rows(dy).value, dy.stride(0), _C.ptr_rows(x).value, x.stride(0), dw.data_ptr(), N, M, N,
                                  db.data_ptr() if db is not None else None)
+    ws = workspace(dev)
     if splits <= 0:
         splits = lib.act_sgemm_tn_grouped_splits(probs, len(pairs), T)
-    ws = workspace(dev, lib.act_sgemm_tn_grouped_workspace(probs, len(pairs), T, splits))
+        while splits > 1 and lib.act_sgemm_tn_grouped_workspace(probs, len(pairs), T, splits) > ws.numel() * 4:
+            splits -= 1
+    else:
+        ws = workspace(dev, lib.act_sgemm_tn_grouped_workspace(probs, len(pairs), T, splits))      # an explicit count gets the space it needs
     check(lib.act_sgemm_tn_grouped_f32(probs, len(pairs), T, splits, ptr(ws), ws.numel() * 4, stream()), "act_sgemm_tn_grouped_f32")
     return dws, dbs
 

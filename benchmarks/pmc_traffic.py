@@ -28,12 +28,15 @@ def fold(name):
     if m:
         ak, bk = m.group(1) == "true", m.group(2) == "true"
         return "sgemm_nt" if ak and bk else ("sgemm_nn" if ak else ("sgemm_tn" if not bk else "sgemm_tt"))
-    if n.startswith("sgemm_nt16_kernel"):
+    if n.startswith("sgemm_nt16_kernel") or n.startswith("sgemm_nt32_kernel") or n.startswith("sgemm_nt_asm_kernel"):
         return "sgemm_nt"
+    m = re.match(r"sgemm_q_asm_kernel<\d+, \d+, (true|false)", n)        # round 4: NN / TN on the hand-scheduled loop (A_K = true: NN)
+    if m:
+        return "sgemm_nn" if m.group(1) == "true" else "sgemm_tn"
     m = re.match(r"sgemm_q16_kernel<\d+, \d+, (true|false), (true|false)", n)
     if m:
         return "sgemm_nn" if m.group(1) == "true" else "sgemm_tn"
-    if n.startswith("sgemm_tn_skinny_kernel") or n.startswith("sgemm_tn_grouped_kernel"):
+    if n.startswith("sgemm_tn_skinny_kernel") or n.startswith("sgemm_tn_grouped_kernel") or n.startswith("sgemm_tn_grouped_asm_kernel"):
         return "sgemm_tn"
     return re.sub(r"<.*", "", n)[:60]
 

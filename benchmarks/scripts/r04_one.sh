@@ -1,1 +1,3 @@
-cd $GRAFT_REPO_ROOT; python -m pytest tests/test_gpu_dense.py -q -m gpu -x -k "hand_scheduled or scalar_fallback or first_use or autotuner" 2>&1 | grep -v Warning | tail -30
+cd $GRAFT_REPO_ROOT; python -m pytest tests -q -m gpu -x -k "grouped or maxpool or knn or group or block or composite or point" 2>&1 | grep -v Warning | tail -12
+ACT_GEMM_GROUPED_ASM=0 python bench.py --no-cpu-baseline --no-other-workloads 2>/dev/null | cut -c1-250
+python bench.py --no-cpu-baseline --no-other-workloads 2>/dev/null | cut -c1-250

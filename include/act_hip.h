@@ -163,8 +163,10 @@ typedef struct {
     const int32_t* ep_arg;
 } act_gemm_fx_t;
 size_t act_sgemm_fx_tile_stats_floats(int M, int N);
-/* The (1,1) fused launches with K % 32 == 0 can run on the hand-scheduled main loop (csrc/gemm_nt_asm_kernel.h), bit-identical to the compiler-scheduled
- * kernels.  on = 0 / 1 selects (returns the previous setting), on < 0 queries; initial value: env ACT_GEMM_FX_ASM (default 0: not faster at K <= 512). */
+/* Which fused launches run on the hand-scheduled main loops (csrc/gemm_nt_asm_kernel.h, gemm_q_asm_kernel.h) instead of the compiler-scheduled kernels;
+ * bit-identical either way.  Bit 0: the (1,1) launches with K % 32 == 0 (default off: not faster at K <= 512); bit 1: the (1,0) launch with the
+ * epilogue-side ep_src / ep_arg term only (default off: 574 -> 598 us at K = 512).  on >= 0 sets the mask (returns the previous one), on < 0 queries; initial value: env
+ * ACT_GEMM_FX_ASM (default 0). */
 int act_gemm_fx_asm(int on);
 int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                      const act_gemm_epilogue_t* epilogue, const act_gemm_fx_t* fx, float* workspace, size_t workspace_bytes, act_stream_t stream);
