@@ -684,6 +684,44 @@ def cosine_distill_loss(student, teacher):
     return CosineLossFn.apply(student, teacher).reshape(())
 
 
+def pairwise_distill_loss(student, teacher, kind, num_mask, temperature=0.07, lambda_param=5e-3):
+    """loss: 'ntxent' | 'barlow' of ACT_PointDistillation (models/act.py:1192-1195,1250-1254): per cloud lightly's NTXentLoss(temperature=0.07) /
+    BarlowTwinsLoss(lambda_param=5e-3) on (student[b], teacher[b]) -- the masked tokens of one cloud are the "batch" of the contrastive loss -- divided by
+    num_mask, summed over the clouds, / batch size.  lightly 1.2.28 is not importable here: the algorithms are the published ones (oracle/layers.py
+    restates them the same way; parity against the package itself is unpinned).  Not in any shipped recipe, so not a tuned path: the matrix products run
+    on the library's GEMMs through K.linear (forward and both gradients), the row-wise pieces are a handful of elementwise / reduction ops.
+      ntxent: the 2n x 2n similarity blocks of 16 clouds at a time are the diagonal blocks of ONE [16 * 2n, C] x [16 * 2n, C]^T product.
+      barlow: one [D, n] x [D, n]^T product per cloud."""
+    B, n, C = student.shape
+    s = _f32c(student); t = _f32c(teacher)
+    if kind == "ntxent":
+        z = torch.cat([torch.nn.functional.normalize(s, dim=2), torch.nn.functional.normalize(t, dim=2)], dim=1)       # [B, 2n, C]
+        m = 2 * n
+        eye = torch.eye(m, dtype=torch.bool, device=s.device)
+        partner = torch.cat([torch.arange(n, m, device=s.device), torch.arange(0, n, device=s.device)])
+        total = s.new_zeros(())
+        for c0 in range(0, B, 16):
+            zc = z[c0:c0 + 16].reshape(-1, C)
+            g = zc.shape[0] // m
+            sim = linear(zc, zc).view(g, m, g, m)
+            blk = torch.diagonal(sim, dim1=0, dim2=2).permute(2, 0, 1) / temperature                                   # [g, 2n, 2n]
+            pos = blk.gather(2, partner.view(1, m, 1).expand(g, m, 1)).squeeze(2)
+            lse = torch.logsumexp(blk.masked_fill(eye, float("-inf")), dim=2)
+            total = total + (lse - pos).mean(dim=1).sum()
+        return (total / num_mask / B).reshape(1)
+    if kind == "barlow":
+        za = (s - s.mean(1, keepdim=True)) / s.std(1, keepdim=True)                                                    # unbiased std along the tokens
+        zb = (t - t.mean(1, keepdim=True)) / t.std(1, keepdim=True)
+        eye = torch.eye(C, device=s.device)
+        w = torch.full((C, C), lambda_param, device=s.device); w.fill_diagonal_(1.0)
+        total = s.new_zeros(())
+        for b in range(B):
+            c = linear(za[b].t().contiguous(), zb[b].t().contiguous()) / n                                             # z_a^T z_b / n  [C, C]
+            total = total + ((c - eye).pow(2) * w).sum()
+        return (total / num_mask / B).reshape(1)
+    raise _C.ActHipError(f"pairwise_distill_loss: unknown kind {kind!r}")
+
+
 class RegressionLossFn(torch.autograd.Function):
     """loss: 'l2' (nn.MSELoss) / 'smoothl1' (nn.SmoothL1Loss), mean over all elements (models/act.py:1186-1191,1255)."""
 

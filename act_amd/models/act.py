@@ -446,9 +446,8 @@ class ACT_PointDistillation(nn.Module):
         self._prefetched = None
         self._teacher_graph = None
         self.loss_type = config.loss
-        if self.loss_type not in ('cosine', 'l2', 'smoothl1'):
-            raise NotImplementedError(f"loss: {self.loss_type!r} -- 'cosine' (the ACT recipe), 'l2' and 'smoothl1' are on this path; "
-                                      "'ntxent' / 'barlow' need the lightly package the reference imports")
+        if self.loss_type not in ('cosine', 'l2', 'smoothl1', 'ntxent', 'barlow'):     # models/act.py:1184-1195
+            raise NotImplementedError(f"loss: {self.loss_type!r} -- the reference knows 'cosine' (the ACT recipe), 'l2', 'smoothl1', 'ntxent' and 'barlow'")
 
     def build_tokenizer(self, cfg):
         self.dvae_tokenizer = ACTPromptedDiscreteVAEwithVIT(cfg)
@@ -574,6 +573,8 @@ class ACT_PointDistillation(nn.Module):
             student_feat = self._project(x_vis)
             if self.loss_type == 'cosine':
                 return K.cosine_distill_loss(student_feat, teacher_feat)
+            if self.loss_type in ('ntxent', 'barlow'):                      # (num_mask = 1 without a decoder, models/act.py:1239)
+                return K.pairwise_distill_loss(student_feat, teacher_feat, self.loss_type, 1)
             return K.regression_distill_loss(student_feat, teacher_feat, self.loss_type)
         num_mask = self.ACT_encoder.num_mask
         vis_idx, msk_idx = split_indices(mask, num_mask)
@@ -597,5 +598,10 @@ class ACT_PointDistillation(nn.Module):
             loss = K.cosine_distill_loss(student_feat, teacher_feat)
             if student_feat_global is not None:                          # models/act.py:1248-1249
                 loss = loss + K.cosine_distill_loss(student_feat_global, teacher_feat)
+            return loss
+        if self.loss_type in ('ntxent', 'barlow'):                          # models/act.py:1250-1254: loss_func per cloud / num_mask, the global term likewise
+            loss = K.pairwise_distill_loss(student_feat, teacher_feat, self.loss_type, num_mask)
+            if student_feat_global is not None:
+                loss = loss + K.pairwise_distill_loss(student_feat_global, teacher_feat, self.loss_type, num_mask)
             return loss
         return K.regression_distill_loss(student_feat, teacher_feat, self.loss_type)   # 'l2' / 'smoothl1': the global term is not used (:1255)

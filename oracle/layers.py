@@ -228,5 +228,42 @@ def cosine_distill_loss(student, teacher):
     return loss.mean() / B
 
 
+def ntxent_pair_loss(out0, out1, temperature=0.07):
+    """lightly 1.2.28 (requirements.txt:14; NOT installed in this image -> restated from its published source, parity unpinned) loss.NTXentLoss
+    (temperature, memory_bank_size=0).forward(out0, out1) on two [n, C] views: rows L2-normalised, the 2n x 2n cosine matrix / temperature with
+    its diagonal removed, cross-entropy (mean over the 2n anchors) towards the other view of the same row."""
+    n = out0.shape[0]
+    z = torch.cat([F.normalize(out0, dim=1), F.normalize(out1, dim=1)], dim=0)
+    logits = z @ z.t() / temperature
+    logits = logits[~torch.eye(2 * n, dtype=torch.bool)].view(2 * n, -1)
+    labels = torch.arange(n)
+    labels = torch.cat([labels + n - 1, labels])
+    return F.cross_entropy(logits, labels)
+
+
+def barlow_pair_loss(z_a, z_b, lambda_param=5e-3):
+    """lightly 1.2.28 loss.BarlowTwinsLoss(lambda_param).forward(z_a, z_b) on two [n, D] views (same provenance note as ntxent_pair_loss): both
+    standardised along the batch (unbiased std), c = z_a^T z_b / n, sum of (c - I)^2 with the off-diagonal terms weighted by lambda."""
+    n, d = z_a.shape
+    za = (z_a - z_a.mean(0)) / z_a.std(0)
+    zb = (z_b - z_b.mean(0)) / z_b.std(0)
+    c = za.t() @ zb / n
+    c_diff = (c - torch.eye(d)).pow(2)
+    off = ~torch.eye(d, dtype=torch.bool)
+    c_diff = torch.where(off, c_diff * lambda_param, c_diff)
+    return c_diff.sum()
+
+
+def pairwise_distill_loss(student, teacher, kind, num_mask):
+    """models/act.py:1243-1254 for the losses that are neither 'cosine' nor 'l1' / 'l2' named: per cloud loss_func(student[b], teacher[b]) / num_mask,
+    summed over the batch, / batch size.  kind: 'ntxent' (temperature 0.07, :1193) or 'barlow' (lambda 5e-3, :1195)."""
+    B = student.shape[0]
+    fn = ntxent_pair_loss if kind == "ntxent" else barlow_pair_loss
+    loss = student.new_zeros(1)
+    for b in range(B):
+        loss = loss + fn(student[b], teacher[b]) / num_mask
+    return loss.mean() / B
+
+
 def trunc_normal_(t, std=0.02):
     return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)

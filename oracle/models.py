@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from . import point_ops as P
 from .layers import (Draws, Encoder, DGCNN, Decoder, TransformerEncoder, TransformerDecoder, BlockList,
-                     cosine_distill_loss, trunc_normal_, knn_graph_ref)
+                     cosine_distill_loss, pairwise_distill_loss, trunc_normal_, knn_graph_ref)
 
 
 class edict(dict):
@@ -343,7 +343,9 @@ class ACT_PointDistillation(nn.Module):
                         nn.init.constant_(m.bias, 0)
             trunc_normal_(self.mask_token)
 
-    def _loss(self, student, teacher):              # models/act.py:1186-1191,1243-1256
+    def _loss(self, student, teacher, num_mask=1):  # models/act.py:1186-1195,1243-1256
+        if self.loss_type in ("ntxent", "barlow"):
+            return pairwise_distill_loss(student, teacher, self.loss_type, num_mask)
         if self.loss_type == "l2":
             return F.mse_loss(student, teacher)
         if self.loss_type == "smoothl1":
@@ -372,7 +374,12 @@ class ACT_PointDistillation(nn.Module):
         pos_full = torch.cat([pos_vis, pos_msk], dim=1)
         student = self.proj_head(self.ACT_decoder(x_full, pos_full, num_mask, draws))
         teacher = teacher[mask].reshape(B, -1, student.shape[-1])
-        loss = self._loss(student, teacher)
+        loss = self._loss(student, teacher, num_mask)
+        if self.cls_loss and self.loss_type in ("ntxent", "barlow"):                # models/act.py:1252-1253: the global term, same loss
+            x_sh = torch.cat([x_cls.unsqueeze(1), x_shallow, self.mask_token.expand(B, num_mask, -1)], dim=1)
+            pos_sh = torch.cat([self.cls_pos.expand(B, -1, -1), pos_full], dim=1)
+            student_g = self.proj_head(self.ACT_decoder(x_sh, pos_sh, num_mask, draws, tag="dec_shallow"))
+            loss = loss + self._loss(student_g, teacher, num_mask)
         if self.cls_loss and self.loss_type == "cosine":                          # second decoder pass on [cls, shallow visible tokens, mask tokens] (models/act.py:1231-1236,1248-1249)
             x_sh = torch.cat([x_cls.unsqueeze(1), x_shallow, self.mask_token.expand(B, num_mask, -1)], dim=1)
             pos_sh = torch.cat([self.cls_pos.expand(B, -1, -1), pos_full], dim=1)

@@ -137,6 +137,40 @@ def test_stage2_tiny_vs_oracle_all_draws_active(dev):
             assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
 
 
+@pytest.mark.parametrize("kind,cls_loss", [("ntxent", False), ("barlow", False), ("ntxent", True)])
+def test_stage2_contrastive_losses_vs_oracle(dev, kind, cls_loss):
+    """loss: ntxent | barlow (models/act.py:1192-1195,1250-1254) at the tiny geometry, every draw replayed: loss and every parameter gradient
+    against the oracle, with and without the cls_loss global term.  (Restated from lightly 1.2.28's published algorithms on both sides: the
+    package is absent, parity against it is unpinned -- oracle/layers.py.)"""
+    import copy
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from act_amd.utils.draws import Draws
+    cfg = copy.deepcopy(TINY_STAGE2)
+    cfg["loss"] = kind
+    if cls_loss:
+        cfg["transformer_config"]["cls_loss"] = True
+        cfg["transformer_config"]["register_shallow_hook"] = 1
+    torch.manual_seed(1)
+    oracle = fill_module(OM.ACT_PointDistillation(OM.edict(cfg)), "ct.").train()
+    model = build_model_from_cfg(EasyDict(cfg))
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model.to(dev).train()
+    pts = torch.from_numpy(clouds(7, 4, TINY_N))
+    rec = OL.Draws(record=True)
+    lo = oracle(pts, rec); lo.backward()
+    lg = model(pts.to(dev), draws=Draws(rec.table, device=dev)); lg.backward()
+    assert abs(lg.item() - lo.item()) <= TOL * max(1.0, abs(lo.item())), (lg.item(), lo.item())
+    od = dict(oracle.named_parameters())
+    checked = 0
+    for n, p in model.named_parameters():
+        if p.requires_grad and od[n].grad is not None and p.grad is not None:
+            assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
+            checked += 1
+    assert checked > 20
+
+
 @pytest.mark.parametrize("B", [2, 8, 128])
 def test_stage2_full_geometry_vs_oracle(dev, B):
     """configs[1] geometry (N=1024, G=64, M=32, d=384 x 12, ViT-B teacher) at B = 2, B = 8 and the HEADLINE batch B = 128 (BatchNorm over 262,144

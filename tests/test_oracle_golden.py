@@ -422,3 +422,28 @@ def test_chamfer_fma_contract_oracle_modes():
                     best, bi = d, k
             assert d1[b, j] == best and i1[b, j] == bi
     assert np.all(np.abs(d1 - p1[0]) <= 2 * np.spacing(np.maximum(d1, p1[0]))) and np.all(np.abs(d2 - p1[1]) <= 2 * np.spacing(np.maximum(d2, p1[1])))
+
+
+def test_contrastive_distillation_losses_known_answers():
+    """loss: ntxent | barlow (models/act.py:1192-1195 -> lightly 1.2.28 NTXentLoss(0.07) / BarlowTwinsLoss(5e-3); the package is not installed here,
+    so the oracle restates the published algorithms -- parity against the package itself is unpinned).  Closed-form cases pin the restatement:
+    * NT-Xent, both views equal and the n rows mutually orthogonal: every anchor sees one positive of similarity 1 and 2n - 2 negatives of
+      similarity 0 -> loss = -log(e^(1/T) / (e^(1/T) + 2n - 2));
+    * Barlow Twins, both views equal with two uncorrelated columns over n = 4 rows: c = (n - 1) / n * I (unbiased std) -> loss = 2 / n^2;
+      a perfectly correlated column pair adds lambda * ((n - 1) / n)^2 per off-diagonal entry;
+    * the ACT wrapper: per cloud / num_mask, mean over the batch (models/act.py:1250-1257)."""
+    import math
+    from oracle import layers as OL
+    n, T = 6, 0.07
+    x = torch.eye(n, 16)
+    want = -math.log(math.exp(1 / T) / (math.exp(1 / T) + 2 * n - 2))
+    assert abs(OL.ntxent_pair_loss(x, 3.0 * x, T).item() - want) <= 1e-6                 # (row scaling is normalised away)
+    za = torch.tensor([[1., 1.], [-1., 1.], [1., -1.], [-1., -1.]])
+    assert abs(OL.barlow_pair_loss(za, za, 5e-3).item() - 2.0 / 16.0) <= 1e-6
+    zc = torch.tensor([[1., 2.], [-1., -2.], [1., 2.], [-1., -2.]])                      # column 1 = 2 x column 0: c = 3/4 everywhere
+    assert abs(OL.barlow_pair_loss(zc, zc, 5e-3).item() - (2.0 / 16.0 + 2 * 5e-3 * 0.5625)) <= 1e-6
+    torch.manual_seed(3)
+    s, t_ = torch.randn(3, 5, 8), torch.randn(3, 5, 8)
+    for kind, fn in (("ntxent", OL.ntxent_pair_loss), ("barlow", OL.barlow_pair_loss)):
+        want = sum(fn(s[b], t_[b]).item() / 5 for b in range(3)) / 3
+        assert abs(OL.pairwise_distill_loss(s, t_, kind, 5).item() - want) <= 1e-6
