@@ -304,13 +304,17 @@ VARIANTS = [
 ]
 
 
-def main():
-    here = os.path.dirname(os.path.abspath(__file__))
+def render():
     parts = [HEADER]
     for c in VARIANTS:
         parts += [gen_function(c), ""]
+    return "\n".join(parts)
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "gemm_nt_asm_loop.h"), "w") as f:
-        f.write("\n".join(parts))
+        f.write(render())
 
 
 if __name__ == "__main__":
