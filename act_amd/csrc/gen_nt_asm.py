@@ -22,13 +22,16 @@ Run: python gen_nt_asm.py   (writes gemm_nt_asm_loop.h next to this file; the he
 import os
 
 S_A, S_B, S_CNT, S_STEP_A, S_STEP_B = 60, 62, 64, 65, 66     # pinned SGPRs: A base (pair), B base (pair), K-tile count, bytes per K tile of A / B
+S_NA, S_NB, S_HAS = 68, 70, 72                               # continuous variants: bases of the NEXT output tile's K-tile 0, 1 = there is one
 
 
 class Cfg:
-    def __init__(self, TM, TN, WM=2, WN=2, a_row=False, b_row=False, pgr=1, affine=False, a_sum=False, **sched):
+    def __init__(self, TM, TN, WM=2, WN=2, a_row=False, b_row=False, pgr=1, affine=False, a_sum=False, cont=False, **sched):
         self.TM, self.TN, self.WM, self.WN = TM, TN, WM, WN
         self.a_row, self.b_row, self.pgr, self.affine, self.a_sum = a_row, b_row, pgr, affine, a_sum
         assert not (affine and a_sum)
+        self.cont = cont
+        assert not cont or pgr == 1
         assert not a_row or TM == 4, "row-contiguous A: 64-row wave extent"
         assert not b_row or TN == 4, "row-contiguous B: 64-column wave extent"
         assert not affine or not a_row
@@ -59,6 +62,11 @@ class Cfg:
             self.sc = n; n += 4
             self.sh = n; n += 4
             self.sx = n; n += 1
+        self.sv8 = self.sv4 = -1
+        if cont:                         # scalars arrive in VGPRs and are moved to the pinned SGPRs inside the asm (see gen_function)
+            n += n & 1
+            self.sv8 = n; n += 8         # pa.lo, pa.hi, pb.lo, pb.hi, pa_next.lo, pa_next.hi, pb_next.lo, pb_next.hi
+            self.sv4 = n; n += 4         # ntiles, step_a, step_b, has_next
         self.bs = -1
         if a_sum:                        # running sums of the A values this thread stages (column sums of A = bias gradients of a weight-gradient GEMM)
             n += n & 1
@@ -75,6 +83,7 @@ class Cfg:
         if self.pgr != 1: s += f"_pg{self.pgr}"
         if self.affine: s += "_affine"
         if self.a_sum: s += "_asum"
+        if self.cont: s += "_cont"
         return s
 
 
@@ -136,10 +145,13 @@ def gen_loop(c):
             k += step
         return k
 
-    def iteration(stage, do_write, do_load, vmwait):
+    def switch_tile():
+        return [f"s_mov_b32 s{S_A}, s{S_NA}", f"s_mov_b32 s{S_A + 1}, s{S_NA + 1}", f"s_mov_b32 s{S_B}, s{S_NB}", f"s_mov_b32 s{S_B + 1}, s{S_NB + 1}"]
+
+    def iteration(stage, do_write, do_load, vmwait, reads0=True):
         """stage: LDS stage of tile t.  do_write: tile t+1 exists (staged registers -> stage^1, barrier, set-0 reads); do_load: tile t+1+PGR exists;
         vmwait: loads that may stay in flight when the staged tile is needed"""
-        emit(f"; ---- iteration: stage {stage}, write {int(do_write)}, load {int(do_load)}")
+        emit(f"; ---- iteration: stage {stage}, write {int(do_write)}, load {do_load}")
         sset = (stage ^ 1) % c.pgr                            # staging set of tile t+1 (and of tile t+1+PGR): tile index mod PGR
         fa = {}
         k = place(fa, reads(1, stage, 1), o["r1_start"], o["r1_step"])
@@ -177,15 +189,25 @@ def gen_loop(c):
             else:
                 w = wa + wbw
                 k = place(fb, [[wait, w[0]]] + [[x] for x in w[1:]], o["w_start"], o["w_step"])
-            if do_load:
+            if do_load:                  # "switch": the loads fetch K-tile 0 of the NEXT output tile (continuous variants)
                 l = loads(sset)
-                k = place(fb, [advance() + [l[0]]] + [[x] for x in l[1:]], k, o["l_step"])
+                k = place(fb, [(switch_tile() if do_load == "switch" else advance()) + [l[0]]] + [[x] for x in l[1:]], k, o["l_step"])
             bpos = max(P - 1 - min(o["tail"], P - 1), k)
             place(fb, [["s_waitcnt lgkmcnt(0)", "s_barrier"]], bpos, 1)
-            place(fb, [[x] for x in reads(0, stage ^ 1, 0)], bpos + o["r0_gap"], o["r0_step"])
+            if reads0:
+                place(fb, [[x] for x in reads(0, stage ^ 1, 0)], bpos + o["r0_gap"], o["r0_step"])
         emit("s_waitcnt lgkmcnt(0)")
         phase(1, fb)
 
+    # ---------------- continuous variants: every scalar operand comes in a VGPR (a persistent tile loop keeps wave-uniform values wherever the compiler
+    # likes, and a physical-SGPR asm operand fed from a VGPR is a compile error) and is moved to its SGPR here; VALU-writes-SGPR -> VMEM-reads-it needs 5 wait states
+    if c.cont:
+        emit("s_nop 7")                  # (the compiler's last VALU writes of the operand VGPRs are outside its hazard recogniser's view of this block)
+        for q, sreg in enumerate([S_A, S_A + 1, S_B, S_B + 1, S_NA, S_NA + 1, S_NB, S_NB + 1]):
+            emit(f"v_readfirstlane_b32 s{sreg}, v{c.sv8 + q}")
+        for q, sreg in enumerate([S_CNT, S_STEP_A, S_STEP_B, S_HAS]):
+            emit(f"v_readfirstlane_b32 s{sreg}, v{c.sv4 + q}")
+        emit("s_nop 7")
     # ---------------- prologue: tile 0 is in LDS stage 0 and visible (C++ side); bases point at tile 0
     for q in range(1, c.pgr + 1):
         emit(f"s_cmp_lt_u32 s{S_CNT}, {q + 1}")
@@ -206,6 +228,15 @@ def gen_loop(c):
         emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 2")
         emit("s_branch 20b")
         emit("30:")
+        if c.cont:
+            # continuous K stream (even K-tile counts only): the last two iterations of this output tile fetch K-tile 0 of the NEXT one and leave it in
+            # LDS stage 0 behind a barrier -- the next call starts its MFMAs at once instead of waiting for a global load + LDS store + barrier
+            emit(f"s_cmp_eq_u32 s{S_HAS}, 0")
+            emit("s_cbranch_scc1 31f")
+            iteration(0, True, "switch", 0)
+            iteration(1, True, False, 0, reads0=False)
+            emit("s_branch 50f")
+            emit("31:")
         emit(f"s_cmp_eq_u32 s{S_CNT}, 1")
         emit("s_cbranch_scc1 41f")
         emit(f"s_cmp_eq_u32 s{S_CNT}, 2")
@@ -260,8 +291,12 @@ def gen_function(c):
     lay = ("A [K][M]" if c.a_row else "A [M][K]") + ", " + ("B [K][N]" if c.b_row else "B [N][K]")
     text.append(f"// {lay}; {c.WM} x {c.WN} waves, wave tile {16 * TM} x {16 * TN} (workgroup {c.BM} x {c.BN}), {c.total} VGPRs, LDS {2 * c.STAGE} B, "
                 f"global prefetch {c.pgr}; schedule {c.sched}")
-    text.append(f"__device__ __forceinline__ void {c.name()}(f32x4 (&acc)[{TM}][{TN}], const float* pa, const float* pb, int ntiles, unsigned step_a, unsigned step_b,")
-    text.append(f"        {vt[c.NA]} offa, {vt[c.NB]} offb, unsigned wbase_a, unsigned wbase_b, unsigned rbase_a, unsigned rbase_b" + (", unsigned sx" if c.affine else "") + (", f32x4& bsum" if c.a_sum else "") + ") {")
+    if c.cont:
+        text.append(f"__device__ __forceinline__ void {c.name()}(f32x4 (&acc)[{TM}][{TN}], u32x8 bases, u32x4 scalars,   // bases: pa, pb, pa_next, pb_next (lo, hi each); scalars: ntiles, step_a, step_b, has_next")
+        text.append(f"        {vt[c.NA]} offa, {vt[c.NB]} offb, unsigned wbase_a, unsigned wbase_b, unsigned rbase_a, unsigned rbase_b) {{")
+    else:
+        text.append(f"__device__ __forceinline__ void {c.name()}(f32x4 (&acc)[{TM}][{TN}], const float* pa, const float* pb, int ntiles, unsigned step_a, unsigned step_b,")
+        text.append(f"        {vt[c.NA]} offa, {vt[c.NB]} offb, unsigned wbase_a, unsigned wbase_b, unsigned rbase_a, unsigned rbase_b" + (", unsigned sx" if c.affine else "") + (", f32x4& bsum" if c.a_sum else "") + ") {")
     text.append("    asm volatile(")
     for l in lines:
         text.append(f'        "{l}\\n"')
@@ -270,15 +305,22 @@ def gen_function(c):
         for j in range(TN):
             a = c.acc + 4 * (i * TN + j)
             outs.append(f'"={{v[{a}:{a + 3}]}}"(acc[{i}][{j}])')
-    ios = [f'"+{{s[{S_A}:{S_A + 1}]}}"(pa)', f'"+{{s[{S_B}:{S_B + 1}]}}"(pb)', f'"+{{s{S_CNT}}}"(ntiles)']
-    if c.affine: ios.append(f'"+{{v{c.sx}}}"(sx)')
-    if c.a_sum: ios.append(f'"+{{v[{c.bs}:{c.bs + 3}]}}"(bsum)')
-    text.append("        : " + ", ".join(outs) + ",")
-    text.append("          " + ", ".join(ios))
-    ins = [f'"{{s{S_STEP_A}}}"(step_a)', f'"{{s{S_STEP_B}}}"(step_b)', f'"{{{vr(c.offa, c.NA)}}}"(offa)', f'"{{{vr(c.offb, c.NB)}}}"(offb)',
-           f'"{{v{c.wb}}}"(wbase_a)', f'"{{v{c.wbb}}}"(wbase_b)', f'"{{v{c.ra}}}"(rbase_a)', f'"{{v{c.rb}}}"(rbase_b)']
-    text.append("        : " + ", ".join(ins))
+    if c.cont:
+        text.append("        : " + ", ".join(outs))
+        ins = [f'"{{{vr(c.sv8, 8)}}}"(bases)', f'"{{{vr(c.sv4, 4)}}}"(scalars)', f'"{{{vr(c.offa, c.NA)}}}"(offa)', f'"{{{vr(c.offb, c.NB)}}}"(offb)',
+               f'"{{v{c.wb}}}"(wbase_a)', f'"{{v{c.wbb}}}"(wbase_b)', f'"{{v{c.ra}}}"(rbase_a)', f'"{{v{c.rb}}}"(rbase_b)']
+        text.append("        : " + ", ".join(ins))
+    else:
+        ios = [f'"+{{s[{S_A}:{S_A + 1}]}}"(pa)', f'"+{{s[{S_B}:{S_B + 1}]}}"(pb)', f'"+{{s{S_CNT}}}"(ntiles)']
+        if c.affine: ios.append(f'"+{{v{c.sx}}}"(sx)')
+        if c.a_sum: ios.append(f'"+{{v[{c.bs}:{c.bs + 3}]}}"(bsum)')
+        text.append("        : " + ", ".join(outs) + ",")
+        text.append("          " + ", ".join(ios))
+        ins = [f'"{{s{S_STEP_A}}}"(step_a)', f'"{{s{S_STEP_B}}}"(step_b)', f'"{{{vr(c.offa, c.NA)}}}"(offa)', f'"{{{vr(c.offb, c.NB)}}}"(offb)',
+               f'"{{v{c.wb}}}"(wbase_a)', f'"{{v{c.wbb}}}"(wbase_b)', f'"{{v{c.ra}}}"(rbase_a)', f'"{{v{c.rb}}}"(rbase_b)']
+        text.append("        : " + ", ".join(ins))
     clob = [f'"v{r}"' for r in range(c.fa[0], c.clob_end)] + ([f'"v{r}"' for r in range(c.sc, c.sx)] if c.affine else [])
+    if c.cont: clob += [f'"s{r}"' for r in range(S_A, S_HAS + 1)]
     text.append("        : " + ", ".join(clob) + ', "scc", "memory");')
     text.append("}")
     return "\n".join(text)
@@ -297,6 +339,7 @@ VARIANTS = [
     Cfg(4, 4), Cfg(4, 2, **SMALL), Cfg(2, 2, r1_step=1, tail=6, **SMALL),                      # NT 128x128, 128x64, 64x64
     Cfg(4, 4, affine=True, l_step=1), Cfg(4, 2, affine=True, l_step=1, affine_per_gap=3),      # NT + A-side affine on load
     Cfg(4, 4, pgr=2), Cfg(4, 2, pgr=2, **SMALL),                                               # NT, two K tiles in flight
+    Cfg(4, 4, cont=True), Cfg(4, 2, cont=True, **SMALL), Cfg(2, 2, cont=True, r1_step=1, tail=6, **SMALL),   # NT, continuous K stream across output tiles (persistent workgroups)
     Cfg(4, 4, b_row=True), Cfg(2, 4, b_row=True, **SMALL),                                     # NN 128x128, 64x128 (2 x 2 waves)
     Cfg(2, 4, WM=4, WN=1, b_row=True, **SMALL), Cfg(1, 4, WM=4, WN=1, b_row=True, r1_step=1, tail=6, **SMALL),   # NN 128x64, 64x64 (4 x 1 waves)
     Cfg(4, 4, a_row=True, b_row=True),                                                         # TN 128x128
