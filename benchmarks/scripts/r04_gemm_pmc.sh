@@ -1,6 +1,6 @@
 # where do the non-MFMA cycles of the NT kernel go?  PMC passes (one group per run) over benchmarks/gemm_pmc_probe.py: our kernel next to hipBLASLt's
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
-ARGS="${GEMM_ARGS:-8192 3072 768 11}"
+ARGS="${GEMM_ARGS:-8192 3072 768 32}"
 i=0
 for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_ACTIVE_INST_SCA" \
@@ -12,6 +12,6 @@ for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
   timeout 300 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $R/gpurun_out/gemm_pmc/p$i -- python $R/benchmarks/gemm_pmc_probe.py $ARGS > $R/gpurun_out/gemm_pmc_p$i.log 2>&1 || tail -3 $R/gpurun_out/gemm_pmc_p$i.log
 done
 cd $R
-python benchmarks/pmc_by_kernel.py "sgemm_nt16|Cijk" gpurun_out/gemm_pmc/p* > gpurun_out/gemm_pmc_summary.txt
+python benchmarks/pmc_by_kernel.py "sgemm_nt_asm|sgemm_nt16|Cijk" gpurun_out/gemm_pmc/p* > gpurun_out/gemm_pmc_summary.txt
 rm -rf gpurun_out/gemm_pmc
 cat gpurun_out/gemm_pmc_summary.txt
