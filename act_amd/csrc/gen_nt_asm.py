@@ -217,6 +217,10 @@ def gen_loop(c):
     emit("10:")
     for x in reads(0, 0, 0): emit(x)
     for r in range(TM * TN * 4): emit(f"v_mov_b32 v{c.acc + r}, 0")
+    # the kernels raise the wave priority at entry (s_setprio 3): a NEW workgroup must get through its address set-up / K-tile-0 staging while the older
+    # workgroup on the CU is in this loop, which never leaves it an issue slot at equal priority (s_memtime stamps: a 3,000-cycle prologue took 97,000 cycles and
+    # was still ~5,000 cycles short when the older workgroup finished -- the matrix pipe idles that long at every hand-over).  The loop itself runs at priority 0.
+    emit("s_setprio 0")
     FULL = (True, True, NL * (c.pgr - 1))
     if c.pgr == 1:
         # ---------------- main loop: pairs of full iterations while >= 4 tiles remain; tails: 3, 2 or 1 tiles remain, stage 0 next
