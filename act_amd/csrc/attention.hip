@@ -72,11 +72,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m = -3.0e38f, l = 0.f;
 
-    for (int kc = 0; kc < Sk; kc += ROWS) {
-        if (kc > 0) __syncthreads();                                 // previous chunk fully consumed
-        // ---- stage this chunk of K and V for every pair of the workgroup (zero rows beyond Sk).  ROWS * HD / 4 is a multiple of 256, so all threads
-        // of an iteration work on the same pair: the (cloud, head) split is wave-uniform 32-bit arithmetic done once per pair, not a 64-bit division
-        // per staged float4
+    // Staging is software-pipelined across key chunks (round 4): the float4 of chunk c+1 are requested right after chunk c went to LDS and stay in flight in
+    // registers while chunk c is multiplied -- with one 32-key chunk resident per step (JT = 1: the teacher's 64 x 128 prefix shape, 4 chunks) the loop was
+    // load-latency bound: every chunk paid a full L2 / fabric round trip between its two barriers (MfmaUtil 36 %).  ROWS * HD / 4 is a multiple of 256, so all
+    // threads of an iteration work on the same pair: the (cloud, head) split is wave-uniform 32-bit arithmetic done once per pair, not a 64-bit division per float4.
+    // Only for JT = 1 (8 float4 per thread at QT >= 2; the larger resident chunks would need 64-128 staging registers and lose a wave per SIMD or spill).
+    constexpr int ITS = ROWS * (HD / 4) / 256;
+    constexpr bool PF = (JT == 1 && QT >= 2);
+    float4 kreg[PAIRS][ITS], vreg[PAIRS][ITS];
+    auto load_chunk = [&](int kc) {
 #pragma unroll
         for (int p2 = 0; p2 < PAIRS; ++p2) {
             const unsigned pr2 = (unsigned)pair0 + p2;
@@ -84,9 +88,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
             const unsigned b2 = live ? pr2 / (unsigned)H : 0u, h2 = live ? pr2 - b2 * (unsigned)H : 0u;
             const float* k0p = a.k0 + (size_t)b2 * a.kv0_bs + h2 * HD; const float* v0p = a.v0 + (size_t)b2 * a.kv0_bs + h2 * HD;
             const float* k1p = a.k1 + (size_t)b2 * a.kv1_bs + h2 * HD; const float* v1p = a.v1 + (size_t)b2 * a.kv1_bs + h2 * HD;
-            float* kd = smem + (size_t)(p2 * 2 + 0) * ROWS * LDK; float* vd = smem + (size_t)(p2 * 2 + 1) * ROWS * LDK;
 #pragma unroll
-            for (int it = 0; it < ROWS * (HD / 4) / 256; ++it) {
+            for (int it = 0; it < ITS; ++it) {
                 const int idx = tid + 256 * it;
                 const int c4 = idx % (HD / 4), rl = idx / (HD / 4), row = kc + rl;
                 float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
@@ -99,8 +102,56 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
                         kx = *reinterpret_cast<const float4*>(k1p + of); vx = *reinterpret_cast<const float4*>(v1p + of);
                     }
                 }
-                *reinterpret_cast<float4*>(kd + rl * LDK + c4 * 4) = kx;
-                *reinterpret_cast<float4*>(vd + rl * LDK + c4 * 4) = vx;
+                kreg[p2][it] = kx; vreg[p2][it] = vx;
+            }
+        }
+    };
+    if constexpr (PF) load_chunk(0);
+    for (int kc = 0; kc < Sk; kc += ROWS) {
+        if (kc > 0) __syncthreads();                                 // previous chunk fully consumed
+        if constexpr (PF) {
+            // ---- this chunk of K and V (zero rows beyond Sk) for every pair of the workgroup: registers -> LDS, then request the next chunk
+#pragma unroll
+            for (int p2 = 0; p2 < PAIRS; ++p2) {
+                float* kd = smem + (size_t)(p2 * 2 + 0) * ROWS * LDK; float* vd = smem + (size_t)(p2 * 2 + 1) * ROWS * LDK;
+#pragma unroll
+                for (int it = 0; it < ITS; ++it) {
+                    const int idx = tid + 256 * it;
+                    const int c4 = idx % (HD / 4), rl = idx / (HD / 4);
+                    *reinterpret_cast<float4*>(kd + rl * LDK + c4 * 4) = kreg[p2][it];
+                    *reinterpret_cast<float4*>(vd + rl * LDK + c4 * 4) = vreg[p2][it];
+                }
+            }
+            if (kc + ROWS < Sk) load_chunk(kc + ROWS);
+        } else {
+            // ---- stage this chunk of K and V for every pair of the workgroup (zero rows beyond Sk).  ROWS * HD / 4 is a multiple of 256, so all threads
+            // of an iteration work on the same pair: the (cloud, head) split is wave-uniform 32-bit arithmetic done once per pair, not a 64-bit division
+            // per staged float4
+    #pragma unroll
+            for (int p2 = 0; p2 < PAIRS; ++p2) {
+                const unsigned pr2 = (unsigned)pair0 + p2;
+                const bool live = (long long)pr2 < npairs;
+                const unsigned b2 = live ? pr2 / (unsigned)H : 0u, h2 = live ? pr2 - b2 * (unsigned)H : 0u;
+                const float* k0p = a.k0 + (size_t)b2 * a.kv0_bs + h2 * HD; const float* v0p = a.v0 + (size_t)b2 * a.kv0_bs + h2 * HD;
+                const float* k1p = a.k1 + (size_t)b2 * a.kv1_bs + h2 * HD; const float* v1p = a.v1 + (size_t)b2 * a.kv1_bs + h2 * HD;
+                float* kd = smem + (size_t)(p2 * 2 + 0) * ROWS * LDK; float* vd = smem + (size_t)(p2 * 2 + 1) * ROWS * LDK;
+    #pragma unroll
+                for (int it = 0; it < ROWS * (HD / 4) / 256; ++it) {
+                    const int idx = tid + 256 * it;
+                    const int c4 = idx % (HD / 4), rl = idx / (HD / 4), row = kc + rl;
+                    float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
+                    if (live && row < Sk) {
+                        if (row < a.S0) {
+                            const unsigned of = (unsigned)row * a.ld0 + c4 * 4;
+                            kx = *reinterpret_cast<const float4*>(k0p + of); vx = *reinterpret_cast<const float4*>(v0p + of);
+                        } else {
+                            const unsigned of = (unsigned)(row - a.S0) * a.ld1 + c4 * 4;
+                            kx = *reinterpret_cast<const float4*>(k1p + of); vx = *reinterpret_cast<const float4*>(v1p + of);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(kd + rl * LDK + c4 * 4) = kx;
+                    *reinterpret_cast<float4*>(vd + rl * LDK + c4 * 4) = vx;
+                }
             }
         }
         __syncthreads();
