@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
     // threads of an iteration work on the same pair: the (cloud, head) split is wave-uniform 32-bit arithmetic done once per pair, not a 64-bit division per float4.
     // Only for JT = 1 (8 float4 per thread at QT >= 2; the larger resident chunks would need 64-128 staging registers and lose a wave per SIMD or spill).
     constexpr int ITS = ROWS * (HD / 4) / 256;
-    constexpr bool PF = (JT == 1 && QT >= 2);
+    constexpr bool PF = (JT <= 2 && QT >= 2);
     float4 kreg[PAIRS][ITS], vreg[PAIRS][ITS];
     auto load_chunk = [&](int kc) {
 #pragma unroll

@@ -181,3 +181,25 @@ def test_finetune_recipes_train_at_their_geometry(dev, recipe):
         pts, _ = RF.subsample(pool[0], cfg.npoints, RF.point_all_for(cfg.npoints, train=True))
         logits = model(pts)
     assert logits.shape == (B, cfg.model.cls_dim) and torch.isfinite(logits).all()
+
+
+def test_unlisted_batch_size_is_reproducible_across_processes():
+    """A batch size nobody tuned for (B = 96 clouds: token counts that are in no shipped table entry) with the product defaults: the first-use autotuner times
+    candidates in each process, and two processes may prefer different ones -- but every candidate of a shape produces the same bits
+    (kernels.stable_candidates), so the whole 3-step Stage-II trajectory, final loss included, is identical bit for bit across processes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ACT_GEMM_")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--batch", "96", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-instrument",
+           "--no-other-workloads"]
+    losses = []
+    for _ in range(2):
+        r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["config"]["clouds_per_gpu"] == 96
+        losses.append(d["config"]["final_loss"])
+    assert losses[0] == losses[1], losses
