@@ -8,6 +8,8 @@ results do not change, kernels.stable_candidates) at the tabled split-K, times t
 timings both beat the incumbent by more than the noise margin.
 
     python benchmarks/instep_tune.py [out.json]            # prints the decisions, writes the refreshed table (default gpurun_out/gemm_tune_instep.json)
+    INSTEP_SPLITS=1 python benchmarks/instep_tune.py ...   # additionally tries other split-K counts (NOT bit-identical to the incumbent: a table change then
+                                                           # changes fp32 summation order -- fixed per table, so still run-to-run deterministic)
 """
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -72,10 +74,11 @@ changes = {}
 for key in hot:
     inc = K._GEMM_TABLE[key]
     best, best_t = inc, base
-    for tile, bn in FAM[(key[0], key[1])]:
-        if tile == inc[0] or key[3] % bn:
-            continue
-        apply(key, (tile, inc[1]))
+    alts = [(tile, inc[1]) for tile, bn in FAM[(key[0], key[1])] if tile != inc[0] and key[3] % bn == 0]
+    if os.environ.get("INSTEP_SPLITS") == "1" and key[2] <= 8192:
+        alts += [(inc[0], sp) for sp in (1, 2, 3, 4, 6) if sp != inc[1] and key[4] // sp >= 128 and (key[4] // sp) % 32 == 0 and key[4] % sp == 0]
+    for tile, sp_ in alts:
+        apply(key, (tile, sp_))
         try:
             t1 = measure()
         except Exception as e:                            # a tile the library refuses for this shape
@@ -84,7 +87,7 @@ for key in hot:
         if t1 < best_t - MARGIN_MS:
             t2 = measure()
             if t2 < best_t - MARGIN_MS:
-                best, best_t = (tile, inc[1]), max(t1, t2)
+                best, best_t = (tile, sp_), max(t1, t2)
     apply(key, best)
     tag = "" if best == inc else f"   <-- {inc} -> {best}"
     print(f"{key}: {best_t:.3f} ms{tag}", flush=True)
