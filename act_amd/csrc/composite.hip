@@ -415,6 +415,11 @@ bool pn_pool_bwd_on_load(const act_pointnet_dims_t& d) {
     static const bool on = [] { const char* e = getenv("ACT_PN_POOL_BWD_FUSE"); return !(e && e[0] == '0'); }();
     return on && pn_fused(d) && d.C % 128 == 0;
 }
+// ... and walked sparsely instead of fed to a dense GEMM (pool_bwd.hip); ACT_PN_POOL_BWD_SPARSE=0 keeps the dense on-load products
+bool pn_pool_bwd_sparse() {
+    static const bool on = [] { const char* e = getenv("ACT_PN_POOL_BWD_SPARSE"); return !(e && e[0] == '0'); }();
+    return on;
+}
 size_t carve_pn(float* base, const act_pointnet_dims_t& d, PnSaved& sv) {
     const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
     const bool fused = pn_fused(d);
@@ -530,7 +535,12 @@ int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params
         return gemm_tn(N_, Cc, R, dy, N_, sc.act, Cc, dw, Cc, ws, wsb, s);
     };
     const bool pool_on_load = pn_pool_bwd_on_load(*d);
-    if (pool_on_load) {
+    if (pool_on_load && pn_pool_bwd_sparse()) {
+        // dh4 has one live entry per (group, channel): both products walk those instead of a dense [R, C] operand (pool_bwd.hip)
+        RUN(act_group_max_bwd_wgrad_f32(dout, sv.arg2, BG, n, C, sv.h3, 512, 512, st(sv.st2, 512, 2), st(sv.st2, 512, 3), g->c4_w, 512, ws, wsb, s));
+        CK(colsum(dout, BG, C, g->c4_b, ws, wsb, s));
+        RUN(act_group_max_bwd_matmul_f32(dout, sv.arg2, BG, n, C, w->c4_w, 512, 512, sc.da3, 512, s));
+    } else if (pool_on_load) {
         // dW4 = dh4^T . relu(bn2(h3)) and da3 = dh4 . W4 with dh4[r][c] = (arg2[r/n][c] == r % n ? dout[r/n][c] : 0) generated on load
         act_gemm_fx_t fx{}; fx.sa_src = dout; fx.sa_arg = sv.arg2; fx.group = n; fx.b_scale = st(sv.st2, 512, 2); fx.b_shift = st(sv.st2, 512, 3);
         CK(gemm_fx(0, 0, C, 512, R, nullptr, C, sv.h3, 512, g->c4_w, 512, epi0(), fx, ws, wsb, s));

@@ -271,6 +271,19 @@ int act_bn_bwd_apply_f32(const float* x, const float* dy, const float* scale, co
 int act_group_max_f32(const float* in, int G, int n, int C, float* out, int32_t* arg, act_stream_t stream);
 int act_group_max_bwd_f32(const float* dout, const int32_t* arg, int G, int n, int C, int accumulate, float* din,
                           act_stream_t stream);
+/* The two products of Encoder.backward whose left operand is the gradient of that max (models/dvae.py:209-216, :262-275: the conv in front of
+ * torch.max(feature, dim=2)).  dh[g*n + j][c] = (arg[g][c] == j ? dout[g][c] : 0) has one non-zero per (group, channel); these walk the live
+ * entries instead of running a dense [G*n, C] GEMM operand (csrc/pool_bwd.hip):
+ *   matmul: dx[g*n + j][0:N] = sum over {c : arg[g][c] == j} dout[g][c] * w[c][0:N]        (w [C, N] row-major; N in {256, 512, 1024})
+ *   wgrad:  dw[c][0:N]       = sum over g of dout[g][c] * act(x[g*n + arg[g][c]][0:N])     (x [G*n, N]; act = relu(x * scale + shift) per
+ *           column when scale/shift are given, identity when both are NULL; N % 64 == 0, C % 128 == 0)
+ * n <= 64 and 256 % n == 0; 16-byte aligned operands, leading dimensions multiples of 4.  The wgrad splits the groups over workgroups and folds
+ * the partial sums in order (workspace bytes from act_group_max_bwd_wgrad_workspace; a smaller workspace only lowers the split count). */
+int act_group_max_bwd_matmul_f32(const float* dout, const int32_t* arg, int G, int n, int C, const float* w, int ldw, int N, float* dx, int lddx,
+                                 act_stream_t stream);
+size_t act_group_max_bwd_wgrad_workspace(int G, int n, int C, int N);
+int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg, int G, int n, int C, const float* x, int ldx, int N, const float* scale,
+                                const float* shift, float* dw, int lddw, float* workspace, size_t workspace_bytes, act_stream_t stream);
 /* out[g,c] = sum over the n rows of group g (gradient of a per-group broadcast add) */
 int act_group_sum_f32(const float* in, int G, int n, int C, float* out, act_stream_t stream);
 

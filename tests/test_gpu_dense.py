@@ -711,6 +711,88 @@ def test_gemm_with_maxpool_backward_generated_on_load(K, group, R, C, N):
     assert CP.lib.act_sgemm_fx_f32(1, 0, R, N, C, None, C, W.data_ptr(), N, out.data_ptr(), N, ctypes.byref(epi), ctypes.byref(bad2), None, 0, st) != 0
 
 
+@pytest.mark.parametrize("group,G,C,N", [(32, 96, 384, 512), (64, 40, 768, 512), (32, 33, 128, 256), (16, 64, 256, 1024)])
+def test_maxpool_backward_products_walk_the_live_entries(K, group, G, C, N):
+    """csrc/pool_bwd.hip: the two products of Encoder.backward that consume the gradient of torch.max(feature, dim=2) (models/dvae.py:211,214)
+    computed from the C live entries per group instead of a dense [G*n, C] operand.  Against float64 on the materialised scatter, against the
+    dense on-load kernels (summation order differs: 1e-6), repeated calls bit-identical, a smaller workspace (fewer splits) within rounding,
+    strided operands, entries with arg outside [0, n) dropped, argument checks."""
+    import ctypes
+    import act_amd.composite as CP
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(group + C + G)
+    R = G * group
+    dout = torch.randn(G, C, generator=g).to(dev)
+    arg = torch.randint(0, group, (G, C), generator=g, dtype=torch.int32)
+    arg[0] = 0                                                           # one group with every channel on row 0 (all other rows empty)
+    arg[1, : C // 2] = group - 1
+    arg = arg.to(dev)
+    dense = torch.zeros(G, group, C, device=dev).scatter_(1, arg.long().unsqueeze(1), dout.unsqueeze(1)).reshape(R, C)
+    st = torch.cuda.current_stream().cuda_stream
+    lib = K.lib
+    # ---- dX = dh . W
+    wide = (torch.randn(C, N + 64, generator=g) * 0.1).to(dev)
+    for W, ldw in ((wide[:, :N].contiguous(), N), (wide, N + 64)):
+        out = torch.full((R, N + 4), 7.0, device=dev)
+        assert lib.act_group_max_bwd_matmul_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, W.data_ptr(), ldw, N, out.data_ptr(), N + 4, st) == 0
+        ref = dense.double() @ W[:, :N].double()
+        assert _rel(out[:, :N], ref) <= 2e-6
+        assert (out[:, N:] == 7.0).all()
+        out_b = torch.empty(R, N + 4, device=dev)
+        assert lib.act_group_max_bwd_matmul_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, W.data_ptr(), ldw, N, out_b.data_ptr(), N + 4, st) == 0
+        assert torch.equal(out_b[:, :N], out[:, :N])
+    if R % 128 == 0 and C % 128 == 0 and group in (32, 64):               # the dense kernel with the scatter generated on load
+        epi = K.GemmEpilogue(); epi.alpha = 1.0
+        fx = CP.GemmFx(); fx.sa_src = dout.data_ptr(); fx.sa_arg = arg.data_ptr(); fx.group = group
+        d_on = torch.empty(R, N, device=dev)
+        Wc = wide[:, :N].contiguous()
+        assert CP.lib.act_sgemm_fx_f32(1, 0, R, N, C, None, C, Wc.data_ptr(), N, d_on.data_ptr(), N, ctypes.byref(epi), ctypes.byref(fx), None, 0, st) == 0
+        assert _rel(out[:, :N], d_on) <= 1e-6
+    # ---- dW = dh^T . act(X)
+    X = torch.randn(R, N, generator=g).to(dev)
+    sc = (torch.rand(N, generator=g) + 0.5).to(dev); sh = (torch.randn(N, generator=g) * 0.2).to(dev)
+    need = lib.act_group_max_bwd_wgrad_workspace(G, group, C, N)
+    ws = torch.empty(max(need, 16) // 4, device=dev)
+    for scale, shift, act in ((sc, sh, torch.relu(X * sc + sh)), (None, None, X)):
+        ref = dense.double().t() @ act.double()
+        p = lambda t: t.data_ptr() if t is not None else None
+        dw = torch.full((C, N + 8), 7.0, device=dev)
+        assert lib.act_group_max_bwd_wgrad_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, X.data_ptr(), N, N, p(scale), p(shift), dw.data_ptr(), N + 8,
+                                               ws.data_ptr(), ws.numel() * 4, st) == 0
+        assert _rel(dw[:, :N], ref) <= 2e-6
+        assert (dw[:, N:] == 7.0).all()
+        dw_b = torch.empty(C, N + 8, device=dev)
+        assert lib.act_group_max_bwd_wgrad_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, X.data_ptr(), N, N, p(scale), p(shift), dw_b.data_ptr(), N + 8,
+                                               ws.data_ptr(), ws.numel() * 4, st) == 0
+        assert torch.equal(dw_b[:, :N], dw[:, :N])
+        for cap in (0, 2 * C * N * 4):                                   # no workspace: one split straight into dw; room for two splits
+            dw_c = torch.empty(C, N, device=dev)
+            assert lib.act_group_max_bwd_wgrad_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, X.data_ptr(), N, N, p(scale), p(shift), dw_c.data_ptr(), N,
+                                                   ws.data_ptr() if cap else None, cap, st) == 0
+            assert _rel(dw_c, ref) <= 2e-6
+    # ---- entries whose arg is outside [0, n) contribute nothing (as in the dense kernels: no row matches)
+    arg_bad = arg.clone(); arg_bad[2, ::3] = group; arg_bad[3, 1::5] = -1
+    keep = ((arg_bad >= 0) & (arg_bad < group))
+    dense_b = torch.zeros(G, group, C, device=dev).scatter_(1, arg_bad.clamp(0, group - 1).long().unsqueeze(1), (dout * keep).unsqueeze(1)).reshape(R, C)
+    Wc = wide[:, :N].contiguous()
+    out = torch.empty(R, N, device=dev)
+    assert lib.act_group_max_bwd_matmul_f32(dout.data_ptr(), arg_bad.data_ptr(), G, group, C, Wc.data_ptr(), N, N, out.data_ptr(), N, st) == 0
+    assert _rel(out, dense_b.double() @ Wc.double()) <= 2e-6
+    dw = torch.empty(C, N, device=dev)
+    assert lib.act_group_max_bwd_wgrad_f32(dout.data_ptr(), arg_bad.data_ptr(), G, group, C, X.data_ptr(), N, N, None, None, dw.data_ptr(), N,
+                                           ws.data_ptr(), ws.numel() * 4, st) == 0
+    assert _rel(dw, dense_b.double().t() @ X.double()) <= 2e-6
+    # ---- argument checks
+    assert lib.act_group_max_bwd_matmul_f32(dout.data_ptr(), arg.data_ptr(), G, 48, C, Wc.data_ptr(), N, N, out.data_ptr(), N, st) != 0      # 256 % n
+    assert lib.act_group_max_bwd_matmul_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, Wc.data_ptr(), N, 384, out.data_ptr(), N, st) != 0  # N
+    assert lib.act_group_max_bwd_matmul_f32(None, arg.data_ptr(), G, group, C, Wc.data_ptr(), N, N, out.data_ptr(), N, st) != 0
+    assert lib.act_group_max_bwd_wgrad_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, X.data_ptr(), N, N, sc.data_ptr(), None, dw.data_ptr(), N,
+                                           ws.data_ptr(), ws.numel() * 4, st) != 0                                                         # scale without shift
+    assert lib.act_group_max_bwd_wgrad_f32(dout.data_ptr(), arg.data_ptr(), G, group, C - 64, X.data_ptr(), N, N, None, None, dw.data_ptr(), N,
+                                           ws.data_ptr(), ws.numel() * 4, st) != 0                                                         # C % 128
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("tile,base", [(17, 10), (18, 11)])
 def test_gemm_nt_pipelined_loop_is_bit_identical(K, tile, base):
     """tiles 17 / 18: the NT b128 kernels with the software-pipelined main loop (fragments of K-tile t+1 read during the MFMAs of tile t, LDS-only
