@@ -7,7 +7,7 @@
 // entries instead; both are bound by the bytes of the DENSE operand (da written once, the activated conv input read once), not by flops.
 //
 //   da[g*n + j][:] = sum over {c : arg[g][c] == j} of dout[g][c] * W[c][:]                       (pool_bwd_dx_kernel)
-//   dW[c][:]       = sum over g of dout[g][c] * act(X[g*n + arg[g][c]][:])                       (pool_bwd_dw_kernel)
+//   dW[c][:]       = sum over g of dout[g][c] * act(X[g*n + arg[g][c]][:])                       (pool_bwd_dw2_kernel)
 //
 // Summation order is fixed by the shapes alone (ascending c inside a row; ascending g inside a split, splits folded in order), so the results
 // are run-to-run and process-to-process identical; they differ from the dense path's MFMA summation order in the last bits.
@@ -91,98 +91,188 @@ __global__ __launch_bounds__(256) void pool_bwd_dx_kernel(const float* __restric
     for (; r < n; ++r) { *reinterpret_cast<V*>(orow + (size_t)r * ldo) = acc; vzero(acc); }
 }
 
+// The same walk with 16-byte loads: a row of N floats takes N / 4 threads, so the workgroup splits into P = 1024 / N parts that take the rows
+// r = p (mod P) -- buckets are laid out part-major so every part walks one contiguous run of the sorted entries.  (Half the load instructions of
+// the float2 form at N = 512: 469 -> 334 us at the Stage-II geometry, 1643 -> 1146 us at C5.)
+template <int P>
+__global__ __launch_bounds__(256) void pool_bwd_dx4_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, const float* __restrict__ W,
+                                                           int ldw, int n, int C, float* __restrict__ out, int ldo) {
+    extern __shared__ unsigned char smem[];
+    int* s_arg = reinterpret_cast<int*>(smem);                                   // [C]
+    float* s_d = reinterpret_cast<float*>(s_arg + C);                            // [C]
+    int* s_start = reinterpret_cast<int*>(s_d + C);                              // [n + 1]  (bucket order)
+    int* s_wsum = s_start + n + 1;                                               // [4]
+    unsigned short* s_ord = reinterpret_cast<unsigned short*>(s_wsum + 4);       // [C]
+    const int tid = threadIdx.x, g = blockIdx.x;
+    for (int c = tid; c < C; c += 256) { s_arg[c] = arg[(size_t)g * C + c]; s_d[c] = dout[(size_t)g * C + c]; }
+    __syncthreads();
+    const int npp = n / P;                                                       // rows (buckets) per part
+    const int S = 256 / n, b_ = tid / S, sg = tid - b_ * S, L = (C + S - 1) / S, c_lo = sg * L, c_hi = min(C, c_lo + L);
+    const int r_ = (b_ % npp) * P + b_ / npp;                                    // bucket b holds row (b % npp) * P + b / npp
+    int cnt = 0;
+    for (int c = c_lo; c < c_hi; ++c) cnt += (s_arg[c] == r_);
+    int incl = cnt;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += s_wsum[w];
+    int p = base + incl - cnt;
+    if (sg == 0) s_start[b_] = p;
+    if (tid == 255) s_start[n] = base + incl;
+    for (int c = c_lo; c < c_hi; ++c) if (s_arg[c] == r_) s_ord[p++] = (unsigned short)c;
+    __syncthreads();
+
+    constexpr int TP = 256 / P;
+    const int part = tid / TP, q = tid - part * TP;                              // (wave-uniform: TP >= 64)
+    const int b_end = (part + 1) * npp;
+    int b = part * npp;
+    const int j_end = s_start[b_end];
+    const float* __restrict__ Wc = W + (size_t)q * 4;
+    float* __restrict__ obase = out + (size_t)g * n * ldo + (size_t)q * 4;
+    constexpr int U = 8;
+    int nb = s_start[b + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto flush = [&]() {
+        *reinterpret_cast<float4*>(obase + (size_t)((b - part * npp) * P + part) * ldo) = acc;
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        ++b;
+    };
+    for (int j0 = s_start[b]; j0 < j_end; j0 += U) {
+        float4 w[U]; float dv[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int c = s_ord[min(j0 + k, j_end - 1)];
+            dv[k] = s_d[c];
+            w[k] = *reinterpret_cast<const float4*>(Wc + (size_t)c * ldw);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int j = j0 + k;
+            if (j < j_end) {                                                     // (wave-uniform)
+                while (j == nb) { flush(); nb = s_start[b + 1]; }
+                vfma(acc, dv[k], w[k]);
+            }
+        }
+    }
+    while (b < b_end) flush();
+}
+
 // ------------------------------------------------------------------------------------------------------------------- dW = dh^T . act(X)
-// Workgroup = (64-column slice, tile of 4 * CPW channels, range of groups).  Per group the [n x 64] slice of X goes through LDS (BatchNorm
-// affine + ReLU applied on the way) together with the tile's (arg, dout) pairs -- arg already as the byte offset of its slice row, entries
-// outside [0, n) zeroed -- double-buffered, the next group's data in flight in registers.  Wave w owns CPW consecutive channels and every
-// lane one column: per (group, channel) one broadcast LDS read of the pair (4 channels per ds_read_b128), one LDS read of the arg row, one FMA.
-template <int CPW, bool AFF>
-__global__ __launch_bounds__(256, (CPW > 64 ? 2 : 3)) void pool_bwd_dw_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg,
-                                                                              const float* __restrict__ X, int ldx, const float* __restrict__ scale,
-                                                                              const float* __restrict__ shift, int n, int C, int G, int gps,
-                                                                              float* __restrict__ part, int ldp, size_t split_stride) {
-    constexpr int CT = 4 * CPW, NP = (CT + 255) / 256;
+// Channel-per-lane form of the same product: workgroup = (64 * NW channels, 64 columns, range of groups), one wave per 64 channels with 64
+// accumulators per lane.  Each lane loads ITS (arg, dout) pairs with plain coalesced loads, turns arg into the offset of its slice row, and
+// reads that row two columns at a time with immediate offsets: per (group, channel, 2 columns) one ds_read_b64 and two FMAs -- no broadcast
+// reads, no per-column address arithmetic.  The slice rows are 66 dwords apart, so the 32 rows of a group sit on 32 different bank pairs and
+// lanes with different arg rows never conflict (n = 64: two rows per pair).  NW = C / 64 up to 6, so the slice of X is read once (C <= 384)
+// or C / 384 times.  One step = GB consecutive groups (GB * n contiguous rows of X): the next step's rows are in flight in registers while
+// this step's GB groups are consumed from LDS, one barrier per step -- a memory round trip (~3 us under load) is amortised over GB groups
+// instead of paid per group.  The accumulators leave through an LDS transpose: the partial tile is written in 128-byte runs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NW, int GB, bool AFF>
+__global__ __launch_bounds__(64 * NW, 2) void pool_bwd_dw2_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, const float* __restrict__ X,
+                                                                  int ldx, const float* __restrict__ scale, const float* __restrict__ shift, int n, int C,
+                                                                  int G, int gps, float* __restrict__ part, int ldp, size_t split_stride, int nslices,
+                                                                  int xcd_map) {
+    constexpr int NT = 64 * NW, KC = 64, STRIDE = KC + 2;
+    constexpr int MAXF = (GB * 64 * 16 / (GB == 4 ? 2 : 1) + NT - 1) / NT;      // GB = 4: n <= 32;  GB = 2: n <= 64
     extern __shared__ float4 smem4[];
-    unsigned char* smem = reinterpret_cast<unsigned char*>(smem4);
-    const int slice_bytes = n * 256, buf_bytes = slice_bytes + CT * 8;           // [n][64] floats | CT row offsets | CT dout
-    const int tid = threadIdx.x, cl = tid & 63, wv = tid >> 6;
-    const int n0 = blockIdx.x * 64, ctile = blockIdx.y * CT;
-    const int g0 = blockIdx.z * gps, g1 = min(G, g0 + gps);
-    const int nf4 = n * 16;                                                      // float4s of one slice
-    constexpr int MAXF = 4;                                                      // n <= 64
-    const int c4 = tid & 15;
-    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (AFF) { sc4 = *reinterpret_cast<const float4*>(scale + n0 + c4 * 4); sh4 = *reinterpret_cast<const float4*>(shift + n0 + c4 * 4); }
-    float4 stg[MAXF]; int sa[NP]; float sdv[NP];
+    float* tile = reinterpret_cast<float*>(smem4);                               // [2][GB * n][STRIDE]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // blockIdx.x -> (column slice, split): workgroups are dealt round-robin to the 8 XCDs, so the slices of ONE group range are given ids that
+    // land on the same XCD next to each other in time
+    int bslice, bsplit;
+    if (xcd_map) { const int x = blockIdx.x & 7, t = blockIdx.x >> 3; bslice = t % nslices; bsplit = (t / nslices) * 8 + x; }
+    else         { bslice = blockIdx.x % nslices; bsplit = blockIdx.x / nslices; }
+    const int n0 = bslice * KC, ch = blockIdx.y * NT + tid;
+    const int g0 = bsplit * gps, g1 = min(G, g0 + gps);
+    const int rows = GB * n, nf4 = rows * 16, buf_floats = rows * STRIDE;
+    float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);       // column quad (tid & 15) of every float4 this thread stages
+    if (AFF) { sc4 = *reinterpret_cast<const float4*>(scale + n0 + (tid & 15) * 4); sh4 = *reinterpret_cast<const float4*>(shift + n0 + (tid & 15) * 4); }
+    const long long row_end = (long long)g1 * n - 1;                             // last row of this workgroup's range (loads past it are clamped)
+    float4 stg[MAXF]; int na[GB]; float nd[GB];
     auto fetch = [&](int g) {
 #pragma unroll
         for (int i = 0; i < MAXF; ++i) {
-            const int f = tid + 256 * i;
-            if (f < nf4) stg[i] = *reinterpret_cast<const float4*>(X + ((size_t)g * n + (f >> 4)) * ldx + n0 + c4 * 4);
+            const int f = tid + NT * i;
+            const long long r = min((long long)g * n + (f >> 4), row_end);
+            if (f < nf4) stg[i] = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + n0 + (tid & 15) * 4);
         }
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int c = tid + 256 * i;
-            if (c < CT) { sa[i] = arg[(size_t)g * C + ctile + c]; sdv[i] = dout[(size_t)g * C + ctile + c]; }
+        for (int k = 0; k < GB; ++k) {
+            const int gg = min(g + k, g1 - 1);
+            na[k] = arg[(size_t)gg * C + ch]; nd[k] = dout[(size_t)gg * C + ch];
         }
     };
     auto put = [&](int buf) {
-        unsigned char* b = smem + buf * buf_bytes;
+        float* b = tile + (size_t)buf * buf_floats;
 #pragma unroll
         for (int i = 0; i < MAXF; ++i) {
-            const int f = tid + 256 * i;
+            const int f = tid + NT * i;
             if (f < nf4) {
                 float4 v = stg[i];
                 if (AFF) {
                     v.x = fmaxf(v.x * sc4.x + sh4.x, 0.f); v.y = fmaxf(v.y * sc4.y + sh4.y, 0.f);
                     v.z = fmaxf(v.z * sc4.z + sh4.z, 0.f); v.w = fmaxf(v.w * sc4.w + sh4.w, 0.f);
                 }
-                *reinterpret_cast<float4*>(b + f * 16) = v;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int c = tid + 256 * i;
-            if (c < CT) {
-                const bool ok = (unsigned)sa[i] < (unsigned)n;
-                *reinterpret_cast<int*>(b + slice_bytes + c * 4) = ok ? sa[i] * 256 : 0;
-                *reinterpret_cast<float*>(b + slice_bytes + CT * 4 + c * 4) = ok ? sdv[i] : 0.f;
+                float* q = b + (f >> 4) * STRIDE + (f & 15) * 4;                 // (8-byte aligned: STRIDE is even)
+                *reinterpret_cast<float2*>(q) = make_float2(v.x, v.y);
+                *reinterpret_cast<float2*>(q + 2) = make_float2(v.z, v.w);
             }
         }
     };
-    float acc[CPW];
+    float acc[64];
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
     if (g0 < g1) { fetch(g0); put(0); }
     __syncthreads();
     int buf = 0;
-    for (int g = g0; g < g1; ++g) {
-        if (g + 1 < g1) fetch(g + 1);
-        const unsigned char* b = smem + buf * buf_bytes;
-        const unsigned char* col = b + cl * 4;
-        const int4* ro = reinterpret_cast<const int4*>(b + slice_bytes + wv * CPW * 4);
-        const float4* dd = reinterpret_cast<const float4*>(b + slice_bytes + CT * 4 + wv * CPW * 4);
+    for (int g = g0; g < g1; g += GB) {
+        int row[GB]; float dv[GB];
 #pragma unroll
-        for (int i = 0; i < CPW; i += 4) {
-            const int4 r4 = ro[i / 4];                                           // (same address in every lane: broadcast)
-            const float4 d4 = dd[i / 4];
-            acc[i + 0] = fmaf(d4.x, *reinterpret_cast<const float*>(col + r4.x), acc[i + 0]);
-            acc[i + 1] = fmaf(d4.y, *reinterpret_cast<const float*>(col + r4.y), acc[i + 1]);
-            acc[i + 2] = fmaf(d4.z, *reinterpret_cast<const float*>(col + r4.z), acc[i + 2]);
-            acc[i + 3] = fmaf(d4.w, *reinterpret_cast<const float*>(col + r4.w), acc[i + 3]);
-            if ((i & 15) == 12) {                                                // 16 channels in flight at a time: pin the chunk's FMAs here
-                float* q = acc + i - 12;                                         // (the scheduler otherwise hoists all CPW reads and spills)
-                asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]), "+v"(q[9]),
-                             "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]) : : "memory");
+        for (int k = 0; k < GB; ++k) {                                           // this step's pairs -> slice-row offsets (groups past the end: weight 0)
+            const bool ok = (unsigned)na[k] < (unsigned)n && g + k < g1;
+            row[k] = (k * n + (ok ? na[k] : 0)) * STRIDE;
+            dv[k] = ok ? nd[k] : 0.f;
+        }
+        if (g + GB < g1) fetch(g + GB);
+        const float* bp = tile + (size_t)buf * buf_floats;
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const float* rp = bp + row[k];
+            const f32x2 dv2 = {dv[k], dv[k]};
+#pragma unroll
+            for (int c = 0; c < 64; c += 2) {
+                const f32x2 x = *reinterpret_cast<const f32x2*>(rp + c);
+                f32x2 a2 = {acc[c], acc[c + 1]};
+                a2 = __builtin_elementwise_fma(dv2, x, a2);                      // v_pk_fma_f32: two columns per VALU issue
+                acc[c] = a2.x; acc[c + 1] = a2.y;
+                if ((c & 15) == 14) {                                            // 16 columns in flight at a time (registers: the scheduler otherwise hoists all 32 reads)
+                    float* q = acc + c - 14;
+                    asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]),
+                                 "+v"(q[9]), "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15]) : : "memory");
+                }
             }
         }
-        if (g + 1 < g1) put(buf ^ 1);
+        if (g + GB < g1) put(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
-    float* __restrict__ o = part + (size_t)blockIdx.z * split_stride + (size_t)(ctile + wv * CPW) * ldp + n0 + cl;
+    // transpose through LDS (per wave: 64 channels x 32 columns at a time, rows 33 dwords apart) and store rows
+    float* tw = tile + wv * (64 * 33);
+    float* o = part + (size_t)bsplit * split_stride + (size_t)(blockIdx.y * NT + wv * 64) * ldp + n0;
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) o[(size_t)i * ldp] = acc[i];
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tw[lane * 33 + k] = acc[32 * h + k];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                      // lgkmcnt(0): the wave's own LDS writes have landed
+        for (int i = 0; i < 64; i += 2) {
+            const int r = i + (lane >> 5), c = lane & 31;
+            o[(size_t)r * ldp + 32 * h + c] = tw[r * 33 + c];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
 }
 
 __global__ __launch_bounds__(256) void pool_bwd_fold_kernel(const float* __restrict__ part, int splits, size_t split_stride, int C, int N4,
@@ -191,16 +281,25 @@ __global__ __launch_bounds__(256) void pool_bwd_fold_kernel(const float* __restr
     if (i >= (long long)C * N4) return;
     const int c = (int)(i / N4), q = (int)(i - (long long)c * N4);
     const float4* __restrict__ p = reinterpret_cast<const float4*>(part) + i;
+    const size_t st4 = split_stride / 4;
     float4 a = p[0];
-    for (int s = 1; s < splits; ++s) { const float4 v = p[(size_t)s * (split_stride / 4)]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    int s = 1;
+    for (; s + 8 <= splits; s += 8) {                                            // 8 loads in flight; the additions stay in split order
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(s + k) * st4];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }
+    }
+    for (; s < splits; ++s) { const float4 v = p[(size_t)s * st4]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
     *reinterpret_cast<float4*>(out + (size_t)c * ldo + q * 4) = a;
 }
 
 bool pool_geom_ok(int n, int C) { return n > 0 && n <= 64 && 256 % n == 0 && C > 0 && C < 65536; }
-int dw_cpw(int C) { return C % 384 == 0 ? 96 : C % 256 == 0 ? 64 : C % 128 == 0 ? 32 : 0; }
+int dw_waves(int C) { return C % 384 == 0 ? 6 : C % 256 == 0 ? 4 : C % 128 == 0 ? 2 : 0; }        // 64 channels per wave
 int dw_splits(int G, int C, int N, size_t workspace_bytes) {
-    const int tiles = (N / 64) * (C / (4 * dw_cpw(C)));
-    int s = (1024 + tiles - 1) / tiles;                                          // ~4 workgroups per CU
+    const int tiles = (N / 64) * (C / (64 * dw_waves(C)));
+    int s = (512 + tiles - 1) / tiles;                                           // two workgroups per CU (measured: 512 / 1024 / 2048 -> 271 / 290 / 326 us)
     s = min(s, max(1, G / 8));                                                   // at least 8 groups per workgroup
     const size_t cap = workspace_bytes / ((size_t)C * N * sizeof(float));
     if ((size_t)s > cap) s = (int)cap;
@@ -218,14 +317,18 @@ extern "C" int act_group_max_bwd_matmul_f32(const float* dout, const int32_t* ar
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * (double)C * N, 4.0 * G * ((double)n * N + 2.0 * C));
     const size_t lds = (size_t)C * 8 + (size_t)(n + 1 + 4) * 4 + (size_t)C * 2;
-    if (N == 256)      hipLaunchKernelGGL(pool_bwd_dx_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
-    else if (N == 512) hipLaunchKernelGGL(pool_bwd_dx_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
-    else               hipLaunchKernelGGL(pool_bwd_dx_kernel<4>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
+    const int parts = 1024 / N;
+    if (n % parts == 0) {
+        if (N == 256)      hipLaunchKernelGGL(pool_bwd_dx4_kernel<4>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
+        else if (N == 512) hipLaunchKernelGGL(pool_bwd_dx4_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
+        else               hipLaunchKernelGGL(pool_bwd_dx4_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
+    } else if (N == 256)   hipLaunchKernelGGL(pool_bwd_dx_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);   // (n = 1, 2)
+    else                   hipLaunchKernelGGL(pool_bwd_dx_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
     ACT_LAUNCH_CHECK(); return 0;
 }
 
 extern "C" size_t act_group_max_bwd_wgrad_workspace(int G, int n, int C, int N) {
-    if (G <= 0 || !pool_geom_ok(n, C) || dw_cpw(C) == 0 || N <= 0 || (N & 63)) return 0;
+    if (G <= 0 || !pool_geom_ok(n, C) || dw_waves(C) == 0 || N <= 0 || (N & 63)) return 0;
     const int s = dw_splits(G, C, N, (size_t)-1);
     return s > 1 ? (size_t)s * C * N * sizeof(float) : 0;
 }
@@ -234,8 +337,8 @@ extern "C" int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg
                                            const float* shift, float* dw, int lddw, float* workspace, size_t workspace_bytes, act_stream_t stream) {
     if (!dout || !arg || !x || !dw) return ACT_E_NULLPTR;
     if ((scale == nullptr) != (shift == nullptr)) return ACT_E_NULLPTR;
-    const int cpw = pool_geom_ok(n, C) ? dw_cpw(C) : 0;
-    if (G <= 0 || cpw == 0 || N <= 0 || (N & 63) || ldx < N || lddw < N || (ldx & 3) || (lddw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)dw & 15) ||
+    const int nw = pool_geom_ok(n, C) ? dw_waves(C) : 0;
+    if (G <= 0 || nw == 0 || N <= 0 || (N & 63) || ldx < N || lddw < N || (ldx & 3) || (lddw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)dw & 15) ||
         (scale && (((uintptr_t)scale | (uintptr_t)shift) & 15)))
         return ACT_E_BADARG;
     int splits = dw_splits(G, C, N, workspace ? workspace_bytes : 0);
@@ -244,21 +347,24 @@ extern "C" int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg
     const int gps = (G + splits - 1) / splits;
     splits = (G + gps - 1) / gps;
     hipStream_t s = (hipStream_t)stream;
-    ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * (double)C * N, 4.0 * ((double)G * n * N * (C / (4 * cpw)) + 2.0 * G * C * (N / 64) + (double)C * N));
+    ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * (double)C * N, 4.0 * ((double)G * n * N * (C / (64 * nw)) + 2.0 * G * C * (N / 64) + (double)C * N));
     float* part = splits > 1 ? workspace : dw;
     const int ldp = splits > 1 ? N : lddw;
     const size_t stride = (size_t)C * N;
-    const dim3 grid(N / 64, C / (4 * cpw), splits);
-    const size_t lds = (size_t)2 * ((size_t)n * 256 + (size_t)4 * cpw * 8);
-#define LAUNCH_DW(CPW_)                                                                                                                          \
-    do {                                                                                                                                         \
-        if (scale) hipLaunchKernelGGL((pool_bwd_dw_kernel<CPW_, true>), grid, dim3(256), lds, s, dout, arg, x, ldx, scale, shift, n, C, G, gps,    \
-                                      part, ldp, stride);                                                                                        \
-        else       hipLaunchKernelGGL((pool_bwd_dw_kernel<CPW_, false>), grid, dim3(256), lds, s, dout, arg, x, ldx, scale, shift, n, C, G, gps,   \
-                                      part, ldp, stride);                                                                                        \
+    const int gb = n <= 32 ? 4 : 2;
+    const size_t lds = max((size_t)2 * gb * n * 66 * sizeof(float), (size_t)nw * 64 * 33 * sizeof(float));
+    const int nslices = N / 64, xcd_map = splits % 8 == 0 ? 1 : 0;
+    const dim3 grid(nslices * splits, C / (64 * nw), 1);
+#define LAUNCH_DW2(NW_, GB_)                                                                                                                      \
+    do {                                                                                                                                          \
+        if (scale) hipLaunchKernelGGL((pool_bwd_dw2_kernel<NW_, GB_, true>), grid, dim3(64 * NW_), lds, s, dout, arg, x, ldx, scale, shift, n, C,  \
+                                      G, gps, part, ldp, stride, nslices, xcd_map);                                                               \
+        else       hipLaunchKernelGGL((pool_bwd_dw2_kernel<NW_, GB_, false>), grid, dim3(64 * NW_), lds, s, dout, arg, x, ldx, scale, shift, n, C, \
+                                      G, gps, part, ldp, stride, nslices, xcd_map);                                                               \
     } while (0)
-    if (cpw == 96) LAUNCH_DW(96); else if (cpw == 64) LAUNCH_DW(64); else LAUNCH_DW(32);
-#undef LAUNCH_DW
+    if (gb == 4) { if (nw == 6) LAUNCH_DW2(6, 4); else if (nw == 4) LAUNCH_DW2(4, 4); else LAUNCH_DW2(2, 4); }
+    else         { if (nw == 6) LAUNCH_DW2(6, 2); else if (nw == 4) LAUNCH_DW2(4, 2); else LAUNCH_DW2(2, 2); }
+#undef LAUNCH_DW2
     ACT_LAUNCH_CHECK();
     if (splits > 1) {
         const long long total = (long long)C * (N / 4);
