@@ -34,7 +34,7 @@ __device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.f, 0.f, 0.f
 
 template <int VEC>
 __global__ __launch_bounds__(256) void pool_bwd_dx_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, const float* __restrict__ W,
-                                                          int ldw, int n, int C, float* __restrict__ out, int ldo) {
+                                                          int ldw, int n, int C, float* __restrict__ out, int ldo, int skip_zero) {
     using V = typename VecT<VEC>::T;
     extern __shared__ unsigned char smem[];
     int* s_arg = reinterpret_cast<int*>(smem);                                   // [C]
@@ -43,8 +43,14 @@ __global__ __launch_bounds__(256) void pool_bwd_dx_kernel(const float* __restric
     int* s_wsum = s_start + n + 1;                                               // [4]
     unsigned short* s_ord = reinterpret_cast<unsigned short*>(s_wsum + 4);       // [C]
     const int tid = threadIdx.x, g = blockIdx.x;
-    for (int c = tid; c < C; c += 256) { s_arg[c] = arg[(size_t)g * C + c]; s_d[c] = dout[(size_t)g * C + c]; }
-    __syncthreads();
+    int live = 0;
+    for (int c = tid; c < C; c += 256) { const float d = dout[(size_t)g * C + c]; s_arg[c] = arg[(size_t)g * C + c]; s_d[c] = d; live |= (d != 0.f); }
+    const int any_live = __syncthreads_or(live);                                 // (also the barrier between the LDS fill and the bucket passes)
+    if (skip_zero && !any_live) {                                               // a group whose gradient is all zero (a masked patch): n zero rows
+        V z; vzero(z);
+        for (int r = 0; r < n; ++r) *reinterpret_cast<V*>(out + ((size_t)g * n + r) * ldo + (size_t)tid * VEC) = z;
+        return;
+    }
     // thread (r, sg): row r, channel segment sg of S = 256 / n
     const int S = 256 / n, r_ = tid / S, sg = tid - r_ * S, L = (C + S - 1) / S, c_lo = sg * L, c_hi = min(C, c_lo + L);
     int cnt = 0;
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256) void pool_bwd_dx_kernel(const float* __restric
 // the float2 form at N = 512: 469 -> 334 us at the Stage-II geometry, 1643 -> 1146 us at C5.)
 template <int P>
 __global__ __launch_bounds__(256) void pool_bwd_dx4_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, const float* __restrict__ W,
-                                                           int ldw, int n, int C, float* __restrict__ out, int ldo) {
+                                                           int ldw, int n, int C, float* __restrict__ out, int ldo, int skip_zero) {
     extern __shared__ unsigned char smem[];
     int* s_arg = reinterpret_cast<int*>(smem);                                   // [C]
     float* s_d = reinterpret_cast<float*>(s_arg + C);                            // [C]
@@ -104,8 +110,15 @@ __global__ __launch_bounds__(256) void pool_bwd_dx4_kernel(const float* __restri
     int* s_wsum = s_start + n + 1;                                               // [4]
     unsigned short* s_ord = reinterpret_cast<unsigned short*>(s_wsum + 4);       // [C]
     const int tid = threadIdx.x, g = blockIdx.x;
-    for (int c = tid; c < C; c += 256) { s_arg[c] = arg[(size_t)g * C + c]; s_d[c] = dout[(size_t)g * C + c]; }
-    __syncthreads();
+    int live = 0;
+    for (int c = tid; c < C; c += 256) { const float d = dout[(size_t)g * C + c]; s_arg[c] = arg[(size_t)g * C + c]; s_d[c] = d; live |= (d != 0.f); }
+    const int any_live = __syncthreads_or(live);                                 // (also the barrier between the LDS fill and the bucket passes)
+    if (skip_zero && !any_live) {                                               // a group whose gradient is all zero (a masked patch): n zero rows
+        constexpr int TPZ = 256 / P;
+        const int part = tid / TPZ, q = tid - part * TPZ;
+        for (int r = part; r < n; r += P) *reinterpret_cast<float4*>(out + ((size_t)g * n + r) * ldo + (size_t)q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const int npp = n / P;                                                       // rows (buckets) per part
     const int S = 256 / n, b_ = tid / S, sg = tid - b_ * S, L = (C + S - 1) / S, c_lo = sg * L, c_hi = min(C, c_lo + L);
     const int r_ = (b_ % npp) * P + b_ / npp;                                    // bucket b holds row (b % npp) * P + b / npp
@@ -174,7 +187,7 @@ template <int NW, int GB, bool AFF>
 __global__ __launch_bounds__(64 * NW, 2) void pool_bwd_dw2_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, const float* __restrict__ X,
                                                                   int ldx, const float* __restrict__ scale, const float* __restrict__ shift, int n, int C,
                                                                   int G, int gps, float* __restrict__ part, int ldp, size_t split_stride, int nslices,
-                                                                  int xcd_map) {
+                                                                  int xcd_map, const int* __restrict__ live, const int* __restrict__ nlive, int splits) {
     constexpr int NT = 64 * NW, KC = 64, STRIDE = KC + 2;
     constexpr int MAXF = (GB * 64 * 16 / (GB == 4 ? 2 : 1) + NT - 1) / NT;      // GB = 4: n <= 32;  GB = 2: n <= 64
     extern __shared__ float4 smem4[];
@@ -186,24 +199,32 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_bwd_dw2_kernel(const float* _
     if (xcd_map) { const int x = blockIdx.x & 7, t = blockIdx.x >> 3; bslice = t % nslices; bsplit = (t / nslices) * 8 + x; }
     else         { bslice = blockIdx.x % nslices; bsplit = blockIdx.x / nslices; }
     const int n0 = bslice * KC, ch = blockIdx.y * NT + tid;
-    const int g0 = bsplit * gps, g1 = min(G, g0 + gps);
+    // positions [g0, g1) of the list of live groups (groups with a non-zero gradient row, ascending; pool_bwd_compact_kernel) -- or of 0 .. G - 1
+    const int total = live ? *nlive : G;
+    if (live) gps = (total + splits - 1) / splits;
+    const int g0 = min(total, bsplit * gps), g1 = min(total, g0 + gps);
+    const int nshift = __ffs(n) - 1;                                             // n is a power of two (256 % n == 0)
     const int rows = GB * n, nf4 = rows * 16, buf_floats = rows * STRIDE;
     float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);       // column quad (tid & 15) of every float4 this thread stages
     if (AFF) { sc4 = *reinterpret_cast<const float4*>(scale + n0 + (tid & 15) * 4); sh4 = *reinterpret_cast<const float4*>(shift + n0 + (tid & 15) * 4); }
-    const long long row_end = (long long)g1 * n - 1;                             // last row of this workgroup's range (loads past it are clamped)
     float4 stg[MAXF]; int na[GB]; float nd[GB];
-    auto fetch = [&](int g) {
+    auto fetch = [&](int g) {                                                    // the step at list positions g .. g + GB - 1 (clamped to the range)
+        int gid[GB];
+#pragma unroll
+        for (int k = 0; k < GB; ++k) { const int pos = min(g + k, g1 - 1); gid[k] = live ? live[pos] : pos; }
 #pragma unroll
         for (int i = 0; i < MAXF; ++i) {
             const int f = tid + NT * i;
-            const long long r = min((long long)g * n + (f >> 4), row_end);
-            if (f < nf4) stg[i] = *reinterpret_cast<const float4*>(X + (size_t)r * ldx + n0 + (tid & 15) * 4);
+            if (f < nf4) {
+                const int rr = f >> 4, k = rr >> nshift;
+                int gk = gid[0];
+#pragma unroll
+                for (int j = 1; j < GB; ++j) gk = (k == j) ? gid[j] : gk;
+                stg[i] = *reinterpret_cast<const float4*>(X + ((size_t)gk * n + (rr & (n - 1))) * ldx + n0 + (tid & 15) * 4);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < GB; ++k) {
-            const int gg = min(g + k, g1 - 1);
-            na[k] = arg[(size_t)gg * C + ch]; nd[k] = dout[(size_t)gg * C + ch];
-        }
+        for (int k = 0; k < GB; ++k) { na[k] = arg[(size_t)gid[k] * C + ch]; nd[k] = dout[(size_t)gid[k] * C + ch]; }
     };
     auto put = [&](int buf) {
         float* b = tile + (size_t)buf * buf_floats;
@@ -275,6 +296,34 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_bwd_dw2_kernel(const float* _
     }
 }
 
+// Live groups: in Stage II the encoder runs on all B * G patches but only the visible 20 % feed the loss (models/act.py:269-275 selects
+// x_vis after the encoder), so 80 % of the rows of dout are exactly zero.  flags -> ascending list + count, all on the device.
+__global__ __launch_bounds__(256) void pool_bwd_flags_kernel(const float* __restrict__ dout, int G, int C, int* __restrict__ flags) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= G) return;
+    int nz = 0;
+    for (int c = lane; c < C; c += 64) nz |= (dout[(size_t)g * C + c] != 0.f);
+    const unsigned long long b = __ballot(nz);
+    if (lane == 0) flags[g] = b != 0ull;
+}
+__global__ __launch_bounds__(1024) void pool_bwd_compact_kernel(const int* __restrict__ flags, int G, int* __restrict__ live, int* __restrict__ nlive) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, per = (G + 1023) / 1024, lo = min(G, tid * per), hi = min(G, lo + per);
+    int cnt = 0;
+    for (int g = lo; g < hi; ++g) cnt += flags[g];
+    int incl = cnt;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    int p = base + incl - cnt;
+    for (int g = lo; g < hi; ++g) if (flags[g]) live[p++] = g;
+    if (tid == 1023) *nlive = base + incl;
+}
+
 __global__ __launch_bounds__(256) void pool_bwd_fold_kernel(const float* __restrict__ part, int splits, size_t split_stride, int C, int N4,
                                                             float* __restrict__ out, int ldo) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,6 +344,11 @@ __global__ __launch_bounds__(256) void pool_bwd_fold_kernel(const float* __restr
     *reinterpret_cast<float4*>(out + (size_t)c * ldo + q * 4) = a;
 }
 
+// ACT_POOL_BWD_LIVE=0: walk every group, also those whose gradient row is all zero (A/B switch; results are identical)
+bool pool_live_on() {
+    static const bool on = [] { const char* e = getenv("ACT_POOL_BWD_LIVE"); return !(e && e[0] == '0'); }();
+    return on;
+}
 bool pool_geom_ok(int n, int C) { return n > 0 && n <= 64 && 256 % n == 0 && C > 0 && C < 65536; }
 int dw_waves(int C) { return C % 384 == 0 ? 6 : C % 256 == 0 ? 4 : C % 128 == 0 ? 2 : 0; }        // 64 channels per wave
 int dw_splits(int G, int C, int N, size_t workspace_bytes) {
@@ -317,20 +371,22 @@ extern "C" int act_group_max_bwd_matmul_f32(const float* dout, const int32_t* ar
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * (double)C * N, 4.0 * G * ((double)n * N + 2.0 * C));
     const size_t lds = (size_t)C * 8 + (size_t)(n + 1 + 4) * 4 + (size_t)C * 2;
-    const int parts = 1024 / N;
+    const int parts = 1024 / N, skip = pool_live_on() ? 1 : 0;
     if (n % parts == 0) {
-        if (N == 256)      hipLaunchKernelGGL(pool_bwd_dx4_kernel<4>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
-        else if (N == 512) hipLaunchKernelGGL(pool_bwd_dx4_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
-        else               hipLaunchKernelGGL(pool_bwd_dx4_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
-    } else if (N == 256)   hipLaunchKernelGGL(pool_bwd_dx_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);   // (n = 1, 2)
-    else                   hipLaunchKernelGGL(pool_bwd_dx_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx);
+        if (N == 256)      hipLaunchKernelGGL(pool_bwd_dx4_kernel<4>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);
+        else if (N == 512) hipLaunchKernelGGL(pool_bwd_dx4_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);
+        else               hipLaunchKernelGGL(pool_bwd_dx4_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);
+    } else if (N == 256)   hipLaunchKernelGGL(pool_bwd_dx_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);   // (n = 1, 2)
+    else                   hipLaunchKernelGGL(pool_bwd_dx_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);
     ACT_LAUNCH_CHECK(); return 0;
 }
+
+static size_t live_list_bytes(int G) { return (((size_t)2 * G + 4) * sizeof(int) + 15) & ~(size_t)15; }   // flags | live | count
 
 extern "C" size_t act_group_max_bwd_wgrad_workspace(int G, int n, int C, int N) {
     if (G <= 0 || !pool_geom_ok(n, C) || dw_waves(C) == 0 || N <= 0 || (N & 63)) return 0;
     const int s = dw_splits(G, C, N, (size_t)-1);
-    return s > 1 ? (size_t)s * C * N * sizeof(float) : 0;
+    return live_list_bytes(G) + (s > 1 ? (size_t)s * C * N * sizeof(float) : 0);
 }
 
 extern "C" int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg, int G, int n, int C, const float* x, int ldx, int N, const float* scale,
@@ -341,12 +397,25 @@ extern "C" int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg
     if (G <= 0 || nw == 0 || N <= 0 || (N & 63) || ldx < N || lddw < N || (ldx & 3) || (lddw & 3) || ((uintptr_t)x & 15) || ((uintptr_t)dw & 15) ||
         (scale && (((uintptr_t)scale | (uintptr_t)shift) & 15)))
         return ACT_E_BADARG;
+    if (workspace && (((uintptr_t)workspace) & 15)) return ACT_E_BADARG;
+    // workspace: [flags | list of live groups | count] then the split partials; too small for the list -> every group is walked
+    int *flags = nullptr, *live = nullptr, *nlive = nullptr;
+    if (pool_live_on() && workspace && workspace_bytes >= live_list_bytes(G)) {
+        flags = reinterpret_cast<int*>(workspace); live = flags + G; nlive = live + G;
+        workspace = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + live_list_bytes(G));
+        workspace_bytes -= live_list_bytes(G);
+    } else {
+        workspace_bytes = workspace ? workspace_bytes : 0;
+    }
     int splits = dw_splits(G, C, N, workspace ? workspace_bytes : 0);
     if (splits < 1) splits = 1;
-    if (splits > 1 && (((uintptr_t)workspace) & 15)) return ACT_E_BADARG;
     const int gps = (G + splits - 1) / splits;
     splits = (G + gps - 1) / gps;
     hipStream_t s = (hipStream_t)stream;
+    if (live) {
+        hipLaunchKernelGGL(pool_bwd_flags_kernel, dim3((G + 3) / 4), dim3(256), 0, s, dout, G, C, flags);
+        hipLaunchKernelGGL(pool_bwd_compact_kernel, dim3(1), dim3(1024), 0, s, flags, G, live, nlive);
+    }
     ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * (double)C * N, 4.0 * ((double)G * n * N * (C / (64 * nw)) + 2.0 * G * C * (N / 64) + (double)C * N));
     float* part = splits > 1 ? workspace : dw;
     const int ldp = splits > 1 ? N : lddw;
@@ -358,9 +427,9 @@ extern "C" int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg
 #define LAUNCH_DW2(NW_, GB_)                                                                                                                      \
     do {                                                                                                                                          \
         if (scale) hipLaunchKernelGGL((pool_bwd_dw2_kernel<NW_, GB_, true>), grid, dim3(64 * NW_), lds, s, dout, arg, x, ldx, scale, shift, n, C,  \
-                                      G, gps, part, ldp, stride, nslices, xcd_map);                                                               \
+                                      G, gps, part, ldp, stride, nslices, xcd_map, live, nlive, splits);                                                               \
         else       hipLaunchKernelGGL((pool_bwd_dw2_kernel<NW_, GB_, false>), grid, dim3(64 * NW_), lds, s, dout, arg, x, ldx, scale, shift, n, C, \
-                                      G, gps, part, ldp, stride, nslices, xcd_map);                                                               \
+                                      G, gps, part, ldp, stride, nslices, xcd_map, live, nlive, splits);                                                               \
     } while (0)
     if (gb == 4) { if (nw == 6) LAUNCH_DW2(6, 4); else if (nw == 4) LAUNCH_DW2(4, 4); else LAUNCH_DW2(2, 4); }
     else         { if (nw == 6) LAUNCH_DW2(6, 2); else if (nw == 4) LAUNCH_DW2(4, 2); else LAUNCH_DW2(2, 2); }

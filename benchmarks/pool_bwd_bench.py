@@ -22,6 +22,9 @@ for name, G, n, C in (("stage2", 8192, 32, 384), ("c5", 16384, 64, 768)):
         arg = ((torch.arange(C, dtype=torch.int32) // k) % n).repeat(G, 1).to(dev)
     elif pat == "same":
         arg = torch.zeros(G, C, dtype=torch.int32, device=dev)
+    keep = float(os.environ.get("POOL_BENCH_LIVE", "1.0"))               # fraction of groups with a non-zero gradient (Stage II: 13 / 64 visible)
+    if keep < 1.0:
+        dout[torch.rand(G, generator=g).to(dev) >= keep] = 0
     W = (torch.randn(C, N, generator=g) * 0.1).to(dev)
     X = torch.randn(G * n, N, device=dev)
     sc = torch.rand(N, device=dev) + 0.5; sh = torch.randn(N, device=dev) * 0.2

@@ -716,13 +716,18 @@ def test_maxpool_backward_products_walk_the_live_entries(K, group, G, C, N):
     """csrc/pool_bwd.hip: the two products of Encoder.backward that consume the gradient of torch.max(feature, dim=2) (models/dvae.py:211,214)
     computed from the C live entries per group instead of a dense [G*n, C] operand.  Against float64 on the materialised scatter, against the
     dense on-load kernels (summation order differs: 1e-6), repeated calls bit-identical, a smaller workspace (fewer splits) within rounding,
-    strided operands, entries with arg outside [0, n) dropped, argument checks."""
+    strided operands, entries with arg outside [0, n) dropped, gradients that are zero for most groups (the masked patches of Stage II: those groups are
+    skipped through a device-side list of live groups) or for all, argument checks."""
     import ctypes
     import act_amd.composite as CP
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(group + C + G)
     R = G * group
-    dout = torch.randn(G, C, generator=g).to(dev)
+    dout = torch.randn(G, C, generator=g)
+    if C != 384:
+        dout[torch.arange(G) % 5 != 0] = 0                               # Stage II: only the visible 20 % of the patches carry a gradient
+        dout[5, 1:] = 0                                                  # (a live group with a single non-zero entry)
+    dout = dout.to(dev)
     arg = torch.randint(0, group, (G, C), generator=g, dtype=torch.int32)
     arg[0] = 0                                                           # one group with every channel on row 0 (all other rows empty)
     arg[1, : C // 2] = group - 1
@@ -765,11 +770,18 @@ def test_maxpool_backward_products_walk_the_live_entries(K, group, G, C, N):
         assert lib.act_group_max_bwd_wgrad_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, X.data_ptr(), N, N, p(scale), p(shift), dw_b.data_ptr(), N + 8,
                                                ws.data_ptr(), ws.numel() * 4, st) == 0
         assert torch.equal(dw_b[:, :N], dw[:, :N])
-        for cap in (0, 2 * C * N * 4):                                   # no workspace: one split straight into dw; room for two splits
+        for cap in (0, 2 * C * N * 4 + 16 * G):                          # no workspace: one split straight into dw, every group walked; room for two splits
             dw_c = torch.empty(C, N, device=dev)
             assert lib.act_group_max_bwd_wgrad_f32(dout.data_ptr(), arg.data_ptr(), G, group, C, X.data_ptr(), N, N, p(scale), p(shift), dw_c.data_ptr(), N,
                                                    ws.data_ptr() if cap else None, cap, st) == 0
             assert _rel(dw_c, ref) <= 2e-6
+    # ---- an all-zero gradient: zero results (no live group at all)
+    zero = torch.zeros_like(dout)
+    out = torch.full((R, N), 7.0, device=dev); dw = torch.full((C, N), 7.0, device=dev)
+    assert lib.act_group_max_bwd_matmul_f32(zero.data_ptr(), arg.data_ptr(), G, group, C, wide.data_ptr(), N + 64, N, out.data_ptr(), N, st) == 0
+    assert lib.act_group_max_bwd_wgrad_f32(zero.data_ptr(), arg.data_ptr(), G, group, C, X.data_ptr(), N, N, None, None, dw.data_ptr(), N,
+                                           ws.data_ptr(), ws.numel() * 4, st) == 0
+    assert (out == 0).all() and (dw == 0).all()
     # ---- entries whose arg is outside [0, n) contribute nothing (as in the dense kernels: no row matches)
     arg_bad = arg.clone(); arg_bad[2, ::3] = group; arg_bad[3, 1::5] = -1
     keep = ((arg_bad >= 0) & (arg_bad < group))
