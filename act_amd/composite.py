@@ -60,7 +60,7 @@ class Dgcnn(ctypes.Structure):
 
 class GemmFx(ctypes.Structure):
     _fields_ = ([(n, _vp) for n in ("a_scale", "a_shift", "b_scale", "b_shift", "tile_stats", "gmax", "garg")] + [("group", _i), ("store_c", _i)]
-                + [(n, _vp) for n in ("sa_src", "sa_arg", "ep_src", "ep_arg")])
+                + [(n, _vp) for n in ("sa_src", "sa_arg", "ep_src", "ep_arg", "row_groups")])
 
 
 _P = ctypes.POINTER
@@ -90,6 +90,7 @@ _SIGS = {
     "act_pointnet_saved_floats": [_P(PointnetDims)],
     "act_pointnet_bwd_scratch_floats": [_P(PointnetDims)],
     "act_pointnet_fwd_f32": [_P(PointnetDims), _P(PointnetParams), _vp, _i, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_pointnet_fwd_groups_f32": [_P(PointnetDims), _P(PointnetParams), _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "act_pointnet_bwd_f32": [_P(PointnetDims), _P(PointnetParams), _vp, _vp, _vp, _P(PointnetGrads), _vp, _vp, _sz, _vp],
     "act_dgcnn_scratch_floats": [_P(Dgcnn)],
     "act_dgcnn_features_f32": [_P(Dgcnn), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -390,7 +391,8 @@ class PointnetFn(torch.autograd.Function):
     ``buffers`` = (bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var), updated in place when training."""
 
     @staticmethod
-    def forward(ctx, x, c1w, c1b, g1, b1, c2w, c2b, c3w, c3b, g2, b2, c4w, c4b, buffers, dims, training):
+    def forward(ctx, x, c1w, c1b, g1, b1, c2w, c2b, c3w, c3b, g2, b2, c4w, c4b, buffers, dims, training, groups=None):
+        # ``groups``: int32 ids of the only groups whose tokens are wanted (padded so that len * n % 128 == 0), or None for all
         dev = x.device
         x = K._f32c(x)
         need_grad = any(ctx.needs_input_grad)
@@ -398,9 +400,11 @@ class PointnetFn(torch.autograd.Function):
         saved = torch.empty(int(lib.act_pointnet_saved_floats(ctypes.byref(dims))), dtype=torch.float32, device=dev)
         out = torch.empty(dims.BG, dims.C, dtype=torch.float32, device=dev)
         ws = K.workspace(dev)
-        args = (ctypes.byref(dims), ctypes.byref(prm), _p(x), int(training), int(need_grad), _p(saved), _p(out), _p(ws), ws.numel() * 4)
-        ensure_tuned(("pn_fwd", dims.BG, dims.n, dims.C), lambda: lib.act_pointnet_fwd_f32(*args, _C.stream()), dev)
-        check(lib.act_pointnet_fwd_f32(*args, _C.stream()), "act_pointnet_fwd_f32")
+        ng = 0 if groups is None else int(groups.numel())
+        args = (ctypes.byref(dims), ctypes.byref(prm), _p(x), int(training), int(need_grad), _p(saved), _p(out),
+                _p(groups) if ng else None, ng, _p(ws), ws.numel() * 4)
+        ensure_tuned(("pn_fwd", dims.BG, dims.n, dims.C, ng), lambda: lib.act_pointnet_fwd_groups_f32(*args, _C.stream()), dev)
+        check(lib.act_pointnet_fwd_groups_f32(*args, _C.stream()), "act_pointnet_fwd_groups_f32")
         if need_grad:
             ctx.save_for_backward(x, saved, c1w, c1b, g1, b1, c2w, c2b, c3w, c3b, g2, b2, c4w, c4b)
             ctx.dims, ctx.training = dims, bool(training)
@@ -423,12 +427,19 @@ class PointnetFn(torch.autograd.Function):
         args = (ctypes.byref(dims), ctypes.byref(prm), _p(x), _p(saved), _p(dout), ctypes.byref(gp), _p(scratch), _p(ws), ws.numel() * 4)
         ensure_tuned(("pn_bwd", dims.BG, dims.n, dims.C), lambda: lib.act_pointnet_bwd_f32(*args, _C.stream()), dev)
         check(lib.act_pointnet_bwd_f32(*args, _C.stream()), "act_pointnet_bwd_f32")
-        return (None,) + grads + (None, None, None)
+        return (None,) + grads + (None, None, None, None)
 
 
-def pointnet_forward(enc, point_groups):
-    """``enc`` = models.dvae.Encoder; point_groups [bs, g, n, 3] -> [bs, g, C]"""
+def pointnet_forward(enc, point_groups, need=None):
+    """``enc`` = models.dvae.Encoder; point_groups [bs, g, n, 3] -> [bs, g, C].  ``need`` [bs, k] (int64 group indices per cloud, a fixed count per
+    cloud) restricts the last conv + max-pool to those groups: the other tokens come back as zeros (csrc/composite.hip act_pointnet_fwd_groups_f32)."""
     bs, g, n, _ = point_groups.shape
+    groups = None
+    if need is not None and need.shape[1] < g and n in (32, 64):
+        ids = (need + torch.arange(bs, device=need.device).unsqueeze(1) * g).reshape(-1).to(torch.int32)
+        pad = (-ids.numel()) % (128 // n)                            # whole 128-row tiles: repeat the last group
+        groups = torch.cat([ids, ids[-1:].expand(pad)]) if pad else ids
+        groups = groups.contiguous()
     dims, (c1, bn1, c2, c3, bn2, c4) = _pointnet_structs(enc, bs * g, n)
     training = enc.training
     if training:
@@ -438,7 +449,7 @@ def pointnet_forward(enc, point_groups):
     w2 = lambda c: c.weight.view(c.weight.shape[0], c.weight.shape[1])
     out = PointnetFn.apply(point_groups.reshape(bs * g * n, 3), w2(c1), c1.bias, bn1.weight, bn1.bias, w2(c2), c2.bias, w2(c3), c3.bias,
                            bn2.weight, bn2.bias, w2(c4), c4.bias,
-                           (bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var), dims, training)
+                           (bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var), dims, training, groups)
     return out.reshape(bs, g, dims.C)
 
 

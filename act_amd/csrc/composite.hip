@@ -454,8 +454,15 @@ size_t act_pointnet_bwd_scratch_floats(const act_pointnet_dims_t* d) { if (bad_p
 
 int act_pointnet_fwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, int training, int keep_for_backward,
                          float* saved, float* out, float* ws, size_t wsb, act_stream_t stream) {
+    return act_pointnet_fwd_groups_f32(d, w, x, training, keep_for_backward, saved, out, nullptr, 0, ws, wsb, stream);
+}
+
+int act_pointnet_fwd_groups_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, int training, int keep_for_backward,
+                                float* saved, float* out, const int32_t* groups, int n_groups, float* ws, size_t wsb, act_stream_t stream) {
     if (!w || !x || !saved || !out) return ACT_E_NULLPTR;
     if (bad_pn(d)) return ACT_E_BADARG;
+    if (groups && (n_groups <= 0 || ((long long)n_groups * d->n) % 128)) return ACT_E_BADARG;
+    if (groups && !pn_fused(*d)) groups = nullptr;                  // (the one-kernel-per-layer schedule computes every group)
     hipStream_t s = (hipStream_t)stream;
     const int BG = d->BG, n = d->n, C = d->C, R = BG * n;
     const bool fused = pn_fused(*d);
@@ -509,7 +516,16 @@ int act_pointnet_fwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params
     {   // conv 512->C on relu(bn2(h3)) applied on load; only the max over the group leaves the kernel
         act_gemm_fx_t fx{}; fx.a_scale = scale2; fx.a_shift = shift2; fx.gmax = out; fx.garg = keep_for_backward ? sv.arg2 : nullptr; fx.group = n; fx.store_c = 0;
         e = epi0(); e.bias = w->c4_b;
-        CK(gemm_fx(1, 1, R, C, 512, sv.h3, 512, w->c4_w, 512, nullptr, C, e, fx, ws, wsb, s));
+        if (groups) {                                               // only the listed groups' tokens are wanted: the rest is zero (arg-max row 0)
+            if (!t_collect) {
+                if (hipMemsetAsync(out, 0, (size_t)BG * C * sizeof(float), s) != hipSuccess) return ACT_E_BADARG;
+                if (keep_for_backward && hipMemsetAsync(sv.arg2, 0, (size_t)BG * C * sizeof(int32_t), s) != hipSuccess) return ACT_E_BADARG;
+            }
+            fx.row_groups = groups;
+            CK(gemm_fx(1, 1, n_groups * n, C, 512, sv.h3, 512, w->c4_w, 512, nullptr, C, e, fx, ws, wsb, s));
+        } else {
+            CK(gemm_fx(1, 1, R, C, 512, sv.h3, 512, w->c4_w, 512, nullptr, C, e, fx, ws, wsb, s));
+        }
     }
     return 0;
 }

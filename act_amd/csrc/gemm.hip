@@ -561,7 +561,8 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     p.epi_vec = C ? epilogue_is_vec(C, ldc, p.epi) : 0;
     p.fx.a_scale = fx->a_scale; p.fx.a_shift = fx->a_shift; p.fx.b_scale = fx->b_scale; p.fx.b_shift = fx->b_shift;
     p.fx.tile_stats = fx->tile_stats; p.fx.gmax = fx->gmax; p.fx.garg = fx->garg; p.fx.group = fx->group; p.fx.store_c = fx->store_c;
-    p.fx.sa_src = fx->sa_src; p.fx.sa_arg = fx->sa_arg; p.fx.ep_src = fx->ep_src; p.fx.ep_arg = fx->ep_arg;
+    p.fx.sa_src = fx->sa_src; p.fx.sa_arg = fx->sa_arg; p.fx.ep_src = fx->ep_src; p.fx.ep_arg = fx->ep_arg; p.fx.row_groups = fx->row_groups;
+    if (fx->row_groups && !(a_kmajor && b_kmajor && fx->gmax && !fx->store_c && !fx->tile_stats)) return ACT_E_BADARG;   // listed groups: pooled output only
     int scatter = 0;                                                   // max-pool backward generated on load / added in the epilogue
     if (fx->sa_src || fx->sa_arg) {
         if (!fx->sa_src || !fx->sa_arg) return ACT_E_NULLPTR;
@@ -591,7 +592,7 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         ActProfScope ps(KID_GEMM_NT, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + ((mask & FX_NOSTORE) ? 0.0 : (double)M * N)));
         // hand-scheduled main loop when every K tile is 32 deep (ACT_GEMM_FX_ASM=0: the compiler-scheduled kernels, for A/B runs); same bits either way
         const dim3 fgrid((unsigned)(p.tiles_m * p.tiles_n));
-        if (!((g_fx_asm.load() & 1) && launch_sgemm_nt_asm_fx(p, tile, mask, fgrid, s)) && !launch_sgemm_nt16_fx(p, tile, mask, fgrid, s)) return ACT_E_BADARG;
+        if (!((g_fx_asm.load() & 1) && !fx->row_groups && launch_sgemm_nt_asm_fx(p, tile, mask, fgrid, s)) && !launch_sgemm_nt16_fx(p, tile, mask, fgrid, s)) return ACT_E_BADARG;
         ACT_LAUNCH_CHECK();
         return 0;
     }

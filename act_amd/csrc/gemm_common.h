@@ -19,6 +19,7 @@ struct GemmFx {
     int store_c;                                   // 0: C is not written (only its group max is wanted)
     const float* sa_src; const int32_t* sa_arg;    // NN / TN: virtual A[r][c] = sa_arg[r/group][c] == r % group ? sa_src[r/group][c] : 0 (max-pool backward on load)
     const float* ep_src; const int32_t* ep_arg;    // NN: C[r][c] += ep_arg[r/group][c] == r % group ? ep_src[r/group][c] : 0 in the epilogue
+    const int32_t* row_groups;                     // NT + group max, no C store: A row m = row_groups[m/group]*group + m%group, pooled row m/group -> row_groups[m/group]
 };
 enum { FX_AFFINE_A = 1, FX_COLSTATS = 2, FX_GROUPMAX = 4, FX_NOSTORE = 8, FX_AFFINE_B = 16, FX_SCATTER_A = 32, FX_SCATTER_EPI = 64 };
 

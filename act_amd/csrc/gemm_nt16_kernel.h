@@ -52,13 +52,15 @@ __device__ __forceinline__ void nt_fx_tail(const GemmParams& p, Acc& acc, float*
                 if (group == 32) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const size_t g = (size_t)(m0 + wm * 64 + h * 32) / 32;
+                        size_t g = (size_t)(m0 + wm * 64 + h * 32) / 32;
+                        if (p.fx.row_groups) g = (size_t)p.fx.row_groups[g];
                         p.fx.gmax[g * p.N + col] = hb[h];
                         if (p.fx.garg) p.fx.garg[g * p.N + col] = hi[h];
                     }
                 } else {                                              // one group of 64 rows: the first half wins ties
                     const bool second = hb[1] > hb[0];
-                    const size_t g = (size_t)(m0 + wm * 64) / 64;
+                    size_t g = (size_t)(m0 + wm * 64) / 64;
+                    if (p.fx.row_groups) g = (size_t)p.fx.row_groups[g];
                     p.fx.gmax[g * p.N + col] = second ? hb[1] : hb[0];
                     if (p.fx.garg) p.fx.garg[g * p.N + col] = second ? hi[1] + 32 : hi[0];
                 }
@@ -148,12 +150,18 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
     // global -> register staging: thread v owns the float4 (row = v>>2 (+64 per extra load), chunk = v&3) of each operand tile;
     // rows 64 apart share the swizzle, so the extra loads are plain immediates on one pointer / one LDS offset per operand
     const int srow = tid >> 2, sch = tid & 3;
-    const float* ga = p.A + (size_t)(MG ? min(m0 + srow, p.M - 1) : m0 + srow) * p.lda + kbeg + sch * 4;
+    // (fused variants: the rows may be the listed groups of a larger tensor, GemmFx::row_groups)
+    auto phys_row = [&](int m) -> size_t {
+        if constexpr (FX != 0) { if (p.fx.row_groups) return (size_t)p.fx.row_groups[m / p.fx.group] * p.fx.group + m % p.fx.group; }
+        return (size_t)m;
+    };
+    const float* ga = p.A + (MG ? (size_t)min(m0 + srow, p.M - 1) : phys_row(m0 + srow)) * p.lda + kbeg + sch * 4;
     // B rows are staged PERMUTED (see epilogue_rows): LDS row j*16 + m of every 16*TN-row block holds global row TN*m + j of that block
     const int srow_b = (srow / (16 * TN)) * (16 * TN) + TN * (srow & 15) + (srow % (16 * TN)) / 16;
     const float* gb = p.B + (size_t)(n0 + srow_b) * p.ldb + kbeg + sch * 4;
     const int s_off = srow * 16 + 4 * (sch ^ ((4 - ((srow >> 2) & 3)) & 3));
-    const size_t stride_a = MG ? (size_t)(min(m0 + srow + 64, p.M - 1) - min(m0 + srow, p.M - 1)) * p.lda : (size_t)64 * p.lda;
+    const ptrdiff_t stride_a = MG ? (ptrdiff_t)(min(m0 + srow + 64, p.M - 1) - min(m0 + srow, p.M - 1)) * p.lda
+                                  : ((ptrdiff_t)phys_row(m0 + srow + 64) - (ptrdiff_t)phys_row(m0 + srow)) * p.lda;   // (a listed group may lie below)
     const size_t stride_b = (size_t)64 * p.ldb;
     // staging registers as named scalars (NA, NB <= 2): arrays indexed inside the helper lambdas are not promoted to
     // registers by hipcc here and would round-trip through scratch memory in the main loop

@@ -23,6 +23,8 @@ _PREFETCH_TEACHER = os.environ.get("ACT_PREFETCH_TEACHER", "1") != "0"
 # graph vs 35.7 ms without on MI355X / ROCm 7.2 (graph launch costs the host as much as the individual launches); opt in with
 # ACT_TEACHER_GRAPH=1.  The device-resident Philox step counter makes eager and replayed executions draw identical noise.
 _TEACHER_GRAPH = os.environ.get("ACT_TEACHER_GRAPH", "0") == "1"
+# the student's patch embedding computes its last conv + max-pool only for the visible patches (exact; ACT_ENCODER_VISIBLE_ONLY=0 for A/B runs)
+NEED_VISIBLE_ONLY = os.environ.get("ACT_ENCODER_VISIBLE_ONLY", "1") != "0"
 
 
 class Mlp(nn.Module):
@@ -234,10 +236,11 @@ class VisableOnlyMaskTransformer(nn.Module):
         bool_masked_pos = masker(center, noaug=noaug, draws=draws)                          # B G
         B, G, _ = center.shape
         num_mask = 0 if (noaug or self.mask_ratio == 0) else self.num_mask
-        tokens = self.encoder(neighborhood)                                                 # B G C
+        vis_idx, _ = split_indices(bool_masked_pos, num_mask)
+        # only the visible patches are read below (x[~bool_masked_pos], models/act.py:269-275): the encoder's last conv + pool skip the masked ones
+        tokens = self.encoder(neighborhood, need=vis_idx if (num_mask > 0 and NEED_VISIBLE_ONLY) else None)   # B G C
         if not isinstance(self.reduce_dim, nn.Identity):
             tokens = K.linear(tokens, self.reduce_dim.weight, self.reduce_dim.bias)
-        vis_idx, _ = split_indices(bool_masked_pos, num_mask)
         x_vis = take_rows(tokens, vis_idx)
         pe = self.pos_embed
         pos = K.mlp(take_rows(center, vis_idx), pe[0].weight, pe[0].bias, pe[2].weight, pe[2].bias)

@@ -65,9 +65,12 @@ class Encoder(nn.Module):
         self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
                                          nn.Conv1d(512, self.encoder_channel, 1))
 
-    def forward(self, point_groups):
+    def forward(self, point_groups, need=None):
+        """``need`` [B, k] (optional, no reference counterpart): the only groups per cloud whose tokens the caller reads -- MaskTransformer keeps the
+        visible patches (models/act.py:269-275).  The last conv + max-pool then run on those groups alone and the other tokens come back as ZEROS; every
+        layer in front still sees all groups (BatchNorm statistics are over all of them), so the wanted tokens and all gradients are unchanged."""
         if CP.ENABLED and not any(isinstance(m, nn.SyncBatchNorm) for m in (self.first_conv[1], self.second_conv[1])):
-            return CP.pointnet_forward(self, point_groups)              # one host call per direction (csrc/composite.hip)
+            return CP.pointnet_forward(self, point_groups, need)        # one host call per direction (csrc/composite.hip)
         bs, g, n, _ = point_groups.shape
         x = point_groups.reshape(bs * g * n, 3)
         c1, bn1, _, c2 = self.first_conv

@@ -161,6 +161,10 @@ typedef struct {
     const int32_t* sa_arg;
     const float*   ep_src;
     const int32_t* ep_arg;
+    const int32_t* row_groups;   /* (1,1) with gmax and store_c = 0 only, nullable: the M / group row groups of A are the LISTED groups of a larger
+                                  * tensor -- virtual row m is row row_groups[m / group] * group + m % group of A, and the pooled row m / group is
+                                  * written to row row_groups[m / group] of gmax / garg (Stage II: the patch embedding is only needed for the
+                                  * visible patches, models/act.py:269-275).  A group may be listed twice (padding M to a multiple of 128). */
 } act_gemm_fx_t;
 size_t act_sgemm_fx_tile_stats_floats(int M, int N);
 /* Which fused launches run on the hand-scheduled main loops (csrc/gemm_nt_asm_kernel.h, gemm_q_asm_kernel.h) instead of the compiler-scheduled kernels;
@@ -417,6 +421,13 @@ size_t act_pointnet_saved_floats(const act_pointnet_dims_t* d);
 int act_pointnet_fwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, int training,
                          int keep_for_backward, float* saved, float* out, float* workspace, size_t workspace_bytes,
                          act_stream_t stream);
+/* The same forward when only some groups' tokens are wanted (Stage II: MaskTransformer keeps the visible patches, models/act.py:269-275): everything in
+ * front of the last conv still runs on all groups (its BatchNorm statistics are over all of them), the last conv + max-pool only on the n_groups listed
+ * groups (int32 ids, device memory; n_groups * n a multiple of 128 -- repeat an id to pad).  out / the saved arg-max rows of unlisted groups are set to
+ * zero; the backward then expects a zero gradient row for them.  groups == NULL: act_pointnet_fwd_f32. */
+int act_pointnet_fwd_groups_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, int training, int keep_for_backward,
+                                float* saved, float* out, const int32_t* groups, int n_groups, float* workspace, size_t workspace_bytes,
+                                act_stream_t stream);
 size_t act_pointnet_bwd_scratch_floats(const act_pointnet_dims_t* d);
 int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params_t* w, const float* x, const float* saved,
                          const float* dout, const act_pointnet_grads_t* grads, float* scratch, float* workspace,

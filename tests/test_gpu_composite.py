@@ -181,6 +181,36 @@ def test_composite_gemm_shape_collection(dev):
     assert CP.lib.act_composite_collect_end(buf, 10) < 0      # not collecting any more
 
 
+@pytest.mark.parametrize("C,n,bs,g,k", [(384, 32, 8, 16, 4), (384, 32, 3, 64, 13), (768, 64, 2, 8, 3), (192, 32, 2, 8, 2), (128, 32, 4, 16, 4)])
+def test_encoder_for_listed_groups_is_exact(dev, C, n, bs, g, k):
+    """Encoder.forward(point_groups, need=idx): the last conv + max-pool run only on the k listed groups per cloud (Stage II reads the visible
+    patches only, models/act.py:269-275).  The listed tokens are the bits of the full forward, the other tokens are zero, and with a gradient that is
+    zero outside the listed groups every parameter gradient and the running statistics are the bits of the full forward + backward (bs * k * n is
+    not a multiple of 128 in the second case: the list is padded with a repeated group; C = 192 falls back to the dense backward products)."""
+    from act_amd.models.dvae import Encoder
+    from tests.golden.fill import fill_module
+    torch.manual_seed(11)
+    nb = 0.2 * torch.randn(bs, g, n, 3, device=dev)
+    need = torch.stack([torch.randperm(g, device=dev)[:k].sort().values for _ in range(bs)])
+    dout = torch.zeros(bs, g, C, device=dev)
+    dout.scatter_(1, need.unsqueeze(-1).expand(-1, -1, C), torch.randn(bs, k, C, device=dev))
+    res = []
+    for listed in (False, True):
+        enc = fill_module(Encoder(C), "need.enc.").to(dev).train()
+        y = enc(nb, need=need if listed else None)
+        y.backward(dout)
+        torch.cuda.synchronize()
+        res.append(dict([("y", y.detach())] + [(kk, p.grad) for kk, p in enc.named_parameters()] + [("buf." + kk, b.clone().float()) for kk, b in enc.named_buffers()]))
+    full, part = res
+    picked = lambda t: torch.gather(t, 1, need.unsqueeze(-1).expand(-1, -1, C))
+    assert torch.equal(picked(part["y"]), picked(full["y"]))
+    rest = torch.ones(bs, g, dtype=torch.bool, device=dev).scatter_(1, need, False)
+    assert (part["y"][rest] == 0).all()
+    for kk in full:
+        if kk != "y":
+            assert torch.equal(part[kk], full[kk]), kk
+
+
 @pytest.mark.parametrize("C,n,bs,g", [(384, 32, 8, 16), (128, 32, 4, 64), (192, 64, 2, 24), (768, 64, 2, 8)])
 def test_encoder_fused_schedule_matches_plain(dev, C, n, bs, g):
     """mini-PointNet with BatchNorm statistics / apply + ReLU / max-pool fused into the GEMMs (csrc/composite.hip, fused schedule) against

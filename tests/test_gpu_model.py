@@ -490,6 +490,44 @@ def test_cross_step_teacher_prefetch_is_exact(dev):
         assert torch.equal(p, results[1][1][n]), n
 
 
+def test_visible_only_patch_embedding_is_exact(dev):
+    """The student's Encoder computes its last conv + max-pool for the visible patches only (models/act.py:269-275 reads x[~bool_masked_pos]; every
+    layer in front, BatchNorm statistics included, still runs on all patches): the 3-step training trajectory is bit-identical to running it on all."""
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import train_step, _Single, freeze_unused_heads
+    from act_amd.utils.config import EasyDict
+    import act_amd.models.act as ACT
+    cfg = EasyDict(optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3, weight_decay=0.05)),
+                   scheduler=dict(type="CosLR", kwargs=dict(epochs=300, initial_epochs=10)), step_per_update=1)
+    import copy
+    from act_amd.models import build_model_from_cfg
+    mcfg = copy.deepcopy(TINY_STAGE2)                       # 32-point patches, 128-wide tokens: the geometry the fused patch embedding takes
+    mcfg["dvae_config"].update(group_size=32, num_group=16)
+    mcfg["transformer_config"].update(encoder_dims=128)
+    batches = [torch.from_numpy(clouds(40 + i, 4, 512)).to(dev) for i in range(3)]
+    results = []
+    saved = ACT.NEED_VISIBLE_ONLY
+    try:
+        for visible_only in (False, True, False, True):     # (first pair: warm-up -- first-use GEMM tuning of either mode's shapes draws random numbers)
+            ACT.NEED_VISIBLE_ONLY = visible_only
+            torch.manual_seed(0)
+            model = fill_module(build_model_from_cfg(EasyDict(mcfg)), "vis.").to(dev).train()
+            model.dvae_tokenizer.prompt_dropout.p = 0.0
+            freeze_unused_heads(model)
+            wrapped = _Single(model)
+            opt, _ = builder.build_opti_sche(wrapped, cfg)
+            torch.manual_seed(77)
+            losses = [train_step(wrapped, opt, b.clone(), cfg) for b in batches]
+            torch.cuda.synchronize()
+            results.append((torch.stack(losses).cpu(), {n: p.detach().clone().cpu() for n, p in model.named_parameters()}))
+    finally:
+        ACT.NEED_VISIBLE_ONLY = saved
+    results = results[2:]
+    assert torch.equal(results[0][0], results[1][0]), (results[0][0], results[1][0])
+    for n, p in results[0][1].items():
+        assert torch.equal(p, results[1][1][n]), n
+
+
 def test_block_mask_type_matches_reference_and_trains(dev):
     """mask_type: block (models/act.py:215-242): device-side implementation == the reference's per-cloud loop (golden g12, injected
     seed indices); a Stage-II step with it runs and agrees with the oracle."""
