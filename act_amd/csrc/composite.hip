@@ -420,6 +420,10 @@ bool pn_pool_bwd_sparse() {
     static const bool on = [] { const char* e = getenv("ACT_PN_POOL_BWD_SPARSE"); return !(e && e[0] == '0'); }();
     return on;
 }
+bool pn_pool_bwd_live() {                                                        // ACT_POOL_BWD_LIVE=0: every group is walked / written / read
+    static const bool on = [] { const char* e = getenv("ACT_POOL_BWD_LIVE"); return !(e && e[0] == '0'); }();
+    return on;
+}
 size_t carve_pn(float* base, const act_pointnet_dims_t& d, PnSaved& sv) {
     const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
     const bool fused = pn_fused(d);
@@ -431,13 +435,14 @@ size_t carve_pn(float* base, const act_pointnet_dims_t& d, PnSaved& sv) {
     else { sv.a1 = c.take(R * 128); sv.a3 = c.take(R * 512); sv.h4 = c.take(R * C); sv.tstats = nullptr; }
     return c.used;
 }
-struct PnBwdScratch { float *dh4, *da3, *dh3, *dgw, *dh2, *dfg, *da1, *dh1, *act; };
+struct PnBwdScratch { float *dh4, *da3, *dh3, *dgw, *dh2, *dfg, *da1, *dh1, *act; int32_t* live; };
 size_t carve_pn_bwd(float* base, const act_pointnet_dims_t& d, PnBwdScratch& sc) {
     const size_t R = (size_t)d.BG * d.n, BG = d.BG, C = d.C;
     Carver c(base);
     sc.dh4 = pn_pool_bwd_on_load(d) ? nullptr : c.take(R * C); sc.da3 = c.take(R * 512); sc.dh3 = c.take(R * 512); sc.dgw = c.take(BG * 512); sc.dh2 = c.take(R * 256);
     sc.dfg = c.take(BG * 256); sc.da1 = c.take(R * 128); sc.dh1 = c.take(R * 128);
     sc.act = (pn_fused(d) && d.C % 128 != 0) ? c.take(R * 512) : nullptr;      // a3 rebuilt for the one weight gradient the fused TN kernel cannot take
+    sc.live = reinterpret_cast<int32_t*>(c.take(BG));                            // groups with a non-zero gradient row (Stage II: the visible patches)
     return c.used;
 }
 bool bad_pn(const act_pointnet_dims_t* d) { return !d || d->BG <= 0 || d->n <= 0 || d->C <= 0 || (d->C & 3); }
@@ -551,11 +556,15 @@ int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params
         return gemm_tn(N_, Cc, R, dy, N_, sc.act, Cc, dw, Cc, ws, wsb, s);
     };
     const bool pool_on_load = pn_pool_bwd_on_load(*d);
+    const int32_t* live = nullptr;
     if (pool_on_load && pn_pool_bwd_sparse()) {
         // dh4 has one live entry per (group, channel): both products walk those instead of a dense [R, C] operand (pool_bwd.hip)
         RUN(act_group_max_bwd_wgrad_f32(dout, sv.arg2, BG, n, C, sv.h3, 512, 512, st(sv.st2, 512, 2), st(sv.st2, 512, 3), g->c4_w, 512, ws, wsb, s));
         CK(colsum(dout, BG, C, g->c4_b, ws, wsb, s));
-        RUN(act_group_max_bwd_matmul_f32(dout, sv.arg2, BG, n, C, w->c4_w, 512, 512, sc.da3, 512, s));
+        // da3 of a group without gradient (a masked patch) is zero: not written here, not read by the BatchNorm backward below
+        live = pn_pool_bwd_live() ? sc.live : nullptr;
+        if (live) RUN(act_group_live_i32(dout, BG, C, sc.live, s));
+        RUN(act_group_max_bwd_matmul_live_f32(dout, sv.arg2, BG, n, C, w->c4_w, 512, 512, sc.da3, 512, live, s));
     } else if (pool_on_load) {
         // dW4 = dh4^T . relu(bn2(h3)) and da3 = dh4 . W4 with dh4[r][c] = (arg2[r/n][c] == r % n ? dout[r/n][c] : 0) generated on load
         act_gemm_fx_t fx{}; fx.sa_src = dout; fx.sa_arg = sv.arg2; fx.group = n; fx.b_scale = st(sv.st2, 512, 2); fx.b_shift = st(sv.st2, 512, 3);
@@ -570,8 +579,8 @@ int act_pointnet_bwd_f32(const act_pointnet_dims_t* d, const act_pointnet_params
         else       CK(colsum(sc.dh4, R, C, g->c4_b, ws, wsb, s));
         CK(gemm_nn(R, 512, C, sc.dh4, C, w->c4_w, 512, sc.da3, 512, epi0(), ws, wsb, s));
     }
-    RUN(act_bn_bwd_f32(sv.h3, sc.da3, st(sv.st2, 512, 2), st(sv.st2, 512, 3), st(sv.st2, 512, 0), st(sv.st2, 512, 1), 1, R, 512, sc.dh3, g->bn2_w, g->bn2_b,
-                       ws, wsb, s));
+    RUN(act_bn_bwd_groups_f32(sv.h3, sc.da3, st(sv.st2, 512, 2), st(sv.st2, 512, 3), st(sv.st2, 512, 0), st(sv.st2, 512, 1), 1, R, 512, live, n, sc.dh3,
+                              g->bn2_w, g->bn2_b, ws, wsb, s));
     // the two column halves of dW3 [512, 512]: [:, :256] from the per-group path, [:, 256:] from the per-point path
     CK(gemm_tn(512, 256, R, sc.dh3, 512, sv.h2, 256, g->c3_w + 256, 512, ws, wsb, s));
     RUN(act_group_sum_f32(sc.dh3, BG, n, 512, sc.dgw, s));

@@ -13,7 +13,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void colstats_stage1(const float* __restrict__ x, const float* __restrict__ dy,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       int relu, int R, int C, int rows_per_block, float* __restrict__ partial) {
+                                                       int relu, int R, int C, int rows_per_block, float* __restrict__ partial,
+                                                       const int32_t* __restrict__ live = nullptr, int live_n = 1) {
     __shared__ float sh[2][4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -24,6 +25,8 @@ __global__ __launch_bounds__(256) void colstats_stage1(const float* __restrict__
         if (MODE == 1) { sc = scale[c]; sf = shift[c]; mu = mean[c]; rs = rstd[c]; }
         else pv = x[c];                                  // pivot (row 0) keeps E[x^2]-E[x]^2 free of cancellation
         auto term = [&](int r, float& f, float& g) {
+            // (MODE 1) rows of a group whose dy is all zero add exact zeros to both sums: skipped without changing a bit
+            if (MODE == 1 && live && !live[r / live_n]) return;
             const float xv = x[(size_t)r * C + c];
             if (MODE == 0) { const float t = xv - pv; f += t; g += t * t; }
             else {
@@ -115,14 +118,43 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ s1, const float* __restrict__ s2, int relu,
-                                                           float invR, long long total, int C, float* __restrict__ dx) {
+                                                           float invR, long long total, int C, float* __restrict__ dx,
+                                                           const int32_t* __restrict__ live = nullptr, int live_n = 1) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const float xv = x[i], sc = scale[c];
-        float d = dy[i];
+        float d = (live && !live[(i / C) / live_n]) ? 0.f : dy[i];    // (a dead group's dy is zero by contract and is not read)
         if (relu && !(xv * sc + shift[c] > 0.f)) d = 0.f;
         const float xh = (xv - mean[c]) * rstd[c];
         dx[i] = sc * (d - s1[c] * invR - xh * s2[c] * invR);
+    }
+}
+// the same map four columns per thread (C % 4 == 0, 16-byte aligned tensors)
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ s1, const float* __restrict__ s2, int relu,
+                                                            float invR, long long total4, int C4, float* __restrict__ dx,
+                                                            const int32_t* __restrict__ live, int live_n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const float4 xv = reinterpret_cast<const float4*>(x)[i], sc = reinterpret_cast<const float4*>(scale)[c4], sf = reinterpret_cast<const float4*>(shift)[c4];
+        const float4 mu = reinterpret_cast<const float4*>(mean)[c4], rs = reinterpret_cast<const float4*>(rstd)[c4];
+        const float4 a1 = reinterpret_cast<const float4*>(s1)[c4], a2 = reinterpret_cast<const float4*>(s2)[c4];
+        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(live && !live[(i / C4) / live_n])) d = reinterpret_cast<const float4*>(dy)[i];
+        if (relu) {
+            if (!(xv.x * sc.x + sf.x > 0.f)) d.x = 0.f;
+            if (!(xv.y * sc.y + sf.y > 0.f)) d.y = 0.f;
+            if (!(xv.z * sc.z + sf.z > 0.f)) d.z = 0.f;
+            if (!(xv.w * sc.w + sf.w > 0.f)) d.w = 0.f;
+        }
+        float4 o;
+        o.x = sc.x * (d.x - a1.x * invR - ((xv.x - mu.x) * rs.x) * a2.x * invR);
+        o.y = sc.y * (d.y - a1.y * invR - ((xv.y - mu.y) * rs.y) * a2.y * invR);
+        o.z = sc.z * (d.z - a1.z * invR - ((xv.z - mu.z) * rs.z) * a2.z * invR);
+        o.w = sc.w * (d.w - a1.w * invR - ((xv.w - mu.w) * rs.w) * a2.w * invR);
+        reinterpret_cast<float4*>(dx)[i] = o;
     }
 }
 
@@ -207,19 +239,29 @@ extern "C" int act_affine_act_f32(const float* x, const float* scale, const floa
 extern "C" int act_bn_bwd_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean,
                               const float* rstd, int relu, int R, int C, float* dx, float* dgamma, float* dbeta,
                               float* workspace, size_t workspace_bytes, act_stream_t stream) {
+    return act_bn_bwd_groups_f32(x, dy, scale, shift, mean, rstd, relu, R, C, nullptr, 1, dx, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+extern "C" int act_bn_bwd_groups_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean,
+                                     const float* rstd, int relu, int R, int C, const int32_t* live, int n, float* dx, float* dgamma, float* dbeta,
+                                     float* workspace, size_t workspace_bytes, act_stream_t stream) {
     if (!x || !dy || !scale || !shift || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return ACT_E_NULLPTR;
-    if (R <= 0 || C <= 0) return ACT_E_BADARG;
+    if (R <= 0 || C <= 0 || (live && (n <= 0 || R % n))) return ACT_E_BADARG;
     const int parts = stats_parts(R, C);
     if (workspace_bytes < (size_t)parts * 2 * C * sizeof(float)) return ACT_E_BADARG;
     int rpb = (R + parts - 1) / parts; rpb = (rpb + 3) / 4 * 4;
     const int nparts = (R + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_BN_BWD, s, 0.0, 20.0 * R * (double)C);
-    hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace);
+    hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace,
+                       live, n);
     hipLaunchKernelGGL(colstats_stage2, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nparts, C, dbeta, dgamma);
     const long long total = (long long)R * C;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, dbeta, dgamma, relu,
-                       1.0f / (float)R, total, C, dx);
+    const bool vec = (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd |
+                                       (uintptr_t)dbeta | (uintptr_t)dgamma) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, dbeta, dgamma, relu,
+                                1.0f / (float)R, total / 4, C / 4, dx, live, n);
+    else     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, dbeta, dgamma, relu,
+                                1.0f / (float)R, total, C, dx, live, n);
     ACT_LAUNCH_CHECK(); return 0;
 }
 

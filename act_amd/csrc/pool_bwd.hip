@@ -34,7 +34,7 @@ __device__ __forceinline__ void vzero(float4& a) { a = make_float4(0.f, 0.f, 0.f
 
 template <int VEC>
 __global__ __launch_bounds__(256) void pool_bwd_dx_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, const float* __restrict__ W,
-                                                          int ldw, int n, int C, float* __restrict__ out, int ldo, int skip_zero) {
+                                                          int ldw, int n, int C, float* __restrict__ out, int ldo, int skip_zero, const int32_t* __restrict__ glive) {
     using V = typename VecT<VEC>::T;
     extern __shared__ unsigned char smem[];
     int* s_arg = reinterpret_cast<int*>(smem);                                   // [C]
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void pool_bwd_dx_kernel(const float* __restric
     int* s_wsum = s_start + n + 1;                                               // [4]
     unsigned short* s_ord = reinterpret_cast<unsigned short*>(s_wsum + 4);       // [C]
     const int tid = threadIdx.x, g = blockIdx.x;
+    if (glive && !glive[g]) return;                                              // (the caller knows this group is dead and never reads its rows)
     int live = 0;
     for (int c = tid; c < C; c += 256) { const float d = dout[(size_t)g * C + c]; s_arg[c] = arg[(size_t)g * C + c]; s_d[c] = d; live |= (d != 0.f); }
     const int any_live = __syncthreads_or(live);                                 // (also the barrier between the LDS fill and the bucket passes)
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void pool_bwd_dx_kernel(const float* __restric
 // the float2 form at N = 512: 469 -> 334 us at the Stage-II geometry, 1643 -> 1146 us at C5.)
 template <int P>
 __global__ __launch_bounds__(256) void pool_bwd_dx4_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg, const float* __restrict__ W,
-                                                           int ldw, int n, int C, float* __restrict__ out, int ldo, int skip_zero) {
+                                                           int ldw, int n, int C, float* __restrict__ out, int ldo, int skip_zero, const int32_t* __restrict__ glive) {
     extern __shared__ unsigned char smem[];
     int* s_arg = reinterpret_cast<int*>(smem);                                   // [C]
     float* s_d = reinterpret_cast<float*>(s_arg + C);                            // [C]
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void pool_bwd_dx4_kernel(const float* __restri
     int* s_wsum = s_start + n + 1;                                               // [4]
     unsigned short* s_ord = reinterpret_cast<unsigned short*>(s_wsum + 4);       // [C]
     const int tid = threadIdx.x, g = blockIdx.x;
+    if (glive && !glive[g]) return;                                              // (the caller knows this group is dead and never reads its rows)
     int live = 0;
     for (int c = tid; c < C; c += 256) { const float d = dout[(size_t)g * C + c]; s_arg[c] = arg[(size_t)g * C + c]; s_d[c] = d; live |= (d != 0.f); }
     const int any_live = __syncthreads_or(live);                                 // (also the barrier between the LDS fill and the bucket passes)
@@ -361,8 +363,21 @@ int dw_splits(int G, int C, int N, size_t workspace_bytes) {
 }
 }  // namespace
 
+extern "C" int act_group_live_i32(const float* d, int G, int C, int32_t* live, act_stream_t stream) {
+    if (!d || !live) return ACT_E_NULLPTR;
+    if (G < 0 || C <= 0) return ACT_E_BADARG;
+    if (G == 0) return 0;
+    hipLaunchKernelGGL(pool_bwd_flags_kernel, dim3((G + 3) / 4), dim3(256), 0, (hipStream_t)stream, d, G, C, live);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+
 extern "C" int act_group_max_bwd_matmul_f32(const float* dout, const int32_t* arg, int G, int n, int C, const float* w, int ldw, int N, float* dx,
                                             int lddx, act_stream_t stream) {
+    return act_group_max_bwd_matmul_live_f32(dout, arg, G, n, C, w, ldw, N, dx, lddx, nullptr, stream);
+}
+
+extern "C" int act_group_max_bwd_matmul_live_f32(const float* dout, const int32_t* arg, int G, int n, int C, const float* w, int ldw, int N, float* dx,
+                                                 int lddx, const int32_t* live, act_stream_t stream) {
     if (!dout || !arg || !w || !dx) return ACT_E_NULLPTR;
     if (G < 0 || !pool_geom_ok(n, C) || N <= 0 || (N != 256 && N != 512 && N != 1024) || ldw < N || lddx < N || (ldw & 3) || (lddx & 3) ||
         ((uintptr_t)w & 15) || ((uintptr_t)dx & 15))
@@ -373,11 +388,11 @@ extern "C" int act_group_max_bwd_matmul_f32(const float* dout, const int32_t* ar
     const size_t lds = (size_t)C * 8 + (size_t)(n + 1 + 4) * 4 + (size_t)C * 2;
     const int parts = 1024 / N, skip = pool_live_on() ? 1 : 0;
     if (n % parts == 0) {
-        if (N == 256)      hipLaunchKernelGGL(pool_bwd_dx4_kernel<4>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);
-        else if (N == 512) hipLaunchKernelGGL(pool_bwd_dx4_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);
-        else               hipLaunchKernelGGL(pool_bwd_dx4_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);
-    } else if (N == 256)   hipLaunchKernelGGL(pool_bwd_dx_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);   // (n = 1, 2)
-    else                   hipLaunchKernelGGL(pool_bwd_dx_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip);
+        if (N == 256)      hipLaunchKernelGGL(pool_bwd_dx4_kernel<4>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip, live);
+        else if (N == 512) hipLaunchKernelGGL(pool_bwd_dx4_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip, live);
+        else               hipLaunchKernelGGL(pool_bwd_dx4_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip, live);
+    } else if (N == 256)   hipLaunchKernelGGL(pool_bwd_dx_kernel<1>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip, live);   // (n = 1, 2)
+    else                   hipLaunchKernelGGL(pool_bwd_dx_kernel<2>, dim3(G), dim3(256), lds, s, dout, arg, w, ldw, n, C, dx, lddx, skip, live);
     ACT_LAUNCH_CHECK(); return 0;
 }
 

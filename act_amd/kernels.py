@@ -795,6 +795,9 @@ _C._declare({
     "act_group_sum_f32": [_vp, _i, _i, _i, _vp, _vp],
     "act_group_max_bwd_matmul_f32": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp],
     "act_group_max_bwd_wgrad_workspace": [_i, _i, _i, _i],
+    "act_group_live_i32": [_vp, _i, _i, _vp, _vp],
+    "act_group_max_bwd_matmul_live_f32": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp],
+    "act_bn_bwd_groups_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp],
     "act_group_max_bwd_wgrad_f32": [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp],
     "act_col_mean_var_f32": [_vp, _i, _i, _vp, _vp, _vp, _sz, _vp],
     "act_bn_bwd_sums_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp],
@@ -805,7 +808,8 @@ _C.lib.act_colsum_workspace.restype = _sz
 _C.lib.act_colstats_workspace.restype = _sz
 _C.lib.act_group_max_bwd_wgrad_workspace.restype = _sz
 for _n in ("act_colstats_workspace", "act_bn_stats_f32", "act_affine_act_f32", "act_bn_bwd_f32", "act_group_max_f32",
-           "act_group_max_bwd_f32", "act_group_max_bwd_matmul_f32", "act_group_max_bwd_wgrad_workspace", "act_group_max_bwd_wgrad_f32", "act_group_sum_f32", "act_col_mean_var_f32", "act_bn_bwd_sums_f32", "act_bn_bwd_apply_f32"):
+           "act_group_max_bwd_f32", "act_group_max_bwd_matmul_f32", "act_group_max_bwd_wgrad_workspace", "act_group_max_bwd_wgrad_f32", "act_group_live_i32",
+           "act_group_max_bwd_matmul_live_f32", "act_bn_bwd_groups_f32", "act_group_sum_f32", "act_col_mean_var_f32", "act_bn_bwd_sums_f32", "act_bn_bwd_apply_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
 
 

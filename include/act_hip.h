@@ -263,6 +263,11 @@ int act_affine_act_f32(const float* x, const float* scale, const float* shift, i
 int act_bn_bwd_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean,
                    const float* rstd, int relu, int R, int C, float* dx, float* dgamma, float* dbeta,
                    float* workspace, size_t workspace_bytes, act_stream_t stream);
+/* the same backward when dy is known to be zero on whole groups of n consecutive rows: rows r with live[r / n] == 0 are treated as dy = 0 and dy is not
+ * read for them (bit-identical to act_bn_bwd_f32 on a dy that holds zeros there: the skipped terms are exact zeros).  live == NULL: act_bn_bwd_f32. */
+int act_bn_bwd_groups_f32(const float* x, const float* dy, const float* scale, const float* shift, const float* mean, const float* rstd, int relu,
+                          int R, int C, const int32_t* live, int n, float* dx, float* dgamma, float* dbeta, float* workspace,
+                          size_t workspace_bytes, act_stream_t stream);
 /* SyncBatchNorm building blocks (the statistics are all-reduced across ranks by the host between the calls, tools/runner_pretrain.py:86-88):
  * per-column mean / biased variance of this rank's rows; backward sums of this rank's rows; dx from the global sums over `count` rows. */
 int act_col_mean_var_f32(const float* x, int R, int C, float* mean, float* var, float* workspace, size_t workspace_bytes, act_stream_t stream);
@@ -285,6 +290,12 @@ int act_group_max_bwd_f32(const float* dout, const int32_t* arg, int G, int n, i
  * the partial sums in order (workspace bytes from act_group_max_bwd_wgrad_workspace; a smaller workspace only lowers the split count). */
 int act_group_max_bwd_matmul_f32(const float* dout, const int32_t* arg, int G, int n, int C, const float* w, int ldw, int N, float* dx, int lddx,
                                  act_stream_t stream);
+/* live[g] = (d[g][0:C] has a non-zero entry).  In Stage II the patch embedding runs on all B*G patches but only the visible ones feed the loss, so
+ * 80 % of the rows of its output gradient are exactly zero (models/act.py:269-275); the kernels below skip those groups (the wgrad builds its own list).
+ * matmul_live: the n rows of a group with live[g] == 0 are NOT written -- for a consumer that takes the same list (act_bn_bwd_groups_f32). */
+int act_group_live_i32(const float* d, int G, int C, int32_t* live, act_stream_t stream);
+int act_group_max_bwd_matmul_live_f32(const float* dout, const int32_t* arg, int G, int n, int C, const float* w, int ldw, int N, float* dx, int lddx,
+                                      const int32_t* live, act_stream_t stream);
 size_t act_group_max_bwd_wgrad_workspace(int G, int n, int C, int N);
 int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg, int G, int n, int C, const float* x, int ldx, int N, const float* scale,
                                 const float* shift, float* dw, int lddw, float* workspace, size_t workspace_bytes, act_stream_t stream);

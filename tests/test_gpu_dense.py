@@ -805,6 +805,52 @@ def test_maxpool_backward_products_walk_the_live_entries(K, group, G, C, N):
     torch.cuda.synchronize()
 
 
+def test_batchnorm_backward_skips_dead_groups_without_changing_a_bit(K):
+    """act_bn_bwd_groups_f32 / act_group_max_bwd_matmul_live_f32 / act_group_live_i32: with a gradient that is zero on whole groups of rows (the masked
+    patches of Stage II) the BatchNorm backward neither reads dy there nor changes a bit of dx / dgamma / dbeta (the skipped terms are exact zeros),
+    and the row walk does not write the dead groups' rows at all."""
+    dev = torch.device("cuda:0")
+    lib = K.lib
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(5)
+    G, n, C, N = 96, 32, 384, 512
+    R = G * n
+    dout = torch.randn(G, C, generator=g)
+    dout[torch.arange(G) % 4 != 1] = 0
+    dout = dout.to(dev)
+    arg = torch.randint(0, n, (G, C), generator=g, dtype=torch.int32).to(dev)
+    W = (torch.randn(C, N, generator=g) * 0.1).to(dev)
+    live = torch.full((G,), 7, dtype=torch.int32, device=dev)
+    assert lib.act_group_live_i32(dout.data_ptr(), G, C, live.data_ptr(), st) == 0
+    assert torch.equal(live.cpu(), (torch.arange(G) % 4 == 1).to(torch.int32))
+    full = torch.empty(R, N, device=dev); part = torch.full((R, N), 7.0, device=dev)
+    assert lib.act_group_max_bwd_matmul_f32(dout.data_ptr(), arg.data_ptr(), G, n, C, W.data_ptr(), N, N, full.data_ptr(), N, st) == 0
+    assert lib.act_group_max_bwd_matmul_live_f32(dout.data_ptr(), arg.data_ptr(), G, n, C, W.data_ptr(), N, N, part.data_ptr(), N, live.data_ptr(), st) == 0
+    rows_live = live.bool().repeat_interleave(n)
+    assert torch.equal(part[rows_live], full[rows_live]) and (part[~rows_live] == 7.0).all() and (full[~rows_live] == 0).all()
+    # BatchNorm(+ReLU) backward on that gradient: dead rows of `part` hold garbage (7.0) and must not be read
+    x = torch.randn(R, N, generator=g).to(dev)
+    gamma = (torch.rand(N, generator=g) + 0.5).to(dev); beta = (torch.randn(N, generator=g) * 0.1).to(dev)
+    mean = x.mean(0); rstd = torch.rsqrt(x.var(0, unbiased=False) + 1e-5)
+    scale = gamma * rstd; shift = beta - mean * scale
+    ws = torch.empty(8 << 20, device=dev)
+    outs = []
+    for dy, lv in ((full, None), (part, live)):
+        dx = torch.empty(R, N, device=dev); dg = torch.empty(N, device=dev); db = torch.empty(N, device=dev)
+        assert lib.act_bn_bwd_groups_f32(x.data_ptr(), dy.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 1, R, N,
+                                         lv.data_ptr() if lv is not None else None, n, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                         ws.numel() * 4, st) == 0
+        outs.append((dx, dg, db))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # against autograd (float64)
+    xd = x.double().requires_grad_(True)
+    y = torch.relu(torch.nn.functional.batch_norm(xd, None, None, gamma.double(), beta.double(), True, 0.0, 1e-5))
+    y.backward(full.double())
+    assert _rel(outs[1][0], xd.grad) <= 2e-5
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("tile,base", [(17, 10), (18, 11)])
 def test_gemm_nt_pipelined_loop_is_bit_identical(K, tile, base):
     """tiles 17 / 18: the NT b128 kernels with the software-pipelined main loop (fragments of K-tile t+1 read during the MFMAs of tile t, LDS-only
