@@ -21,7 +21,7 @@ import sys
 
 
 def fold(name):
-    n = name.replace("void ", "").split("(")[0]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     m = re.match(r"sgemm_kernel<\d+, \d+, \d+, (true|false), (true|false)", n)
     if not m:
         m = re.match(r"sgemm16_kernel<\d+, \d+, (true|false), (true|false)", n)

@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:58]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:58]
     grid = (r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
     k = (name, grid)
     agg[k][0] += 1
