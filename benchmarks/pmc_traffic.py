@@ -57,19 +57,23 @@ def main():
     # (bn_bwd_apply_kernel: reads x and dy, writes dx, each [262144, C] fp32, C = 128 and 512 once per Stage-II step)
     # round 3: per-workload calibration bytes (argv[3] = c2 | s1 | c5): mean [rows, C] fp32 tensor size over the bn_bwd_apply launches of a step --
     # c2: mini-PointNet BN(128), BN(512) on 128*64*32 rows; s1: those two + the FoldingNet BN(512) x 2 on 128*64*32 rows; c5: 32*512*64 rows
+    # round 4: the kernel is bn_bwd_apply4_kernel (four columns per thread), and in Stage II the BN(512) launch reads dy only for the rows of the
+    # visible patches (13 of 64 groups per cloud at c2, 103 of 512 at c5; act_bn_bwd_groups_f32): read bytes = x (all rows) + dy (live rows)
     WORKLOAD = sys.argv[3] if len(sys.argv) > 3 else "c2"
-    CAL_KERNEL = "bn_bwd_apply_kernel"
+    CAL_KERNEL = "bn_bwd_apply4_kernel"
     CAL_BYTES = {"c2": 262144.0 * (128 + 512) / 2 * 4, "s1": 262144.0 * (128 + 512 + 512 + 512) / 4 * 4,
                  "c5": 1048576.0 * (128 + 512) / 2 * 4}[WORKLOAD]
+    CAL_READ = {"c2": 262144.0 * (2 * 128 + (1 + 13.0 / 64) * 512) / 2 * 4, "s1": 2.0 * CAL_BYTES,
+                "c5": 1048576.0 * (2 * 128 + (1 + 103.0 / 512) * 512) / 2 * 4}[WORKLOAD]
     fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-    kf = 2.0 * CAL_BYTES / (fetch[CAL_KERNEL][0] * 1024.0)
+    kf = CAL_READ / (fetch[CAL_KERNEL][0] * 1024.0)
     kw = CAL_BYTES / (write[CAL_KERNEL][0] * 1024.0)
     out = {"workload": WORKLOAD, "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline --no-instrument",
            "units": "bytes per launch = counter [KiB] * 1024 * calibration factor",
-           "calibration": {"kernel": CAL_KERNEL, "known_bytes_written_per_launch": CAL_BYTES, "known_bytes_read_per_launch": 2.0 * CAL_BYTES,
+           "calibration": {"kernel": CAL_KERNEL, "known_bytes_written_per_launch": CAL_BYTES, "known_bytes_read_per_launch": CAL_READ,
                            "fetch_factor": kf, "write_factor": kw,
-                           "cross_check": "colstats_stage1 (BatchNorm backward sums) reads x and dy = 2 x 262144 x (128 + 512) / 2 x 4 = 671,088,640 B per launch on average and writes (almost) nothing"},
+                           "cross_check": "colsum / layernorm / affine kernels of known size in the same file"},
            "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         fb = fetch.get(k, (0.0, 0))[0] * 1024.0 * kf
