@@ -9,8 +9,11 @@
 //   da[g*n + j][:] = sum over {c : arg[g][c] == j} of dout[g][c] * W[c][:]                       (pool_bwd_dx_kernel)
 //   dW[c][:]       = sum over g of dout[g][c] * act(X[g*n + arg[g][c]][:])                       (pool_bwd_dw2_kernel)
 //
-// Summation order is fixed by the shapes alone (ascending c inside a row; ascending g inside a split, splits folded in order), so the results
-// are run-to-run and process-to-process identical; they differ from the dense path's MFMA summation order in the last bits.
+// Summation order is fixed by the shapes and the set of live groups alone (ascending c inside a row; ascending g inside a split, splits folded
+// in order), so the results are run-to-run and process-to-process identical; they differ from the dense path's MFMA summation order in the
+// last bits.  Groups whose gradient row is entirely zero -- in Stage II the 51 masked of 64 patches per cloud, whose tokens the student never
+// reads (models/act.py:269-275) -- are skipped: the weight gradient walks a device-built list of live groups, the row walk returns at once
+// (writing zeros, or nothing when the consumer takes the same liveness flags: act_bn_bwd_groups_f32).
 #include "common.h"
 
 namespace {
