@@ -182,9 +182,11 @@ __global__ __launch_bounds__(256) void pool_bwd_dx4_kernel(const float* __restri
 // Channel-per-lane form of the same product: workgroup = (64 * NW channels, 64 columns, range of groups), one wave per 64 channels with 64
 // accumulators per lane.  Each lane loads ITS (arg, dout) pairs with plain coalesced loads, turns arg into the offset of its slice row, and
 // reads that row two columns at a time with immediate offsets: per (group, channel, 2 columns) one ds_read_b64 and two FMAs -- no broadcast
-// reads, no per-column address arithmetic.  The slice rows are 66 dwords apart, so the 32 rows of a group sit on 32 different bank pairs and
-// lanes with different arg rows never conflict (n = 64: two rows per pair).  NW = C / 64 up to 6, so the slice of X is read once (C <= 384)
-// or C / 384 times.  One step = GB consecutive groups (GB * n contiguous rows of X): the next step's rows are in flight in registers while
+// reads, no per-column address arithmetic.  The slice rows are 68 dwords apart: the compiler pairs the adjacent 8-byte reads into
+// ds_read2_b64, which the LDS serves like a 16-byte access -- 16 lanes per cycle, four consecutive banks per lane -- so a pitch of 4 (mod 64)
+// dwords puts rows r and r' on disjoint bank quads unless r = r' (mod 16).  Measured at the Stage-II geometry, every group live, random arg
+// rows: pitch 66 / 70 / 74 / 98: 315 us, 72: 252, 68: 215 (rows 0..31 in lane order: 255, 216, 195).  NW = C / 64 up to 6, so the slice of
+// X is read once (C <= 384) or C / 384 times.  One step = GB consecutive groups (GB * n contiguous rows of X): the next step's rows are in flight in registers while
 // this step's GB groups are consumed from LDS, one barrier per step -- a memory round trip (~3 us under load) is amortised over GB groups
 // instead of paid per group.  The accumulators leave through an LDS transpose: the partial tile is written in 128-byte runs.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_bwd_dw2_kernel(const float* _
                                                                   int ldx, const float* __restrict__ scale, const float* __restrict__ shift, int n, int C,
                                                                   int G, int gps, float* __restrict__ part, int ldp, size_t split_stride, int nslices,
                                                                   int xcd_map, const int* __restrict__ live, const int* __restrict__ nlive, int splits) {
-    constexpr int NT = 64 * NW, KC = 64, STRIDE = KC + 2;
+    constexpr int NT = 64 * NW, KC = 64, STRIDE = KC + 4;                        // row pitch 68 dwords: the bank note above
     constexpr int MAXF = (GB * 64 * 16 / (GB == 4 ? 2 : 1) + NT - 1) / NT;      // GB = 4: n <= 32;  GB = 2: n <= 64
     extern __shared__ float4 smem4[];
     float* tile = reinterpret_cast<float*>(smem4);                               // [2][GB * n][STRIDE]
@@ -242,9 +244,7 @@ __global__ __launch_bounds__(64 * NW, 2) void pool_bwd_dw2_kernel(const float* _
                     v.x = fmaxf(v.x * sc4.x + sh4.x, 0.f); v.y = fmaxf(v.y * sc4.y + sh4.y, 0.f);
                     v.z = fmaxf(v.z * sc4.z + sh4.z, 0.f); v.w = fmaxf(v.w * sc4.w + sh4.w, 0.f);
                 }
-                float* q = b + (f >> 4) * STRIDE + (f & 15) * 4;                 // (8-byte aligned: STRIDE is even)
-                *reinterpret_cast<float2*>(q) = make_float2(v.x, v.y);
-                *reinterpret_cast<float2*>(q + 2) = make_float2(v.z, v.w);
+                *reinterpret_cast<float4*>(b + (f >> 4) * STRIDE + (f & 15) * 4) = v;    // (16-byte aligned: STRIDE % 4 == 0)
             }
         }
     };
@@ -439,7 +439,7 @@ extern "C" int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg
     const int ldp = splits > 1 ? N : lddw;
     const size_t stride = (size_t)C * N;
     const int gb = n <= 32 ? 4 : 2;
-    const size_t lds = max((size_t)2 * gb * n * 66 * sizeof(float), (size_t)nw * 64 * 33 * sizeof(float));
+    const size_t lds = max((size_t)2 * gb * n * 68 * sizeof(float), (size_t)nw * 64 * 33 * sizeof(float));
     const int nslices = N / 64, xcd_map = splits % 8 == 0 ? 1 : 0;
     const dim3 grid(nslices * splits, C / (64 * nw), 1);
 #define LAUNCH_DW2(NW_, GB_)                                                                                                                      \
