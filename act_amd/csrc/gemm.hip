@@ -338,6 +338,81 @@ __global__ __launch_bounds__(256) void sgemm_tn_skinny_kernel(const float* __res
     }
 }
 
+// The same reduction with 16-byte loads of the wide operand (W % 4 == 0, 16-byte aligned): a row of W floats takes W / 4 threads, the workgroup's
+// other threads are k-lanes (8 at W = 128), every wave-level load moves 1 KB instead of 256 B.  Round 4: the dW of the 3 -> 128 first conv
+// (wide = dh1 [262144, 128], 134 MB) 166 -> see DESIGN; the launch is also cut into enough K ranges to fill the chip when K is only a few
+// thousand rows (the 16-workgroup launches of the position-embedding weight gradients took 117 us for 4 MB).
+template <bool SMALL_N>
+__global__ __launch_bounds__(256) void sgemm_tn_skinny4_kernel(const float* __restrict__ wide, int ldw, int W, const float* __restrict__ skinny,
+                                                               int lds, int ns, int K, int rows_per_part, int M, int N, int tpr_shift,
+                                                               float* __restrict__ partial) {
+    extern __shared__ float red4[];                                   // [KL - 1][tpr][4 * 8]
+    const int tpr = 1 << tpr_shift, KL = 256 >> tpr_shift;
+    const int c4 = threadIdx.x & (tpr - 1), klane = threadIdx.x >> tpr_shift;
+    const int col = (blockIdx.x * tpr + c4) * 4;
+    const int kbeg = blockIdx.y * rows_per_part, kend = min(K, kbeg + rows_per_part);
+    float acc[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
+    if (col < W) {
+#pragma unroll 4
+        for (int k = kbeg + klane; k < kend; k += KL) {
+            const float4 w = *reinterpret_cast<const float4*>(wide + (size_t)k * ldw + col);
+            const float* sk = skinny + (size_t)k * lds;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < ns) { const float sv = sk[j]; acc[0][j] += w.x * sv; acc[1][j] += w.y * sv; acc[2][j] += w.z * sv; acc[3][j] += w.w * sv; }
+        }
+    }
+    if (klane > 0) {
+        float* r = red4 + ((size_t)(klane - 1) * tpr + c4) * 32;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[q * 8 + j] = acc[q][j];
+    }
+    __syncthreads();
+    if (klane == 0 && col < W) {
+        float* dst = partial + (size_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < ns) {
+                    float v = acc[q][j];
+                    for (int l = 1; l < KL; ++l) v += red4[((size_t)(l - 1) * tpr + c4) * 32 + q * 8 + j];      // k-lanes in order
+                    if (SMALL_N) dst[(size_t)(col + q) * N + j] = v;      // C[m = col + q][n = j]
+                    else         dst[(size_t)j * N + col + q] = v;        // C[m = j][n = col + q]
+                }
+    }
+}
+// fold of the K-range partials for those launches (up to 1024 ranges, a few hundred outputs): 64 outputs x 4 range-lanes per workgroup, eight loads
+// in flight per thread, lanes folded through LDS in a fixed order, then the ordinary epilogue
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
+                                                            const act_gemm_epilogue_t epi) {
+    __shared__ float red[3][64];
+    const long long total = (long long)M * N;
+    const long long i = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x >> 6;
+    float v = 0.f;
+    if (i < total) {
+#pragma unroll 8
+        for (int sp = lane; sp < splits; sp += 4) v += partial[(size_t)sp * total + i];
+    }
+    if (lane > 0) red[lane - 1][threadIdx.x & 63] = v;
+    __syncthreads();
+    if (lane == 0 && i < total) {
+        v = (v + red[0][threadIdx.x]) + (red[1][threadIdx.x] + red[2][threadIdx.x]);
+        const int row = (int)(i / N), col = (int)(i % N);
+        v = epilogue_apply(epi, v, row, col);
+        float* c = C + (size_t)row * ldc + col;
+        if (epi.accumulate) v += *c;
+        *c = v;
+    }
+}
+
 template <int BM, int BN, int BK>
 static void launch_variant(const GemmParams& p, int ak, int bk, bool vec, bool full, bool pipe, dim3 grid, hipStream_t s) {
 #define L(AK, BKK, V, F, P) hipLaunchKernelGGL((sgemm_kernel<BM, BN, BK, AK, BKK, V, F, P>), grid, dim3(256), 0, s, p)
@@ -399,6 +474,33 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     ActProfScope ps(kid, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
 
     if (!a_kmajor && !b_kmajor && tile == 0 && (M <= 8 || N <= 8) && K >= 2048 && workspace) {
+        // wide operand as float4 rows (round 4): W % 4 == 0, 16 .. 64 threads per row, the rest of the workgroup are k-lanes
+        static const bool skinny4 = [] { const char* e = getenv("ACT_GEMM_SKINNY4"); return !(e && e[0] == '0'); }();
+        const bool small_n = N <= 8;
+        const float* wide = small_n ? A : B; const float* skin = small_n ? B : A;
+        const int ldw_ = small_n ? lda : ldb, lds_ = small_n ? ldb : lda, W = small_n ? M : N, ns = small_n ? N : M;
+        if (skinny4 && W % 4 == 0 && W >= 64 && (ldw_ & 3) == 0 && (reinterpret_cast<uintptr_t>(wide) & 15) == 0) {
+            int tpr_shift = 6; while ((4 << tpr_shift) > W && tpr_shift > 4) --tpr_shift;       // 64 / 32 / 16 threads per row
+            const int tpr = 1 << tpr_shift, KL = 256 >> tpr_shift, gx = (W + 4 * tpr - 1) / (4 * tpr);
+            int nparts = (1024 + gx - 1) / gx;                                                  // ~4 workgroups per CU
+            nparts = min(nparts, max(1, K / (8 * KL)));                                         // at least 8 rows per k-lane
+            nparts = min(nparts, 1024);
+            const size_t fit = workspace_bytes / ((size_t)M * N * sizeof(float));
+            if ((size_t)nparts > fit) nparts = (int)fit;
+            if (nparts >= 1) {
+                const int rpp = ((K + nparts - 1) / nparts + KL - 1) / KL * KL;
+                nparts = (K + rpp - 1) / rpp;
+                const size_t ldsb = (size_t)(KL - 1) * tpr * 32 * sizeof(float);
+                if (small_n) hipLaunchKernelGGL(sgemm_tn_skinny4_kernel<true>, dim3(gx, nparts), dim3(256), ldsb, s, wide, ldw_, W, skin, lds_, ns, K, rpp, M, N,
+                                                tpr_shift, workspace);
+                else         hipLaunchKernelGGL(sgemm_tn_skinny4_kernel<false>, dim3(gx, nparts), dim3(256), ldsb, s, wide, ldw_, W, skin, lds_, ns, K, rpp, M, N,
+                                                tpr_shift, workspace);
+                ACT_LAUNCH_CHECK();
+                hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)(((long long)M * N + 63) / 64)), dim3(256), 0, s, workspace, nparts, M, N, C, ldc, p.epi);
+                ACT_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         int nparts = K / 1024; if (nparts > 256) nparts = 256; if (nparts < 1) nparts = 1;
         const int rpp = ((K + nparts - 1) / nparts + 3) / 4 * 4;
         nparts = (K + rpp - 1) / rpp;

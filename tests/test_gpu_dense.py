@@ -568,7 +568,7 @@ def test_gemm_row_strided_operands(K):
         assert _rel(K.gemm(dy, ws, True, False), dy.double().cpu() @ ws.double().cpu()) <= 2e-5       # NN with a strided B
 
 
-@pytest.mark.parametrize("M,N,Kd", [(128, 3, 262144), (3, 512, 65536), (512, 5, 40000), (1, 70, 4099), (100, 8, 2048)])
+@pytest.mark.parametrize("M,N,Kd", [(128, 3, 262144), (3, 512, 65536), (512, 5, 40000), (1, 70, 4099), (100, 8, 2048), (128, 3, 8192), (64, 8, 3001), (5, 1024, 20000)])
 def test_gemm_skinny_weight_gradient(K, M, N, Kd):
     """TN products with one dimension <= 8 (first conv / FoldingNet weight gradients) run the streaming-reduction kernel."""
     a = _rnd(f"sk.a{M}{N}", Kd, M); b = _rnd(f"sk.b{M}{N}", Kd, N)
