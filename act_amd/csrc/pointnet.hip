@@ -48,6 +48,53 @@ __global__ __launch_bounds__(256) void colstats_stage1(const float* __restrict__
     }
 }
 
+// MODE 1 with four columns per thread (C % 4 == 0, 16-byte aligned operands): workgroup = 16 column quads x 16 row-lanes, four rows in flight
+// per thread = eight 16-byte loads; the 4-byte form moves 2.4 TB/s on the two-operand backward sums, this one see DESIGN (round 4).  Same
+// partial layout; the row-lanes are folded through LDS in a fixed order.
+__global__ __launch_bounds__(256) void colstats_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            int relu, int R, int C, int rows_per_block, float* __restrict__ partial,
+                                                            const int32_t* __restrict__ live, int live_n) {
+    __shared__ float4 sh[2][15][16];
+    const int cq = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cq * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float4 f[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { f[u] = make_float4(0.f, 0.f, 0.f, 0.f); g[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (c < C) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sf = *reinterpret_cast<const float4*>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), rs = *reinterpret_cast<const float4*>(rstd + c);
+        auto term = [&](int r, float4& ff, float4& gg) {
+            if (live && !live[r / live_n]) return;                      // (exact zeros: skipped without changing a bit)
+            const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * C + c);
+            float4 d = *reinterpret_cast<const float4*>(dy + (size_t)r * C + c);
+            if (relu) {
+                if (!(xv.x * sc.x + sf.x > 0.f)) d.x = 0.f;
+                if (!(xv.y * sc.y + sf.y > 0.f)) d.y = 0.f;
+                if (!(xv.z * sc.z + sf.z > 0.f)) d.z = 0.f;
+                if (!(xv.w * sc.w + sf.w > 0.f)) d.w = 0.f;
+            }
+            ff.x += d.x; ff.y += d.y; ff.z += d.z; ff.w += d.w;
+            gg.x += d.x * ((xv.x - mu.x) * rs.x); gg.y += d.y * ((xv.y - mu.y) * rs.y);
+            gg.z += d.z * ((xv.z - mu.z) * rs.z); gg.w += d.w * ((xv.w - mu.w) * rs.w);
+        };
+        int r = r0 + ry;
+        for (; r + 48 < r1; r += 64) { term(r, f[0], g[0]); term(r + 16, f[1], g[1]); term(r + 32, f[2], g[2]); term(r + 48, f[3], g[3]); }
+        for (; r < r1; r += 16) term(r, f[0], g[0]);
+    }
+    auto add4 = [](const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); };
+    float4 fs = add4(add4(f[0], f[1]), add4(f[2], f[3])), gs = add4(add4(g[0], g[1]), add4(g[2], g[3]));
+    if (ry > 0) { sh[0][ry - 1][cq] = fs; sh[1][ry - 1][cq] = gs; }
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        for (int l = 0; l < 15; ++l) { fs = add4(fs, sh[0][l][cq]); gs = add4(gs, sh[1][l][cq]); }
+        *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.y * 2 + 0) * C + c) = fs;
+        *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.y * 2 + 1) * C + c) = gs;
+    }
+}
+
 // BatchNorm finalize: mean, biased var -> scale = gamma*rstd, shift = beta - mean*scale; running stats (momentum, unbiased var)
 // fold the stage-1 partial rows [nparts][2][C]: workgroup = 64 columns x 4 part-lanes, 8 loads in flight per thread, lanes folded
 // through LDS in a fixed order (a single thread per column walking ~1000 partial rows is a 150 us chain of dependent loads)
@@ -252,12 +299,17 @@ extern "C" int act_bn_bwd_groups_f32(const float* x, const float* dy, const floa
     const int nparts = (R + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_BN_BWD, s, 0.0, 20.0 * R * (double)C);
-    hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace,
-                       live, n);
+    const bool vec = (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd |
+                                       (uintptr_t)dbeta | (uintptr_t)dgamma | (uintptr_t)workspace) & 15) == 0;
+    static const bool stats4 = [] { const char* e = getenv("ACT_BN_BWD_STATS4"); return !(e && e[0] == '0'); }();
+    if (vec && stats4)
+        hipLaunchKernelGGL(colstats_bwd4_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace,
+                           live, n);
+    else
+        hipLaunchKernelGGL(colstats_stage1<1>, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace,
+                           live, n);
     hipLaunchKernelGGL(colstats_stage2, dim3((C + 63) / 64), dim3(256), 0, s, workspace, nparts, C, dbeta, dgamma);
     const long long total = (long long)R * C;
-    const bool vec = (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd |
-                                       (uintptr_t)dbeta | (uintptr_t)dgamma) & 15) == 0;
     if (vec) hipLaunchKernelGGL(bn_bwd_apply4_kernel, dim3(grid_for(total / 4, 256)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, dbeta, dgamma, relu,
                                 1.0f / (float)R, total / 4, C / 4, dx, live, n);
     else     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, dbeta, dgamma, relu,
