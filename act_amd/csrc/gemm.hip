@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256) void sgemm_splitk_reduce(const float* __restri
             const int row = (int)(i / n4), col = (int)(i - (long long)row * n4) * 4;
             const float* p = partial + (size_t)row * N + col;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4                                                      // (four loads in flight; the additions stay in split order)
             for (int s = 0; s < splits; ++s) {
                 const float4 x = *reinterpret_cast<const float4*>(p + (size_t)s * total);
                 v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(256) void sgemm_splitk_reduce(const float* __restri
     } else {
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
             float v = 0.f;
+#pragma unroll 4
             for (int s = 0; s < splits; ++s) v += partial[(size_t)s * total + i];
             const int row = (int)(i / N), col = (int)(i % N);
             v = epilogue_apply(epi, v, row, col);

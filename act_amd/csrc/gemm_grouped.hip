@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void sgemm_grouped_reduce_kernel(const Grouped
             const long long off = rem * 4;
             const float* part = g.ws + g.p[pi].part_off + off;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4                                                      // (four loads in flight; the additions stay in K-range order)
             for (int s = 0; s < g.splits; ++s) {
                 const float4 x = *reinterpret_cast<const float4*>(part + (size_t)s * M * N);
                 v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(256) void sgemm_grouped_reduce_kernel(const Grouped
             if (pi < 0) continue;
             const float* part = g.ws + g.p[pi].bias_off + rem;
             float v = 0.f;
+#pragma unroll 4
             for (int s = 0; s < g.splits; ++s) v += part[(size_t)s * g.p[pi].M];
             g.p[pi].bias_out[rem] = v;
         }
