@@ -521,10 +521,12 @@ int act_pointnet_fwd_groups_f32(const act_pointnet_dims_t* d, const act_pointnet
     {   // conv 512->C on relu(bn2(h3)) applied on load; only the max over the group leaves the kernel
         act_gemm_fx_t fx{}; fx.a_scale = scale2; fx.a_shift = shift2; fx.gmax = out; fx.garg = keep_for_backward ? sv.arg2 : nullptr; fx.group = n; fx.store_c = 0;
         e = epi0(); e.bias = w->c4_b;
-        if (groups) {                                               // only the listed groups' tokens are wanted: the rest is zero (arg-max row 0)
+        if (groups) {                                               // only the listed groups' tokens are wanted: the rest is a constant zero
             if (!t_collect) {
                 if (hipMemsetAsync(out, 0, (size_t)BG * C * sizeof(float), s) != hipSuccess) return ACT_E_BADARG;
-                if (keep_for_backward && hipMemsetAsync(sv.arg2, 0, (size_t)BG * C * sizeof(int32_t), s) != hipSuccess) return ACT_E_BADARG;
+                // arg-max of an unlisted group = -1 (no row): every backward form drops an out-of-range arg (arg == r tests, (unsigned)arg < n),
+                // so a gradient row that a caller hands in for an unlisted group reaches neither dX nor dW4 -- its true gradient is zero
+                if (keep_for_backward && hipMemsetAsync(sv.arg2, 0xFF, (size_t)BG * C * sizeof(int32_t), s) != hipSuccess) return ACT_E_BADARG;
             }
             fx.row_groups = groups;
             CK(gemm_fx(1, 1, n_groups * n, C, 512, sv.h3, 512, w->c4_w, 512, nullptr, C, e, fx, ws, wsb, s));

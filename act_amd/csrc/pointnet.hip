@@ -299,8 +299,11 @@ extern "C" int act_bn_bwd_groups_f32(const float* x, const float* dy, const floa
     const int nparts = (R + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_BN_BWD, s, 0.0, 20.0 * R * (double)C);
-    const bool vec = (C % 4 == 0) && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd |
-                                       (uintptr_t)dbeta | (uintptr_t)dgamma | (uintptr_t)workspace) & 15) == 0;
+    // the kernel choice (and with it the fp32 summation order of dgamma / dbeta) depends on the SHAPE only: C % 4 == 0 takes the 16-byte
+    // forms and requires 16-byte aligned operands (BADARG otherwise) instead of silently falling back to the scalar order
+    const bool vec = (C % 4 == 0);
+    if (vec && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd |
+                 (uintptr_t)dbeta | (uintptr_t)dgamma | (uintptr_t)workspace) & 15) != 0) return ACT_E_BADARG;
     static const bool stats4 = [] { const char* e = getenv("ACT_BN_BWD_STATS4"); return !(e && e[0] == '0'); }();
     if (vec && stats4)
         hipLaunchKernelGGL(colstats_bwd4_kernel, dim3((C + 63) / 64, nparts), dim3(256), 0, s, x, dy, scale, shift, mean, rstd, relu, R, C, rpb, workspace,

@@ -708,7 +708,7 @@ def pairwise_distill_loss(student, teacher, kind, num_mask, temperature=0.07, la
             pos = blk.gather(2, partner.view(1, m, 1).expand(g, m, 1)).squeeze(2)
             lse = torch.logsumexp(blk.masked_fill(eye, float("-inf")), dim=2)
             total = total + (lse - pos).mean(dim=1).sum()
-        return (total / num_mask / B).reshape(1)
+        return (total / num_mask / B).reshape(())
     if kind == "barlow":
         za = (s - s.mean(1, keepdim=True)) / s.std(1, keepdim=True)                                                    # unbiased std along the tokens
         zb = (t - t.mean(1, keepdim=True)) / t.std(1, keepdim=True)
@@ -718,7 +718,7 @@ def pairwise_distill_loss(student, teacher, kind, num_mask, temperature=0.07, la
         for b in range(B):
             c = linear(za[b].t().contiguous(), zb[b].t().contiguous()) / n                                             # z_a^T z_b / n  [C, C]
             total = total + ((c - eye).pow(2) * w).sum()
-        return (total / num_mask / B).reshape(1)
+        return (total / num_mask / B).reshape(())
     raise _C.ActHipError(f"pairwise_distill_loss: unknown kind {kind!r}")
 
 

@@ -63,16 +63,18 @@ class _Single(nn.Module):
 
 class _Announced:
     """the batch that the previous train_step on THIS model already augmented (in place) and announced to the teacher prefetch: a weak
-    reference plus the tensor version right after the augmentation, kept on the model object (two models trained in one process do not
-    see each other's batches), so the same tensor handed back as ``points`` is not augmented twice"""
+    reference plus the tensor version right after the augmentation, kept per model in a module-level WeakKeyDictionary (two models trained in one
+    process do not see each other's batches; nothing is stored ON the module, so ``torch.save(model)`` / ``mp.spawn(args=(model,))`` still pickle
+    it), so the same tensor handed back as ``points`` is not augmented twice"""
+    _by_model = weakref.WeakKeyDictionary()
 
     @staticmethod
     def mark(model, t):
-        model.__dict__["_act_announced"] = (weakref.ref(t), t._version)
+        _Announced._by_model[model] = (weakref.ref(t), t._version)
 
     @staticmethod
     def is_marked(model, t):
-        ref, version = model.__dict__.get("_act_announced", (None, -1))
+        ref, version = _Announced._by_model.get(model, (None, -1))
         return ref is not None and ref() is t and version == t._version
 
 

@@ -155,7 +155,7 @@ def cpu_group_baseline(B=128, N=1024, G=64, M=32, reps=3):
             "group_sample": f"Group(FPS {G} + kNN {M}) on {B} x {N} clouds, plain-C oracle, OpenMP over clouds ({os.cpu_count()} host cores visible)"}
 
 
-def other_workloads(timeout_s=150):
+def other_workloads(timeout_s=100):
     """python bench.py --stage 1 / --config c5 (10 / 6 timed steps, no instrumented pass, no CPU baseline) -> {name: {clouds_per_s, ms_per_step,
     final_loss, steps, workload}}; a failure is reported in place of the numbers, never raised."""
     import subprocess
@@ -176,7 +176,56 @@ def other_workloads(timeout_s=150):
                          "workload": d["config"]["workload"], "wall_s": time.time() - t0}
         except Exception as e:
             res[name] = {"failed": str(e)[-300:], "wall_s": time.time() - t0}
+    # the children inherit every ACT_* switch of this process: say which were set, so an A/B run of the parent cannot silently relabel these numbers
+    res["act_env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith("ACT_")}
     return res
+
+
+XGMI_LINK_GBS = 153.0               # per xGMI link and direction; 7 links per GPU (point-to-point, fully connected 8-GPU node)
+
+
+def self_launch(n, argv):
+    """``python bench.py --gpus N`` (N > 1) WITHOUT a launcher environment: spawn the N ranks here -- re-run this same file under
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>`` (the driver's own launch form;
+    reference main.py:21-28,44-58 reads the ranks from the launcher env the same way) -- and hand its stdout (rank 0's ONE JSON line) and exit code
+    through.  One-node only, as the reference (utils/dist_utils.py:9-24: local_rank == rank)."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ACT_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"bench.py: no launcher environment (WORLD_SIZE unset) -- spawning {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, cwd=ROOT, env=env)
+
+
+def allreduce_probe(device, numel, world, backend, reps=10, warm=3):
+    """standalone timing of ONE all-reduce (sum) of the Stage-II gradient payload (``numel`` fp32 = every trainable parameter,
+    tools/runner_pretrain.py:89 DDP payload): hipEvents on the current stream, which torch's process group makes wait for the collective's own
+    stream.  bus GB/s = 2 (N-1)/N x bytes / t (ring convention); xGMI peak for a ring is ONE link per direction per neighbour (153 GB/s), for a
+    fully-connected direct all-reduce 7 links."""
+    buf = torch.ones(numel, device=device, dtype=torch.float32)
+    for _ in range(warm):
+        dist.all_reduce(buf)
+        buf.fill_(1.0)
+    torch.cuda.synchronize(); dist.barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record(); dist.all_reduce(buf); b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)[reps // 2]
+    t = torch.tensor([ms], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = t.item()
+    nbytes = 4.0 * numel
+    alg = nbytes / (ms * 1e-3) / 1e9
+    bus = alg * 2.0 * (world - 1) / world
+    return {"backend": backend, "world_size_seen_by_rccl": dist.get_world_size(), "allreduce_payload_MB": nbytes / 1e6, "allreduce_ms": ms,
+            "allreduce_alg_GBps": alg, "allreduce_bus_GBps": bus,
+            "allreduce_GBps_vs_xgmi": {"bus_over_one_link": bus / XGMI_LINK_GBS, "bus_over_seven_links": bus / (7 * XGMI_LINK_GBS),
+                                       "link_GBps": XGMI_LINK_GBS},
+            "allreduce_note": f"median of {reps} back-to-back all-reduces of the whole gradient payload, max over ranks, nothing else on the chip "
+                              "(in the training step the 25 MB DDP buckets overlap the backward); world 1 moves no data"}
 
 
 _NEXT = None
@@ -201,6 +250,13 @@ def main():
                     help="skip the short configs[2] (Stage I) and configs[4] (C5 stress) timings that the default single-GPU run appends as other_workloads")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: launch the ranks ourselves (a SCALE run must not depend on the caller's launcher)
+        ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if ndev < args.gpus and os.environ.get("ACT_BENCH_SHARE_GPU") != "1":
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible (ACT_BENCH_SHARE_GPU=1 ACT_BENCH_BACKEND=gloo puts every "
+                             "rank on the visible devices round-robin: a test mode, not a measurement)")
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -219,7 +275,11 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    gpus_flag = args.gpus
+    if world != args.gpus:                              # the launcher's environment is the truth (main.py:44-58); never die on the flag
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: reporting n_gpus={world}", file=sys.stderr, flush=True)
+        args.gpus = world
 
     import act_amd._C as C
     from act_amd.models import build_model_from_cfg
@@ -334,10 +394,21 @@ def main():
         hb = [torch.zeros(2, device=device, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(hb, torch.tensor([host_idle_ms, 1e3 * host_issue / args.steps], device=device, dtype=torch.float64))
         host_by_rank = [[round(v, 3) for v in t.tolist()] for t in hb]
+    ms_by_rank = None
     if world > 1:
+        el = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(el, torch.tensor([elapsed], device=device, dtype=torch.float64))
+        ms_by_rank = [round(1e3 * e.item() / args.steps, 4) for e in el]
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    comm = None
+    if world > 1 or force_ddp:
+        n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        comm = allreduce_probe(device, n_train, world, dist.get_backend())
+        comm["launched_by"] = "bench.py itself (torch.distributed.run child)" if os.environ.get("ACT_BENCH_SELF_LAUNCHED") == "1" else "external launcher"
+        if gpus_flag != world:
+            comm["gpus_flag"] = gpus_flag
     loss_val = float(loss.item())
     if not math.isfinite(loss_val):                      # a diverged / NaN step would still be timed happily: refuse to report it
         raise RuntimeError(f"bench: non-finite loss {loss_val} after {args.warmup + args.steps + 3} steps")
@@ -381,6 +452,13 @@ def main():
                       if args.stage == 2 else {})},
     }
 
+    out["config"]["parity_bar"] = ("loss and features within 1e-4 of the fp32 CPU oracle at this geometry and batch; FPS / kNN indices bit-exact; gradients "
+                                   "flip-tolerant: <= 1e-3 of a gradient's elements may exceed 1e-4 (the reference's own fp32 summation-order noise through the "
+                                   "hard arg-max / max-pool choices), L2 error <= 5e-3 (tests/test_gpu_model.py)")
+    if ms_by_rank:
+        out["ms_per_step_by_rank"] = ms_by_rank
+    if comm:
+        out["comm"] = comm
     if windows:
         out["sustained"] = {"window_steps": WIN, "ms_per_step_by_window": windows, "first": windows[0], "last": windows[-1],
                             "note": "hipEvent time of consecutive 50-step windows of the timed region (clock / power drift shows as a slope)"}
@@ -450,6 +528,27 @@ def main():
                 break
         out["kernels"] = kernels
         out["hip_kernel_ms_per_step"] = tot_ms / nprof
+        # ---- whole-step roofline: FLOPs the HIP kernels really executed this step (sum of 2mnk of every launch, counted at launch) against the
+        # timed region's step time; next to it the reference formulation's count (38.2 GFLOP per cloud for Stage II at the configs[1]
+        # geometry) -- clouds/s x 38.2 GFLOP exceeds the fp32 MFMA peak because exact restructurings removed work (config.exact_restructurings).
+        ex_tflop = sum(v["flops"] for v in table.values()) / nprof / 1e12
+        step_s = elapsed / args.steps
+        ref_tflop = {("c2", 2): 38.2e-3 * B, ("c5", 2): 483e-3 * B, ("c2", 1): 70e-3 * B}.get(("c5" if c5 else "c2", args.stage))
+        out["roofline"]["step"] = {"executed_tflop": ex_tflop, "reference_formulation_tflop": ref_tflop,
+                                   "achieved_tflops": ex_tflop / step_s, "frac": ex_tflop / step_s / PEAK_F32_MFMA_TFLOPS,
+                                   "reference_formulation_tflops_equiv": (ref_tflop / step_s) if ref_tflop else None,
+                                   "note": "executed = sum over every GEMM / attention launch of one step of 2mnk as launched (per GPU); "
+                                           "reference_formulation = SURVEY 8(d) FLOPs of the reference's own graph for this batch"}
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_util_%s.json" % tag)), reverse=True):
+            try:
+                pm = json.load(open(pf))
+                mu = {k: round(v["mfma_util_percent_time_weighted"], 1) for k, v in pm["kernels"].items()}
+            except Exception:
+                continue
+            out["roofline"]["mfma_util"] = {"percent_time_weighted": mu, "dominant": mu.get(dom),
+                                            "source": "committed profile figure, not measured in this run: rocprofv3 --pmc MfmaUtil pass of this workload, "
+                                                      "profiles/" + os.path.basename(pf)}
+            break
         # ---- FPS + kNN "Group" throughput (BASELINE metric part 2), hipEvents on the current stream ------------------
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         grp = model.group_divider if hasattr(model, "group_divider") else None

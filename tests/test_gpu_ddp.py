@@ -208,17 +208,25 @@ def test_sync_batchnorm_two_ranks_equals_full_batch(tmp_path):
     assert rel(r[0]["y"], enc(nb_all[:4].to(dev)).detach().cpu()) > 1e-3
 
 
-def test_bench_two_ranks_on_one_gpu_prints_one_line(tmp_path):
-    """bench.py under the driver's launcher with world size 2 (both ranks on cuda:0, gloo instead of RCCL: the only multi-rank form a one-GPU box
-    allows): warm-up, timed steps, the idle-GPU host-cost steps and the instrumented pass all run on EVERY rank (each step contains the gradient
-    all-reduce, so a rank-0-only pass would wait in a collective for ever), rank 0 prints exactly one JSON line with the whole-job value."""
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_ranks_on_one_gpu_prints_one_line(tmp_path, launcher):
+    """bench.py at world size 2 (both ranks on cuda:0, gloo instead of RCCL: the only multi-rank form a one-GPU box allows), launched (i) the
+    driver's way under torch.distributed.run and (ii) as plain ``python bench.py --gpus 2`` with NO launcher environment -- bench.py then spawns
+    its own ranks (reference main.py:21-28,44-58 takes the ranks from the launcher env; utils/dist_utils.py:9-24).  Warm-up, timed steps, the
+    idle-GPU host-cost steps, the all-reduce probe and the instrumented pass all run on EVERY rank (each step contains the gradient all-reduce, so a
+    rank-0-only pass would wait in a collective for ever); rank 0 prints exactly one JSON line with the whole-job value."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ACT_BENCH_SHARE_GPU="1", ACT_BENCH_BACKEND="gloo", ACT_GEMM_AUTOTUNE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547"] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -227,6 +235,27 @@ def test_bench_two_ranks_on_one_gpu_prints_one_line(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # whole-job clouds/s = B * world / step time
     assert "roofline" in d and "cpu_baseline" not in d and d["config"]["final_loss"] == d["config"]["final_loss"]
+    assert d["roofline"]["step"]["executed_tflop"] > 0 and "parity_bar" in d["config"]
+    assert len(d["ms_per_step_by_rank"]) == 2 and max(d["ms_per_step_by_rank"]) == pytest.approx(d["ms_per_step"], rel=1e-3)
+    c = d["comm"]
+    assert c["backend"] == "gloo" and c["world_size_seen_by_rccl"] == 2 and c["allreduce_ms"] > 0 and c["allreduce_bus_GBps"] > 0
+    assert ("bench.py itself" in c["launched_by"]) == (launcher == "self")
+
+
+def test_bench_tolerates_a_gpus_flag_that_disagrees_with_the_launcher(tmp_path):
+    """the launcher's WORLD_SIZE is the truth: ``--gpus 8`` under a one-rank launcher environment reports n_gpus = 1 instead of dying on an assert
+    (round-4 verdict: the one 8-GPU slot must not be lost to a flag)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", ACT_GEMM_AUTOTUNE="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline",
+           "--no-instrument", "--no-other-workloads"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1" and "reporting n_gpus=1" in r.stderr
 
 
 # ---- the RCCL backend itself (backend "nccl" == RCCL on ROCm), world size 1 on the one GPU of the box --------------------------------

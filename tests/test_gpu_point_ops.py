@@ -43,6 +43,21 @@ def test_group_against_golden(dev):
     assert np.array_equal(big, g["fps_idx_big"])
 
 
+def test_knn_order_against_the_independent_pin(dev):
+    """the HIP kNN-group against g17: the reference's in-tree knn_point neighbour sets (models/dvae.py:120-152) ordered by float64-exact distance,
+    on the groups without a near-tie (245 of 256 at the configs[1] geometry, 323 of 512 at 4096 points / k = 64) -- a golden that contains none of
+    the builder's kNN code (tests/golden/make_golden_knn_order.py).  Bit-exact index sequences on every pinned group, equal sets on the rest."""
+    g = golden("g17_knn_order")
+    for tag in ("c2", "big"):
+        seed, B, N, G, k = (int(v) for v in g[f"{tag}_geometry"])
+        fidx, center, kidx, nbr, _ = _group_hip(clouds(seed, B, N), G, k, dev)
+        assert np.array_equal(fidx, g[f"{tag}_fps_idx"])
+        pinned, want = g[f"{tag}_pinned"], g[f"{tag}_order"].astype(np.int64)
+        assert pinned.sum() >= (245 if tag == "c2" else 323)
+        assert np.array_equal(kidx[pinned], want[pinned])
+        assert np.array_equal(np.sort(kidx[~pinned], -1), np.sort(want[~pinned], -1))
+
+
 @pytest.mark.parametrize("B,N,G,M", [(3, 64, 8, 4), (2, 100, 10, 7), (5, 256, 32, 16), (2, 777, 33, 32), (4, 1024, 64, 32),
                                      (2, 2048, 128, 32), (1, 3000, 50, 64), (2, 8192, 64, 64), (1, 20000, 16, 8)])
 def test_group_against_oracle(dev, oracle_c, B, N, G, M):

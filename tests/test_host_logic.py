@@ -1,5 +1,6 @@
 """CPU: host-side logic of the finetune / inference path that needs no GPU (config surface, registry, synthetic labelled
 dataset, accuracy metrics, FPS-pool table of tools/runner_finetune.py:141-150)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -273,3 +274,17 @@ def test_announced_batch_mark_is_per_model():
     a.add_(1.0)                                              # a new version of the tensor is a new batch
     assert not _Announced.is_marked(m1, a)
     assert "_act_announced" not in m1.state_dict()
+
+
+def test_bench_refuses_to_spawn_more_ranks_than_devices():
+    """``python bench.py --gpus 2`` with no launcher environment spawns its own ranks -- but only when the devices exist: on a box with fewer
+    GPUs it must say so at once instead of starting ranks that die one by one (here: 0 GPUs)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ACT_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=300)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two devices visible: the spawn would go ahead")
+    assert r.returncode != 0 and "--gpus 2 but" in r.stderr and "GPU(s) visible" in r.stderr

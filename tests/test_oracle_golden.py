@@ -45,6 +45,23 @@ def test_group_matches_golden_and_knn_point_sets():
     assert (nb[:, :, 0, :] == 0).all()
 
 
+def test_knn_order_against_the_independent_pin():
+    """g17 (tests/golden/make_golden_knn_order.py): neighbour ORDER from the reference's in-tree knn_point sets (models/dvae.py:120-152) sorted by
+    float64-exact distance, on the groups where no two consecutive distances are within fp32 rounding -- nothing of the builder's kNN went into
+    it.  The oracle's kNN (direct difference, ascending, lowest index on ties) must reproduce it exactly on every pinned group."""
+    g = golden("g17_knn_order")
+    for tag, min_pinned in (("c2", 0.9), ("big", 0.5)):
+        seed, B, N, G, k = (int(v) for v in g[f"{tag}_geometry"])
+        pts = clouds(seed, B, N)
+        nb, center, fidx, kidx = OP.group_ref(pts, G, k)
+        assert np.array_equal(fidx, g[f"{tag}_fps_idx"])
+        pinned = g[f"{tag}_pinned"]
+        assert pinned.mean() >= min_pinned, pinned.mean()
+        assert np.array_equal(kidx[pinned], g[f"{tag}_order"].astype(np.int64)[pinned])
+        # the unpinned groups (a near-tie): still the same SET as the reference's knn_point
+        assert np.array_equal(np.sort(kidx[~pinned], -1), np.sort(g[f"{tag}_order"].astype(np.int64)[~pinned], -1))
+
+
 def test_c_oracle_equals_numpy_oracle(oracle_c):
     pts = clouds(3, 3, 512)
     B, N, G, Mk = 3, 512, 32, 16
