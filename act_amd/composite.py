@@ -33,6 +33,10 @@ class BlockDims(ctypes.Structure):
     _fields_ = [("B", _i), ("S", _i), ("D", _i), ("heads", _i), ("hidden", _i), ("eps", _f)]
 
 
+class BlockStack(ctypes.Structure):
+    _fields_ = [("depth", _i), ("blocks", _vp), ("gate1", _vp), ("gate2", _vp)]
+
+
 class PrefixVit(ctypes.Structure):
     _fields_ = ([(n, _i) for n in ("B", "P", "G", "D", "heads", "hidden", "depth", "tokens_dims", "pos_hidden")] +
                 [("eps", _f), ("drop_p", _f), ("seed_base", _u64), ("seed_dev", _vp)] +
@@ -81,6 +85,11 @@ _SIGS = {
     "act_block_bwd_scratch_floats": [_P(BlockDims)],
     "act_block_fwd_f32": [_P(BlockDims), _P(BlockParams), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
     "act_block_bwd_f32": [_P(BlockDims), _P(BlockParams), _vp, _vp, _vp, _vp, _vp, _P(BlockParams), _vp, _vp, _sz, _vp, _sz, _vp, _vp],
+    "act_block_stack_saved_floats": [_P(BlockDims), _i, _i],
+    "act_block_stack_bwd_scratch_floats": [_P(BlockDims), _i],
+    "act_block_stack_fwd_f32": [_P(BlockDims), _P(BlockStack), _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_block_stack_bwd_f32": [_P(BlockDims), _P(BlockStack), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp],
+    "act_add_f32": [_vp, _vp, _vp, ctypes.c_longlong, _vp],
     "act_prefix_block_saved_floats": [_P(BlockDims), _i],
     "act_prefix_block_bwd_scratch_floats": [_P(BlockDims), _i],
     "act_prefix_block_fwd_f32": [_P(BlockDims), _i, _P(BlockParams), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
@@ -268,6 +277,143 @@ class BlockFn(torch.autograd.Function):
                 dw1, db1, dw2, db2, None, None, None)
 
 
+# ---- a stack of blocks: the loop of TransformerEncoder / TransformerDecoder in ONE host call per direction -------------------------------
+STACK = os.environ.get("ACT_BLOCK_STACK", "1") != "0"       # 0: one BlockFn per block (A/B measurements, bit-identity test)
+# blocks per host call (0 = the whole stack).  Under DDP a stack's parameter gradients become ready together, when its backward call returns:
+# chunks of 4 let the bucket all-reduces of the deeper blocks start while the shallower ones are still being differentiated.
+STACK_CHUNK = int(os.environ.get("ACT_BLOCK_STACK_CHUNK", "0"))
+_SDIMS = {}
+_NPB = 12                                                    # tensors per block, in BlockParams order
+
+
+def _stack_dims(B, S, D, heads, hidden, eps, depth):
+    key = (B, S, D, heads, hidden, float(eps), depth)
+    d = _SDIMS.get(key)
+    if d is None:
+        dims = BlockDims(B, S, D, heads, hidden, float(eps))
+        r = ctypes.byref(dims)
+        _SDIMS[key] = d = (dims, int(lib.act_block_stack_saved_floats(r, depth, 1)), int(lib.act_block_stack_saved_floats(r, depth, 0)),
+                           int(lib.act_block_stack_bwd_scratch_floats(r, depth)))
+    return d
+
+
+def _ptr_array(tensors, dev_index):
+    """(c_void_p * n) of the device addresses of contiguous CUDA tensors on the current device (None -> NULL): the lean form of _p for long lists"""
+    ptrs = []
+    for t in tensors:
+        if t is None:
+            ptrs.append(None)
+            continue
+        if not t.is_cuda or not t.is_contiguous() or t.device.index != dev_index:
+            raise _C.ActHipError("act_amd kernels need contiguous CUDA tensors on the current device (there is no CPU fallback)")
+        ptrs.append(t.data_ptr())
+    return (_vp * len(ptrs))(*ptrs)
+
+
+class BlockStackFn(torch.autograd.Function):
+    """x = blk_l(x + pos) for the blocks of a TransformerEncoder / TransformerDecoder (models/act.py:109-112,140-143) as ONE host call per
+    direction (act_block_stack_fwd_f32 / act_block_stack_bwd_f32): the same launches in the same order as ``depth`` BlockFn calls -- bit-identical,
+    gradient of ``pos`` included (accumulated in the order an autograd engine folds the per-block gradients) -- for 1/depth of the host work.
+    ``gates``: list of (gate_attn, gate_mlp) / None per block; ``params``: 12 tensors per block in BlockParams order (qkv bias may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, gates, heads, eps, train_w, *params):
+        B, S, D = x.shape
+        dev = x.device
+        depth = len(params) // _NPB
+        hidden = params[8].shape[0]
+        dims, n_keep, n_nokeep, _ = _stack_dims(B, S, D, heads, hidden, eps, depth)
+        _C._same_device(x)
+        x2d = K._f32c(x).reshape(B * S, D)
+        pos2d = K._f32c(pos).reshape(B * S, D) if pos is not None else None
+        need_grad = any(ctx.needs_input_grad)
+        parr = _ptr_array(params, dev.index)
+        g1 = g2 = None
+        gts = ()
+        if gates is not None and any(g is not None for g in gates):
+            gts = tuple(t for g in gates for t in (g if g is not None else (None, None)))
+            g1, g2 = _ptr_array(gts[0::2], dev.index), _ptr_array(gts[1::2], dev.index)
+        st = BlockStack(depth, ctypes.cast(parr, _vp), ctypes.cast(g1, _vp) if g1 is not None else None,
+                        ctypes.cast(g2, _vp) if g2 is not None else None)
+        saved = torch.empty(n_keep if need_grad else n_nokeep, dtype=torch.float32, device=dev)
+        out = torch.empty(B, S, D, dtype=torch.float32, device=dev)
+        ws = K.workspace(dev)
+        args = (ctypes.byref(dims), ctypes.byref(st), x2d.data_ptr(), pos2d.data_ptr() if pos2d is not None else None, int(need_grad),
+                saved.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
+        ensure_tuned(("stack_fwd", B, S, D, heads, hidden, depth), lambda: lib.act_block_stack_fwd_f32(*args, _C.stream()), dev)
+        check(lib.act_block_stack_fwd_f32(*args, _C.stream()), "act_block_stack_fwd_f32")
+        if need_grad:
+            ctx.save_for_backward(saved, *[t for t in params if t is not None], *[t for t in gts if t is not None])
+            ctx.keep = (parr, g1, g2, st, params, gts)      # pointer arrays of tensors that save_for_backward keeps alive (and version-checks)
+            ctx.dims = (B, S, D, heads, hidden, eps, depth)
+            ctx.has_pos = pos is not None
+            ctx.train_w = int(train_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors[0]                          # (also runs the in-place-modification check on every saved weight)
+        parr, g1, g2, st, params, gts = ctx.keep
+        B, S, D, heads, hidden, eps, depth = ctx.dims
+        dev = dout.device
+        dims, _, _, n_scratch = _stack_dims(B, S, D, heads, hidden, eps, depth)
+        dout = K._f32c(dout).reshape(B * S, D)
+        tw = ctx.train_w
+        dx = torch.empty(B, S, D, dtype=torch.float32, device=dev)
+        dpos = torch.empty(B, S, D, dtype=torch.float32, device=dev) if (ctx.has_pos and depth > 1) else None
+        scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
+        grads, garr = (None,) * len(params), None
+        if tw:
+            grads = tuple(torch.empty_like(t) if t is not None else None for t in params)
+            garr = _ptr_array(grads, dev.index)
+        ws = K.workspace(dev)
+        side, sws = None, None
+        if tw == 2 and K.OVERLAP_DW:
+            side = K.side_stream(dev, 1).cuda_stream
+            sws = _ws_of(dev, side)
+        args = (ctypes.byref(dims), ctypes.byref(st), saved.data_ptr(), dout.data_ptr(), dx.data_ptr(), dpos.data_ptr() if dpos is not None else None,
+                ctypes.cast(garr, _vp) if garr is not None else None, scratch.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                sws.data_ptr() if sws is not None else None, (sws.numel() * 4 if sws is not None else 0))
+        ensure_tuned(("stack_bwd", B, S, D, heads, hidden, depth, bool(tw)), lambda: lib.act_block_stack_bwd_f32(*args, _C.stream(), side), dev)
+        check(lib.act_block_stack_bwd_f32(*args, _C.stream(), side), "act_block_stack_bwd_f32")
+        return (dx, (dpos if dpos is not None else dx) if ctx.has_pos else None, None, None, None, None) + grads
+
+
+def _stack_leaves(blocks):
+    """(norm1, qkv, proj, norm2, fc1, fc2) modules of every block, cached on the ModuleList (attribute walks through nn.Module.__getattr__ are the
+    bulk of the host cost of collecting 12 x depth tensors per call)"""
+    cache = blocks.__dict__.get("_act_leaves")
+    if cache is None or len(cache) != len(blocks) or any(c[6] is not b for c, b in zip(cache, blocks)):
+        cache = [(b.norm1, b.attn.qkv, b.attn.proj, b.norm2, b.mlp.fc1, b.mlp.fc2, b) for b in blocks]
+        blocks.__dict__["_act_leaves"] = cache
+    return cache
+
+
+def block_stack(blocks, x, pos, gates, draws=None, tag="enc"):
+    """the loop ``for blk in blocks: x = blk(x + pos)`` -- one BlockStackFn per chunk of blocks when the composite path is on, else one
+    Block.forward per block (ACT_COMPOSITE=0 / ACT_BLOCK_STACK=0)."""
+    n = len(blocks)
+    if not (ENABLED and STACK) or n == 0 or any(type(b).forward is not type(blocks[0]).forward for b in blocks):
+        for i, blk in enumerate(blocks):
+            x = blk(x, pos, draws, f"{tag}.{i}", gates[i] if gates is not None else None)
+        return x
+    if draws is not None:                                    # injected DropPath draws (parity tests): the gates every Block.forward would compute
+        gates = [blk.gates(x.shape[0], x.device, draws, f"{tag}.{i}") for i, blk in enumerate(blocks)]
+        gates = [tuple(g) if g[0] is not None else None for g in gates]
+    leaves = _stack_leaves(blocks)
+    b0 = blocks[0]
+    heads, eps, tw = b0.attn.num_heads, b0.norm1.eps, (2 if b0.overlap_wgrad else 1)
+    chunk = STACK_CHUNK if STACK_CHUNK > 0 else n
+    for c0 in range(0, n, chunk):
+        params = []
+        for n1, qkv, proj, n2, fc1, fc2, _ in leaves[c0:c0 + chunk]:
+            p1, pq, pp, p2, pf1, pf2 = n1._parameters, qkv._parameters, proj._parameters, n2._parameters, fc1._parameters, fc2._parameters
+            params += [p1["weight"], p1["bias"], pq["weight"], pq["bias"], pp["weight"], pp["bias"], p2["weight"], p2["bias"],
+                       pf1["weight"], pf1["bias"], pf2["weight"], pf2["bias"]]
+        x = BlockStackFn.apply(x, pos, gates[c0:c0 + chunk] if gates is not None else None, heads, eps, tw, *params)
+    return x
+
+
 # ---- prefix block (prompts = keys / values only) ---------------------------------------------------------------------------
 _PDIMS = {}
 
@@ -343,37 +489,66 @@ def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj
 
 
 # ---- the frozen prompt-tuned Transformer of the teacher, whole stack --------------------------------------------------------
+def _vit_tensors(tok):
+    """every tensor the frozen prompt-tuned Transformer reads, in a fixed order: 10 stem tensors, 12 per block, 4 prompt tables.  The leaf MODULES are
+    cached on ``tok`` (attribute walks through nn.Module.__getattr__ cost more than the launches they feed); the tensors are read fresh each call."""
+    lv = tok.__dict__.get("_act_vit_leaves")
+    blocks = tok.visual_embed[0]
+    if lv is None or lv[0] is not blocks:
+        vp = tok.visual_pos_embed
+        lv = tok.__dict__["_act_vit_leaves"] = (blocks, vp[0], vp[2], tok.proj_pre, tok.proj_post, tok.visual_embed[1])
+    _, vp0, vp2, pre, post, nrm = lv
+    ts = []
+    for m in (vp0, vp2, pre, post, nrm):
+        pr = m._parameters
+        ts += [pr["weight"], pr["bias"]]
+    for n1, qkv, proj, n2, fc1, fc2, _ in _stack_leaves(blocks):
+        p1, pq, pp, p2, pf1, pf2 = n1._parameters, qkv._parameters, proj._parameters, n2._parameters, fc1._parameters, fc2._parameters
+        ts += [p1["weight"], p1["bias"], pq["weight"], pq["bias"], pp["weight"], pp["bias"], p2["weight"], p2["bias"],
+               pf1["weight"], pf1["bias"], pf2["weight"], pf2["bias"]]
+    tp = tok._parameters
+    ts += [tp["visual_prompt_token"], tp["visual_prompt_pos"], tp.get("deep_prompt_tokens"), tp.get("deep_prompt_pos")]
+    return ts, blocks
+
+
 def prefix_vit_forward(tok, tokens, center, drop_p, seed_base, seed_dev):
     """``tok`` = ACTPromptedDiscreteVAEwithVIT (frozen); tokens [B,G,tokens_dims], center [B,G,3] -> [B,G,tokens_dims].
-    visual_embedding_deep_prompt (models/dvae.py:536-576), inference form, in one host call (~125 launches)."""
+    visual_embedding_deep_prompt (models/dvae.py:536-576), inference form, in one host call (~125 launches).  The parameter struct (~190 device
+    pointers) is cached on ``tok`` and re-used as long as every tensor still sits at the same address (a ``.to()``, a re-assigned Parameter or a
+    changed batch geometry rebuilds it)."""
     B, G, td = tokens.shape
     dev = tokens.device
-    blocks = tok.visual_embed[0]
-    depth, Pn, D = tok.visual_embed_depth, tok.num_prompt_token, tok.visual_embed_dim
-    vp, nrm = tok.visual_pos_embed, tok.visual_embed[1]
-    b0 = blocks[0]
-    m = PrefixVit()
-    m.B, m.P, m.G, m.D, m.heads, m.hidden, m.depth, m.tokens_dims, m.pos_hidden = (B, Pn, G, D, b0.num_heads, b0.mlp.fc1.weight.shape[0], depth, td,
-                                                                                    vp[0].weight.shape[0])
-    m.eps, m.drop_p, m.seed_base, m.seed_dev = float(b0.eps), float(drop_p), int(seed_base) & (2 ** 64 - 1), _p(seed_dev)
-    m.pos_w0, m.pos_b0, m.pos_w1, m.pos_b1 = _p(vp[0].weight), _p(vp[0].bias), _p(vp[2].weight), _p(vp[2].bias)
-    m.pre_w, m.pre_b, m.post_w, m.post_b = _p(tok.proj_pre.weight), _p(tok.proj_pre.bias), _p(tok.proj_post.weight), _p(tok.proj_post.bias)
-    m.norm_w, m.norm_b = _p(nrm.weight), _p(nrm.bias)
-    toks = (_vp * depth)(*[_p(tok.visual_prompt_token[0] if i == 0 else tok.deep_prompt_tokens[i - 1]) for i in range(depth)])
-    poss = (_vp * depth)(*[_p(tok.visual_prompt_pos[0] if i == 0 else tok.deep_prompt_pos[i - 1]) for i in range(depth)])
-    blks = (BlockParams * depth)()
-    for i, blk in enumerate(blocks):
-        a, ml = blk.attn, blk.mlp
-        blks[i] = _block_params(blk.norm1.weight, blk.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, blk.norm2.weight,
-                                blk.norm2.bias, ml.fc1.weight, ml.fc1.bias, ml.fc2.weight, ml.fc2.bias)
-    m.prompt_tok, m.prompt_pos, m.blocks = toks, poss, blks
-    n_scratch = int(lib.act_prefix_vit_scratch_floats(ctypes.byref(m)))
+    ts, blocks = _vit_tensors(tok)
+    depth = tok.visual_embed_depth
+    sig = (B, G, td, dev.index, depth, tuple([t.data_ptr() if t is not None else 0 for t in ts]))
+    cache = tok.__dict__.get("_act_vit_struct")
+    if cache is None or cache[0] != sig:
+        Pn, D = tok.num_prompt_token, tok.visual_embed_dim
+        b0 = blocks[0]
+        if depth > 1 and (ts[-2] is None or ts[-1] is None):
+            raise _C.ActHipError("prefix_vit_forward: a depth > 1 prompt-tuned Transformer needs deep_prompt_tokens / deep_prompt_pos")
+        ptr = _ptr_array(ts, dev.index)                        # validates device / contiguity of every tensor
+        m = PrefixVit()
+        m.B, m.P, m.G, m.D, m.heads, m.hidden, m.depth, m.tokens_dims, m.pos_hidden = (B, Pn, G, D, b0.num_heads, ts[18].shape[0], depth, td,
+                                                                                        ts[0].shape[0])
+        m.eps = float(b0.eps)
+        (m.pos_w0, m.pos_b0, m.pos_w1, m.pos_b1, m.pre_w, m.pre_b, m.post_w, m.post_b, m.norm_w, m.norm_b) = [ptr[i] for i in range(10)]
+        row = Pn * D * 4                                              # prompt tables [1 | depth-1, Pn, D]: row i of the deep table = layer i + 1
+        nb = 10 + _NPB * depth
+        toks = (_vp * depth)(*[ptr[nb] if i == 0 else ptr[nb + 2] + (i - 1) * row for i in range(depth)])
+        poss = (_vp * depth)(*[ptr[nb + 1] if i == 0 else ptr[nb + 3] + (i - 1) * row for i in range(depth)])
+        blks = (_vp * (_NPB * depth))(*[ptr[10 + i] for i in range(_NPB * depth)])
+        m.prompt_tok, m.prompt_pos, m.blocks = toks, poss, ctypes.cast(blks, _P(BlockParams))
+        n_scratch = int(lib.act_prefix_vit_scratch_floats(ctypes.byref(m)))
+        cache = tok.__dict__["_act_vit_struct"] = (sig, m, n_scratch, (toks, poss, blks, ptr))
+    _, m, n_scratch, _ = cache
+    m.drop_p, m.seed_base, m.seed_dev = float(drop_p), int(seed_base) & (2 ** 64 - 1), _p(seed_dev)
     scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
     out = torch.empty(B, G, td, dtype=torch.float32, device=dev)
     ws = K.workspace(dev)
     tokens, center = K._f32c(tokens), K._f32c(center)
     args = (ctypes.byref(m), _p(tokens), _p(center), _p(out), _p(scratch), _p(ws), ws.numel() * 4)
-    ensure_tuned(("vit", B, Pn, G, D, m.heads, m.hidden, depth, td), lambda: lib.act_prefix_vit_fwd_f32(*args, _C.stream()), dev)
+    ensure_tuned(("vit", B, m.P, G, m.D, m.heads, m.hidden, depth, td), lambda: lib.act_prefix_vit_fwd_f32(*args, _C.stream()), dev)
     check(lib.act_prefix_vit_fwd_f32(*args, _C.stream()), "act_prefix_vit_fwd_f32")
     return out
 

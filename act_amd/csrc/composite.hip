@@ -293,6 +293,54 @@ int act_block_bwd_f32(const act_block_dims_t* d, const act_block_params_t* w, co
     return 0;
 }
 
+// ============================================================================================== a stack of blocks (TransformerEncoder / Decoder loop)
+static bool bad_stack(const act_block_dims_t* d, const act_block_stack_t* st) { return bad_dims(d) || !st || st->depth <= 0 || !st->blocks; }
+size_t act_block_stack_saved_floats(const act_block_dims_t* d, int depth, int keep_for_backward) {
+    if (bad_dims(d) || depth <= 0) return 0;
+    // per block the slab of act_block_fwd_f32 (ONE slab re-used by every block when nothing is kept) + two [T, D] buffers for the hidden state between blocks
+    return act_block_saved_floats(d) * (size_t)(keep_for_backward ? depth : 1) + 2 * (size_t)d->B * d->S * d->D;
+}
+size_t act_block_stack_bwd_scratch_floats(const act_block_dims_t* d, int depth) {
+    if (bad_dims(d) || depth <= 0) return 0;
+    return act_block_bwd_scratch_floats(d) + 2 * (size_t)d->B * d->S * d->D;
+}
+int act_block_stack_fwd_f32(const act_block_dims_t* d, const act_block_stack_t* st, const float* x, const float* pos, int keep_for_backward,
+                            float* saved, float* out, float* ws, size_t wsb, act_stream_t stream) {
+    if (!x || !saved || !out) return ACT_E_NULLPTR;
+    if (bad_stack(d, st)) return ACT_E_BADARG;
+    const size_t per = act_block_saved_floats(d), TD = (size_t)d->B * d->S * d->D;
+    const int L = st->depth;
+    float* hid[2] = {saved + per * (size_t)(keep_for_backward ? L : 1), saved + per * (size_t)(keep_for_backward ? L : 1) + TD};
+    const float* cur = x;
+    for (int l = 0; l < L; ++l) {
+        float* o = (l == L - 1) ? out : hid[l & 1];
+        CK(act_block_fwd_f32(d, &st->blocks[l], cur, pos, st->gate1 ? st->gate1[l] : nullptr, st->gate2 ? st->gate2[l] : nullptr, keep_for_backward,
+                             saved + (keep_for_backward ? per * (size_t)l : 0), o, ws, wsb, stream));
+        cur = o;
+    }
+    return 0;
+}
+int act_block_stack_bwd_f32(const act_block_dims_t* d, const act_block_stack_t* st, const float* saved, const float* dout, float* dx, float* dpos,
+                            const act_block_grads_t* grads, float* scratch, float* ws, size_t wsb, float* sws, size_t swsb, act_stream_t stream,
+                            act_stream_t side_stream) {
+    if (!saved || !dout || !dx || !scratch) return ACT_E_NULLPTR;
+    if (bad_stack(d, st)) return ACT_E_BADARG;
+    const size_t per = act_block_saved_floats(d), TD = (size_t)d->B * d->S * d->D;
+    const int L = st->depth;
+    float* blk_scratch = scratch;
+    float* hid[2] = {scratch + act_block_bwd_scratch_floats(d), scratch + act_block_bwd_scratch_floats(d) + TD};
+    const float* cur = dout;
+    for (int l = L - 1; l >= 0; --l) {
+        float* o = (l == 0) ? dx : hid[l & 1];
+        CK(act_block_bwd_f32(d, &st->blocks[l], st->gate1 ? st->gate1[l] : nullptr, st->gate2 ? st->gate2[l] : nullptr, saved + per * (size_t)l, cur, o,
+                             grads ? &grads[l] : nullptr, blk_scratch, ws, wsb, sws, swsb, stream, side_stream));
+        // gradient of the shared pos: ((dx_{L-1} + dx_{L-2}) + dx_{L-3}) + ... in the order the blocks finish (what an autograd engine's input buffer does)
+        if (dpos && L > 1 && l < L - 1) RUN(act_add_f32(l == L - 2 ? cur : dpos, o, dpos, (long long)TD, stream));
+        cur = o;
+    }
+    return 0;
+}
+
 // ============================================================================================== prefix block (prompts = keys / values only)
 size_t act_prefix_block_saved_floats(const act_block_dims_t* d, int P) {
     if (bad_dims(d) || P < 0) return 0;

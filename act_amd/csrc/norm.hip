@@ -607,3 +607,24 @@ extern "C" int act_scale_rows_f32(const float* x, const float* gate, int T, int 
     hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)g), dim3(256), 0, s, x, gate, total4, D / 4, rows_per_scale, y);
     ACT_LAUNCH_CHECK(); return 0;
 }
+
+// out = a + b (float4 stream): the accumulation of a gradient that several consumers of one tensor produce (act_block_stack_bwd_f32)
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long long total4, float* __restrict__ out) {
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 u = a4[i], v = b4[i];
+        o4[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    }
+}
+extern "C" int act_add_f32(const float* a, const float* b, float* out, long long n, act_stream_t stream) {
+    if (!a || !b || !out) return ACT_E_NULLPTR;
+    if (n < 0 || (n & 3) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15)) return ACT_E_BADARG;
+    if (n == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_ELTWISE, s, 0.0, 12.0 * (double)n);
+    long long g = (n / 4 + 255) / 256; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)g), dim3(256), 0, s, a, b, n / 4, out);
+    ACT_LAUNCH_CHECK(); return 0;
+}

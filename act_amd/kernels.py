@@ -1276,6 +1276,9 @@ def block_forward_prefix_perkernel(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, b
 # ---- the product forms of the block-level Functions live in act_amd.composite (one host call per module); resolved lazily so that
 # either module may be imported first.  ACT_COMPOSITE=0 selects the per-kernel host path above.
 def __getattr__(name):
+    if name == "block_stack":
+        from . import composite
+        return composite.block_stack
     if name in ("BlockFn", "PrefixBlockFn", "block_forward_prefix"):
         from . import composite
         if composite.ENABLED:

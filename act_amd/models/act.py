@@ -112,9 +112,7 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, x, pos, draws=None, tag="enc"):
         gates = stack_gates(self.blocks, x.shape[0], x.device, draws, self.__dict__.setdefault("_keep_cache", {}))
-        for i, block in enumerate(self.blocks):
-            x = block(x, pos, draws, f"{tag}.{i}", gates[i])
-        return x
+        return K.block_stack(self.blocks, x, pos, gates, draws, tag)           # every block in one host call per direction (composite.BlockStackFn)
 
 
 class TransformerDecoder(nn.Module):
@@ -141,8 +139,7 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, x, pos, return_token_num, draws=None, tag="dec"):
         gates = stack_gates(self.blocks, x.shape[0], x.device, draws, self.__dict__.setdefault("_keep_cache", {}))
-        for i, block in enumerate(self.blocks):
-            x = block(x, pos, draws, f"{tag}.{i}", gates[i])
+        x = K.block_stack(self.blocks, x, pos, gates, draws, tag)
         x = x[:, -return_token_num:].contiguous()          # only the mask tokens are predicted
         return K.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
 

@@ -24,7 +24,17 @@ def step(i):
     return train_step(w, opt, cur, cfg, next_points=nxt[0])
 for i in range(5): step(i)
 torch.cuda.synchronize()
-pr = cProfile.Profile(); pr.enable()
-for i in range(10): step(i)
-pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(32)
+IDLE = "--idle" in sys.argv          # every profiled step starts against an idle GPU: no back-pressure waits inside the numbers
+pr = cProfile.Profile()
+import time
+wall = 0.0
+for i in range(10):
+    if IDLE:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter(); pr.enable()
+    step(i)
+    pr.disable(); wall += time.perf_counter() - t0
+torch.cuda.synchronize()
+print(f"host wall per step ({'idle GPU' if IDLE else 'queued'}): {wall / 10 * 1e3:.2f} ms (with cProfile overhead)")
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(40)
+st.sort_stats("cumtime").print_stats(45)

@@ -388,6 +388,31 @@ int act_block_bwd_f32(const act_block_dims_t* d, const act_block_params_t* w, co
                       float* workspace, size_t workspace_bytes, float* side_workspace, size_t side_workspace_bytes,
                       act_stream_t stream, act_stream_t side_stream);
 
+/* A STACK of `depth` such blocks in one host call -- x = blk_l(x + pos) for l = 0 .. depth-1, the loop of TransformerEncoder.forward /
+ * TransformerDecoder.forward (models/act.py:109-112,140-143) -- and its backward.  Pure launch sequencing: the forward is depth calls of
+ * act_block_fwd_f32, the backward depth calls of act_block_bwd_f32 in reverse order plus, when dpos != NULL, depth-1 element-wise additions that
+ * accumulate the gradient of the shared `pos` input as ((dx_{depth-1} + dx_{depth-2}) + ...) + dx_0, the order in which an autograd engine
+ * folds the per-block gradients: results are bit-identical to the per-block calls (tests/test_gpu_composite.py).
+ * gate1 / gate2: arrays of depth pointers (entries nullable; a NULL array = no DropPath anywhere).
+ * saved: act_block_stack_saved_floats(d, depth, keep_for_backward) floats; scratch: act_block_stack_bwd_scratch_floats(d, depth).
+ * grads: array of depth structs (NULL = frozen stack, dX only).  dx = gradient of x; dpos (nullable) = gradient of pos, a separate buffer
+ * when depth > 1 (with depth == 1 it is not written: the gradient of pos IS dx). */
+typedef struct {
+    int depth;
+    const act_block_params_t* blocks;          /* [depth] */
+    const float* const* gate1;                 /* [depth] or NULL */
+    const float* const* gate2;                 /* [depth] or NULL */
+} act_block_stack_t;
+size_t act_block_stack_saved_floats(const act_block_dims_t* d, int depth, int keep_for_backward);
+size_t act_block_stack_bwd_scratch_floats(const act_block_dims_t* d, int depth);
+int act_block_stack_fwd_f32(const act_block_dims_t* d, const act_block_stack_t* st, const float* x, const float* pos, int keep_for_backward,
+                            float* saved, float* out, float* workspace, size_t workspace_bytes, act_stream_t stream);
+int act_block_stack_bwd_f32(const act_block_dims_t* d, const act_block_stack_t* st, const float* saved, const float* dout, float* dx, float* dpos,
+                            const act_block_grads_t* grads, float* scratch, float* workspace, size_t workspace_bytes, float* side_workspace,
+                            size_t side_workspace_bytes, act_stream_t stream, act_stream_t side_stream);
+/* out[i] = a[i] + b[i] (one rounding; out may alias a or b), n % 4 == 0, 16-byte aligned */
+int act_add_f32(const float* a, const float* b, float* out, long long n, act_stream_t stream);
+
 /* Block on G patch tokens per cloud with P prompt tokens acting as keys / values only (prompt-tuned frozen Transformer,
  * models/dvae.py:536-576: every layer replaces the prompt rows of its input and the output drops them).  dims: S = G.
  * x, pos [B*G, D]; prompt rows either prm [B*P, D] (= dropout(prompt) + prompt_pos, differentiable path) or n1p [B*P, D]

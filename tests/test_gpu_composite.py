@@ -49,6 +49,91 @@ def test_block_composite_is_bit_identical(dev, B, S, D, H, qkv_bias, train_w):
     assert res[0][1].abs().max() > 0
 
 
+@pytest.mark.parametrize("B,S,D,H,qkv_bias,train_w,depth,with_pos,with_gates", [
+    (4, 14, 384, 6, False, 2, 12, True, True),        # the student encoder of the benchmark (weight gradients on the auxiliary stream)
+    (4, 64, 384, 6, False, 1, 2, True, True),         # the decoder
+    (3, 33, 128, 2, True, 1, 5, True, False),
+    (2, 16, 64, 2, True, 1, 3, False, True),          # no position input: dpos is None
+    (2, 16, 64, 2, False, 0, 4, True, False),         # frozen stack: dX only
+    (2, 16, 64, 2, False, 1, 1, True, True),          # depth 1: the gradient of pos IS dx
+])
+def test_block_stack_is_bit_identical_to_a_chain_of_block_calls(dev, B, S, D, H, qkv_bias, train_w, depth, with_pos, with_gates):
+    """act_block_stack_fwd/bwd_f32 (composite.BlockStackFn: every block of a TransformerEncoder / Decoder in one host call per direction) against
+    ``depth`` BlockFn calls chained by autograd (models/act.py:109-112): output, gradient of x, the ACCUMULATED gradient of the shared pos (same
+    association order as the autograd engine's input buffer) and every parameter gradient, bit for bit."""
+    import act_amd.composite as CP
+    torch.manual_seed(0)
+    x0 = torch.randn(B, S, D, device=dev); pos0 = 0.1 * torch.randn(B, S, D, device=dev)
+    gates = [(torch.floor(0.8 + torch.rand(B, device=dev)) / 0.8, torch.floor(0.8 + torch.rand(B, device=dev)) / 0.8) if (with_gates and l % 2 == 1) else None
+             for l in range(depth)]
+    dout = torch.randn(B, S, D, device=dev)
+    res = []
+    for stacked in (False, True):
+        ps = [_params(dev, D, 4 * D, qkv_bias, 10 + l) for l in range(depth)]
+        if train_w == 0:
+            ps = [[p.detach() if p is not None else None for p in blk] for blk in ps]
+        x = x0.clone().requires_grad_(True)
+        pos = pos0.clone().requires_grad_(True) if with_pos else None
+        if stacked:
+            y = CP.BlockStackFn.apply(x, pos, gates, H, 1e-5, train_w, *[p for blk in ps for p in blk])
+        else:
+            y = x
+            for l in range(depth):
+                g1, g2 = gates[l] if gates[l] is not None else (None, None)
+                y = CP.BlockFn.apply(y, pos, g1, g2, *ps[l], H, 1e-5, train_w)
+        y.backward(dout)
+        torch.cuda.synchronize()
+        res.append([y.detach(), x.grad, pos.grad if with_pos else None] + [p.grad for blk in ps for p in blk if p is not None])
+    for i, (a, b) in enumerate(zip(*res)):
+        if a is None:
+            assert b is None, i
+            continue
+        assert torch.equal(a, b), i
+    assert res[0][1].abs().max() > 0
+    # inference form (no_grad: one saved slab re-used by every block)
+    with torch.no_grad():
+        ps = [[p.detach() if p is not None else None for p in _params(dev, D, 4 * D, qkv_bias, 10 + l)] for l in range(depth)]
+        yi = CP.BlockStackFn.apply(x0, pos0 if with_pos else None, gates, H, 1e-5, train_w, *[p for blk in ps for p in blk])
+    assert torch.equal(yi, res[0][0])
+
+
+def test_block_stack_training_trajectory_is_bit_identical(dev):
+    """the tiny Stage-II model trained for 3 AdamW steps with the stack-level host calls (default) and with one BlockFn per block (ACT_BLOCK_STACK=0
+    semantics), DropPath active, cross-step teacher prefetch on: losses and every parameter torch.equal; also in chunks of 2 blocks per call."""
+    import act_amd.composite as CP
+    from act_amd.models import build_model_from_cfg
+    from act_amd.tools import builder
+    from act_amd.tools.runner_pretrain import train_step, _Single, freeze_unused_heads
+    from act_amd.utils.config import EasyDict
+    from tests.golden.fill import fill_module, clouds, TINY_STAGE2, TINY_B, TINY_N
+    cfg = EasyDict(optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3, weight_decay=0.05)),
+                   scheduler=dict(type="CosLR", kwargs=dict(epochs=300, initial_epochs=10)), step_per_update=1)
+    batches = [torch.from_numpy(clouds(60 + i, TINY_B, TINY_N)).to(dev) for i in range(3)]
+    saved = (CP.STACK, CP.STACK_CHUNK)
+    results = []
+    try:
+        for stack, chunk in ((False, 0), (True, 0), (True, 2), (False, 0)):
+            CP.STACK, CP.STACK_CHUNK = stack, chunk
+            torch.manual_seed(0)
+            model = fill_module(build_model_from_cfg(EasyDict(copy.deepcopy(TINY_STAGE2))), "g4.").to(dev).train()
+            model.dvae_tokenizer.prompt_dropout.p = 0.0
+            freeze_unused_heads(model)
+            wrapped = _Single(model)
+            opt, _ = builder.build_opti_sche(wrapped, cfg)
+            torch.manual_seed(99)
+            pts = [b.clone() for b in batches]
+            losses = [train_step(wrapped, opt, pts[i], cfg, next_points=(pts[i + 1] if i + 1 < 3 else None)) for i in range(3)]
+            torch.cuda.synchronize()
+            results.append((torch.stack(losses).cpu(), {n: p.detach().clone().cpu() for n, p in model.named_parameters()}))
+    finally:
+        CP.STACK, CP.STACK_CHUNK = saved
+    ref = results[3]                                         # (the first run also pays the first-use GEMM tuning, which draws random numbers)
+    for got in results[1:3]:
+        assert torch.equal(ref[0], got[0]), (ref[0], got[0])
+        for n, p in ref[1].items():
+            assert torch.equal(p, got[1][n]), n
+
+
 def test_composite_shutdown_releases_the_fork_join_events(dev):
     """the library's only state are the fork / join events of streams that produced work for another stream: act_composite_shutdown destroys them,
     and a later call works (and gives the same bits) on fresh ones"""

@@ -288,3 +288,54 @@ def test_bench_refuses_to_spawn_more_ranks_than_devices():
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
         pytest.skip("two devices visible: the spawn would go ahead")
     assert r.returncode != 0 and "--gpus 2 but" in r.stderr and "GPU(s) visible" in r.stderr
+
+
+def test_fused_adamw_fast_path_equals_torch_adamw():
+    """builder.FusedAdamW: the cached-list step issues the same two native calls as torch.optim.AdamW(fused=True) -- parameters, moments and step
+    counters stay torch.equal over steps with a changing lr, a parameter that loses its gradient for one step (stock fallback), step hooks and a
+    state_dict round trip (tools/builder.py:38-55 builds these two groups)."""
+    import copy
+    from act_amd.tools.builder import FusedAdamW
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.LayerNorm(8), torch.nn.Linear(8, 3))
+    net_b = copy.deepcopy(net_a)
+
+    def groups(net):
+        nd = [p for p in net.parameters() if p.dim() == 1]; d = [p for p in net.parameters() if p.dim() > 1]
+        return [{'params': nd, 'weight_decay': 0.}, {'params': d, 'weight_decay': 0.05}]
+    oa = FusedAdamW(groups(net_a), lr=1e-3, weight_decay=0.05, fused=True)
+    ob = torch.optim.AdamW(groups(net_b), lr=1e-3, weight_decay=0.05, fused=True)
+    fired = []
+    oa.register_step_pre_hook(lambda *a: fired.append(1))
+    for i in range(6):
+        x = torch.randn(5, 6)
+        for net, o in ((net_a, oa), (net_b, ob)):
+            for g in o.param_groups:
+                g['lr'] = 1e-3 / (i + 1)
+            net(x).pow(2).sum().backward()
+            if i == 3:
+                net[2].bias.grad = None                  # a parameter without gradient: the stock step handles it
+            o.step(); o.zero_grad()
+        if i == 1:
+            assert set(oa._fast) == {0, 1}               # the cached lists are in use from the second step on
+        if i == 4:
+            oa.load_state_dict(copy.deepcopy(oa.state_dict()))
+    assert len(fired) == 6
+    assert all(p.grad is None for p in net_a.parameters())
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.equal(pa, pb)
+    sa, sb = oa.state_dict()['state'], ob.state_dict()['state']
+    for k in sb:
+        assert all(torch.equal(sa[k][n], sb[k][n]) for n in ('step', 'exp_avg', 'exp_avg_sq'))
+
+
+def test_announced_batch_marker_does_not_break_pickling():
+    """runner_pretrain._Announced keeps its weak reference OUTSIDE the module: a model that went through train_step bookkeeping pickles"""
+    import io
+    from act_amd.tools.runner_pretrain import _Announced
+    m = torch.nn.Linear(2, 2); t = torch.zeros(3)
+    _Announced.mark(m, t)
+    assert _Announced.is_marked(m, t)
+    t.add_(1)
+    assert not _Announced.is_marked(m, t)
+    torch.save(m, io.BytesIO())
