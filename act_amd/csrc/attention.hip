@@ -31,13 +31,21 @@ struct AttnFwdArgs {
 // JT = 32-key tiles per LDS-resident key chunk (Sk <= 128: one chunk; longer sequences: chunks of 128 keys with an online
 // softmax -- running max m and sum l per query; the rescale of the output accumulators is a per-lane scalar because every
 // accumulator register of a lane belongs to the same query).  QT = 32-query tiles per (cloud, head) handled by a workgroup.
-template <int HD, int JT, int QT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
+// VT (round 5, opt-in, measured slower -- see g_attn_vt): V is staged TRANSPOSED, Vt[d][key] with a row pitch of ROWS + 4 floats, so that the A operand of the second product -- V^T[d = lane][key(r)]
+// for the four consecutive keys of MFMA steps r = 4g .. 4g+3 -- is ONE ds_read_b128 per four MFMAs, exactly like the K fragments of the first product.
+// With V as [key][d] every MFMA step needed its own ds_read_b32, and the compiler emitted `ds_read2_b32; s_waitcnt lgkmcnt(0); 2 x v_mfma` sixteen times
+// per chunk: an exposed LDS round trip per 128 MFMA cycles.  The transpose costs nothing: a lane = one head-dimension column loads the four keys of a
+// quad with four coalesced dword loads (a wave reads a 256-byte row segment per instruction) and writes them with one conflict-free ds_write_b128.
+// Same products in the same order: bit-identical to VT = false (tests/test_gpu_dense.py).
+template <int HD, int JT, int QT, bool VT>
+__global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const AttnFwdArgs a) {
     constexpr int LDK = HD + 4;
     constexpr int PAIRS = (QT == 1) ? 4 : (QT == 2 ? 2 : 1);       // (cloud, head) pairs per workgroup
     constexpr int ROWS = JT * 32;
+    constexpr int LDT = ROWS + 4;                                   // Vt row pitch: 4 (mod 32) dwords -> conflict-free b128 reads / writes
+    constexpr int KSZ = ROWS * LDK, VSZ = VT ? HD * LDT : ROWS * LDK, PSZ = KSZ + VSZ;     // floats per pair: K image, V image
     static_assert((ROWS * (HD / 4)) % 256 == 0, "staging: whole iterations per pair");
-    extern __shared__ __attribute__((aligned(16))) float smem[];    // [PAIRS][2][ROWS][LDK]
+    extern __shared__ __attribute__((aligned(16))) float smem[];    // [PAIRS][K image | V image]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, Sk = a.S0 + a.S1;
     const long long npairs = (long long)a.B * H;
@@ -48,8 +56,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
     const long long pr = pair0 + pl;
     const bool active = pl < PAIRS && pr < npairs && qblock + qt * 32 < a.Sq;
     const int b = active ? (int)(pr / H) : 0, h = active ? (int)(pr % H) : 0;
-    const float* Ks = smem + (size_t)(pl * 2 + 0) * ROWS * LDK;
-    const float* Vs = smem + (size_t)(pl * 2 + 1) * ROWS * LDK;
+    const float* Ks = smem + (size_t)pl * PSZ;
+    const float* Vs = smem + (size_t)pl * PSZ + KSZ;
     const int ql = lane & 31, half = lane >> 5;
     const int q = qblock + qt * 32 + ql;
     const float scale = a.scale;
@@ -80,6 +88,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
     constexpr int ITS = ROWS * (HD / 4) / 256;
     constexpr bool PF = (JT <= 2 && QT >= 2);
     float4 kreg[PAIRS][ITS], vreg[PAIRS][ITS];
+    // VT: staging item idx = (key quad idx / HD, column idx % HD): the four keys kc + 4*quad + 0..3 of one column, zero beyond Sk.  The launcher takes
+    // this path only when S0 % ROWS == 0, so a chunk lies in ONE key segment: base pointer and row pitch are scalars, an address is one 32-bit offset;
+    // keys beyond Sk re-read the chunk's first row (always valid) and are zeroed afterwards -- no divergent control flow around the loads.
+    auto load_vt = [&](const float* v0p, const float* v1p, bool live, int kc, int idx) -> float4 {
+        const bool seg0 = kc < a.S0;
+        const float* vb = seg0 ? v0p : v1p;
+        const unsigned ld = seg0 ? a.ld0 : a.ld1;
+        const int r0 = seg0 ? kc : kc - a.S0;
+        const int d = idx % HD, q4 = 4 * (idx / HD);
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = kc + q4 + j < Sk;
+            t[j] = live ? vb[(unsigned)(r0 + (ok ? q4 + j : 0)) * ld + d] : 0.f;
+        }
+        return make_float4(t[0], t[1], t[2], t[3]);
+    };
+    // ... zeroed when the quad goes to LDS, not when it is requested (a select on the loaded value would put `s_waitcnt vmcnt(0)` right behind the
+    // prefetch of the NEXT chunk and serialise it with this chunk's products)
+    auto mask_vt = [&](float4 v, int kc, int idx) -> float4 {
+        const int k0 = kc + 4 * (idx / HD);
+        v.x = k0 + 0 < Sk ? v.x : 0.f; v.y = k0 + 1 < Sk ? v.y : 0.f; v.z = k0 + 2 < Sk ? v.z : 0.f; v.w = k0 + 3 < Sk ? v.w : 0.f;
+        return v;
+    };
+    auto v_lds_offset = [&](int idx) -> int {                        // where staging item idx of a pair goes inside the pair's V image
+        return VT ? (idx % HD) * LDT + 4 * (idx / HD) : (idx / (HD / 4)) * LDK + (idx % (HD / 4)) * 4;
+    };
     auto load_chunk = [&](int kc) {
 #pragma unroll
         for (int p2 = 0; p2 < PAIRS; ++p2) {
@@ -96,12 +131,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
                 if (live && row < Sk) {
                     if (row < a.S0) {
                         const unsigned of = (unsigned)row * a.ld0 + c4 * 4;
-                        kx = *reinterpret_cast<const float4*>(k0p + of); vx = *reinterpret_cast<const float4*>(v0p + of);
+                        kx = *reinterpret_cast<const float4*>(k0p + of); if (!VT) vx = *reinterpret_cast<const float4*>(v0p + of);
                     } else {
                         const unsigned of = (unsigned)(row - a.S0) * a.ld1 + c4 * 4;
-                        kx = *reinterpret_cast<const float4*>(k1p + of); vx = *reinterpret_cast<const float4*>(v1p + of);
+                        kx = *reinterpret_cast<const float4*>(k1p + of); if (!VT) vx = *reinterpret_cast<const float4*>(v1p + of);
                     }
                 }
+                if (VT) vx = load_vt(v0p, v1p, live, kc, idx);
                 kreg[p2][it] = kx; vreg[p2][it] = vx;
             }
         }
@@ -113,13 +149,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
             // ---- this chunk of K and V (zero rows beyond Sk) for every pair of the workgroup: registers -> LDS, then request the next chunk
 #pragma unroll
             for (int p2 = 0; p2 < PAIRS; ++p2) {
-                float* kd = smem + (size_t)(p2 * 2 + 0) * ROWS * LDK; float* vd = smem + (size_t)(p2 * 2 + 1) * ROWS * LDK;
+                float* kd = smem + (size_t)p2 * PSZ; float* vd = kd + KSZ;
 #pragma unroll
                 for (int it = 0; it < ITS; ++it) {
                     const int idx = tid + 256 * it;
                     const int c4 = idx % (HD / 4), rl = idx / (HD / 4);
                     *reinterpret_cast<float4*>(kd + rl * LDK + c4 * 4) = kreg[p2][it];
-                    *reinterpret_cast<float4*>(vd + rl * LDK + c4 * 4) = vreg[p2][it];
+                    *reinterpret_cast<float4*>(vd + v_lds_offset(idx)) = VT ? mask_vt(vreg[p2][it], kc, idx) : vreg[p2][it];
                 }
             }
             if (kc + ROWS < Sk) load_chunk(kc + ROWS);
@@ -134,7 +170,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
                 const unsigned b2 = live ? pr2 / (unsigned)H : 0u, h2 = live ? pr2 - b2 * (unsigned)H : 0u;
                 const float* k0p = a.k0 + (size_t)b2 * a.kv0_bs + h2 * HD; const float* v0p = a.v0 + (size_t)b2 * a.kv0_bs + h2 * HD;
                 const float* k1p = a.k1 + (size_t)b2 * a.kv1_bs + h2 * HD; const float* v1p = a.v1 + (size_t)b2 * a.kv1_bs + h2 * HD;
-                float* kd = smem + (size_t)(p2 * 2 + 0) * ROWS * LDK; float* vd = smem + (size_t)(p2 * 2 + 1) * ROWS * LDK;
+                float* kd = smem + (size_t)p2 * PSZ; float* vd = kd + KSZ;
     #pragma unroll
                 for (int it = 0; it < ROWS * (HD / 4) / 256; ++it) {
                     const int idx = tid + 256 * it;
@@ -143,14 +179,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
                     if (live && row < Sk) {
                         if (row < a.S0) {
                             const unsigned of = (unsigned)row * a.ld0 + c4 * 4;
-                            kx = *reinterpret_cast<const float4*>(k0p + of); vx = *reinterpret_cast<const float4*>(v0p + of);
+                            kx = *reinterpret_cast<const float4*>(k0p + of); if (!VT) vx = *reinterpret_cast<const float4*>(v0p + of);
                         } else {
                             const unsigned of = (unsigned)(row - a.S0) * a.ld1 + c4 * 4;
-                            kx = *reinterpret_cast<const float4*>(k1p + of); vx = *reinterpret_cast<const float4*>(v1p + of);
+                            kx = *reinterpret_cast<const float4*>(k1p + of); if (!VT) vx = *reinterpret_cast<const float4*>(v1p + of);
                         }
                     }
+                    if (VT) vx = mask_vt(load_vt(v0p, v1p, live, kc, idx), kc, idx);
                     *reinterpret_cast<float4*>(kd + rl * LDK + c4 * 4) = kx;
-                    *reinterpret_cast<float4*>(vd + rl * LDK + c4 * 4) = vx;
+                    *reinterpret_cast<float4*>(vd + v_lds_offset(idx)) = vx;
                 }
             }
         }
@@ -205,16 +242,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnFwdArgs a) {
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
         // ---- O^T += V^T P^T : o[dt][r] = out(d = dt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
+        if constexpr (VT) {
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
+            for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // this half-wave's k index for step r
-                const float* vp = Vs + (size_t)key * LDK + ql;
+                for (int g = 0; g < 4; ++g) {                                   // steps r = 4g .. 4g+3: keys jt*32 + 8g + 4*half + 0..3
+                    float4 vv[HD / 32];
 #pragma unroll
-                for (int dt = 0; dt < HD / 32; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], acc[jt][r], o[dt], 0, 0, 0);
-            }
+                    for (int dt = 0; dt < HD / 32; ++dt)
+                        vv[dt] = *reinterpret_cast<const float4*>(Vs + (size_t)(dt * 32 + ql) * LDT + jt * 32 + 8 * g + 4 * half);
+#pragma unroll
+                    for (int dt = 0; dt < HD / 32; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[dt].x, acc[jt][4 * g + 0], o[dt], 0, 0, 0);
+#pragma unroll
+                    for (int dt = 0; dt < HD / 32; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[dt].y, acc[jt][4 * g + 1], o[dt], 0, 0, 0);
+#pragma unroll
+                    for (int dt = 0; dt < HD / 32; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[dt].z, acc[jt][4 * g + 2], o[dt], 0, 0, 0);
+#pragma unroll
+                    for (int dt = 0; dt < HD / 32; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[dt].w, acc[jt][4 * g + 3], o[dt], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // this half-wave's k index for step r
+                    const float* vp = Vs + (size_t)key * LDK + ql;
+#pragma unroll
+                    for (int dt = 0; dt < HD / 32; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], acc[jt][r], o[dt], 0, 0, 0);
+                }
+        }
     }
     if (active && q < a.Sq) {
         const float inv_l = 1.0f / l;
@@ -1156,13 +1213,18 @@ static int launch_attn_bwd_mfma(const AttnBwdArgs& a, int head_dim, hipStream_t 
     return head_dim == 64 ? launch_attn_bwd_mfma_t<64>(a, s) : launch_attn_bwd_mfma_t<32>(a, s);
 }
 
+// dev A/B knob, default OFF: 1 = V staged transposed (kernel comment).  Measured 5-7 % SLOWER on every shape (teacher prefix 64 q x 128 k 45.1 -> 48.3 us,
+// S = 512 226 -> 238 us, profiles/r05_attn_vt_ab.txt): the four dword loads per quad cost more than the sixteen exposed ds_read_b32 round trips they remove --
+// three waves per SIMD already hide those.  Kept as a measured non-improvement; bit-identical either way.
+static const bool g_attn_vt = [] { const char* e = getenv("ACT_ATTN_VT"); return e && e[0] == '1'; }();
 template <int HD, int JT, int QT>
 static int launch_attn_fwd3(const AttnFwdArgs& a, hipStream_t s) {
     constexpr int pairs = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
-    const size_t smem = (size_t)pairs * 2 * JT * 32 * (HD + 4) * sizeof(float);
+    const bool vt = g_attn_vt && (a.S0 % (JT * 32)) == 0;              // a key chunk must not straddle the two key segments (kernel comment)
+    const size_t smem = (size_t)pairs * (JT * 32 * (HD + 4) + (vt ? HD * (JT * 32 + 4) : JT * 32 * (HD + 4))) * sizeof(float);
     const long long np = (long long)a.B * a.H;
     const unsigned gx = (unsigned)((np + pairs - 1) / pairs), gy = (unsigned)((a.Sq + QT * 32 - 1) / (QT * 32));
-    auto k = attn_fwd_kernel<HD, JT, QT>;
+    auto k = vt ? attn_fwd_kernel<HD, JT, QT, true> : attn_fwd_kernel<HD, JT, QT, false>;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;

@@ -221,7 +221,7 @@ _NEW_TUNED = {}
 if os.environ.get("ACT_GEMM_TUNE_SAVE"):
     import atexit as _atexit
 
-    def _dump_tuned(path=os.environ["ACT_GEMM_TUNE_SAVE"]):
+    def _dump_tuned(path=os.environ["ACT_GEMM_TUNE_SAVE"].replace("%p", str(os.getpid()))):      # "%p" -> pid: one file per process of a test session
         import json
         merged = dict(_GEMM_TABLE); merged.update(_NEW_TUNED)
         with open(path, "w") as f:
