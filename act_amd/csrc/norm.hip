@@ -6,6 +6,7 @@
 // One wave per row: a row of D=384/768 floats sits in registers (float4 per lane), statistics come from DPP
 // wave reductions, nothing is staged through LDS.  All kernels are HBM-bound: one read + one write per element.
 #include "common.h"
+#include <stdlib.h>
 
 #define LN_MAXV 8          // float4 per lane: D <= 64*4*8 = 2048
 
@@ -407,7 +408,13 @@ extern "C" int act_prompt_rows_bwd_f32(const float* dy, const float* mask, int B
     ACT_LAUNCH_CHECK(); return 0;
 }
 
-static int ln_rows_per_block(int T) { int r = (T + 1023) / 1024; r = (r + 3) / 4 * 4; return r < 16 ? 16 : r; }
+// rows per 4-wave workgroup of the LayerNorm backward (a wave walks its rows one after the other: every row is a load -> reduce -> store round trip of
+// ~2 us, so 16 rows per workgroup made the 1,792-row launches of the student a 4-round-trip chain on 112 of 256 CUs).  ACT_LN_BWD_RPB overrides (A/B).
+static int ln_rows_per_block(int T) {
+    static const int env = [] { const char* e = getenv("ACT_LN_BWD_RPB"); return e ? atoi(e) : 0; }();
+    const int floor_ = env >= 4 ? (env + 3) / 4 * 4 : 16;
+    int r = (T + 1023) / 1024; r = (r + 3) / 4 * 4; return r < floor_ ? floor_ : r;
+}
 extern "C" size_t act_layernorm_bwd_workspace(int T, int D) {
     const int rpb = ln_rows_per_block(T); const int nblk = (T + rpb - 1) / rpb;
     return (size_t)nblk * D * 2 * sizeof(float);
