@@ -1,5 +1,5 @@
 # per-round evidence (RND=rNN, default r05): bench lines of every workload + rocprofv3 kernel stats, per-workload PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and
-# MfmaUtil.  usage: ${RND}_profiles.sh <tag> <bench args...>   e.g.  ${RND}_profiles.sh c2 ; ${RND}_profiles.sh s1 --stage 1 ; ${RND}_profiles.sh c5 --config c5
+# MfmaUtil.  usage: [RND=r05] profiles.sh <tag> <bench args...>   e.g.  profiles.sh c2 ; profiles.sh s1 --stage 1 ; profiles.sh c5 --config c5
 set -x
 RND=${RND:-r05}
 R=$GRAFT_REPO_ROOT; TAG=$1; shift; ARGS="$@"
