@@ -12,6 +12,7 @@ depend on the call history.
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -379,13 +380,19 @@ class BlockStackFn(torch.autograd.Function):
         return (dx, (dpos if dpos is not None else dx) if ctx.has_pos else None, None, None, None, None) + grads
 
 
+# host-side caches keyed by module, kept OUTSIDE the modules (weak keys): nothing un-picklable (ctypes structs) or stale is ever attached to a model that
+# the user may deepcopy / torch.save / hand to mp.spawn
+_LEAVES = weakref.WeakKeyDictionary()          # ModuleList of blocks -> [(norm1, qkv, proj, norm2, fc1, fc2, block)]
+_VIT_LEAVES = weakref.WeakKeyDictionary()      # tokenizer -> (blocks, pos0, pos2, proj_pre, proj_post, norm)
+_VIT_STRUCT = weakref.WeakKeyDictionary()      # tokenizer -> (signature, PrefixVit, scratch floats, keep-alive ctypes arrays)
+
+
 def _stack_leaves(blocks):
-    """(norm1, qkv, proj, norm2, fc1, fc2) modules of every block, cached on the ModuleList (attribute walks through nn.Module.__getattr__ are the
-    bulk of the host cost of collecting 12 x depth tensors per call)"""
-    cache = blocks.__dict__.get("_act_leaves")
+    """(norm1, qkv, proj, norm2, fc1, fc2) modules of every block, cached per ModuleList (attribute walks through nn.Module.__getattr__ are the
+    bulk of the host cost of collecting 12 x depth tensors per call); rebuilt when a block of the list was replaced"""
+    cache = _LEAVES.get(blocks)
     if cache is None or len(cache) != len(blocks) or any(c[6] is not b for c, b in zip(cache, blocks)):
-        cache = [(b.norm1, b.attn.qkv, b.attn.proj, b.norm2, b.mlp.fc1, b.mlp.fc2, b) for b in blocks]
-        blocks.__dict__["_act_leaves"] = cache
+        cache = _LEAVES[blocks] = [(b.norm1, b.attn.qkv, b.attn.proj, b.norm2, b.mlp.fc1, b.mlp.fc2, b) for b in blocks]
     return cache
 
 
@@ -491,12 +498,12 @@ def block_forward_prefix(x2d, pos2d, prm2d, B, P, G, n1w, n1b, wqkv, bqkv, wproj
 # ---- the frozen prompt-tuned Transformer of the teacher, whole stack --------------------------------------------------------
 def _vit_tensors(tok):
     """every tensor the frozen prompt-tuned Transformer reads, in a fixed order: 10 stem tensors, 12 per block, 4 prompt tables.  The leaf MODULES are
-    cached on ``tok`` (attribute walks through nn.Module.__getattr__ cost more than the launches they feed); the tensors are read fresh each call."""
-    lv = tok.__dict__.get("_act_vit_leaves")
+    cached per ``tok`` (attribute walks through nn.Module.__getattr__ cost more than the launches they feed); the tensors are read fresh each call."""
+    lv = _VIT_LEAVES.get(tok)
     blocks = tok.visual_embed[0]
     if lv is None or lv[0] is not blocks:
         vp = tok.visual_pos_embed
-        lv = tok.__dict__["_act_vit_leaves"] = (blocks, vp[0], vp[2], tok.proj_pre, tok.proj_post, tok.visual_embed[1])
+        lv = _VIT_LEAVES[tok] = (blocks, vp[0], vp[2], tok.proj_pre, tok.proj_post, tok.visual_embed[1])
     _, vp0, vp2, pre, post, nrm = lv
     ts = []
     for m in (vp0, vp2, pre, post, nrm):
@@ -514,14 +521,14 @@ def _vit_tensors(tok):
 def prefix_vit_forward(tok, tokens, center, drop_p, seed_base, seed_dev):
     """``tok`` = ACTPromptedDiscreteVAEwithVIT (frozen); tokens [B,G,tokens_dims], center [B,G,3] -> [B,G,tokens_dims].
     visual_embedding_deep_prompt (models/dvae.py:536-576), inference form, in one host call (~125 launches).  The parameter struct (~190 device
-    pointers) is cached on ``tok`` and re-used as long as every tensor still sits at the same address (a ``.to()``, a re-assigned Parameter or a
+    pointers) is cached per ``tok`` (module-level weak dictionary) and re-used as long as every tensor still sits at the same address (a ``.to()``, a re-assigned Parameter or a
     changed batch geometry rebuilds it)."""
     B, G, td = tokens.shape
     dev = tokens.device
     ts, blocks = _vit_tensors(tok)
     depth = tok.visual_embed_depth
     sig = (B, G, td, dev.index, depth, tuple([t.data_ptr() if t is not None else 0 for t in ts]))
-    cache = tok.__dict__.get("_act_vit_struct")
+    cache = _VIT_STRUCT.get(tok)
     if cache is None or cache[0] != sig:
         Pn, D = tok.num_prompt_token, tok.visual_embed_dim
         b0 = blocks[0]
@@ -540,7 +547,7 @@ def prefix_vit_forward(tok, tokens, center, drop_p, seed_base, seed_dev):
         blks = (_vp * (_NPB * depth))(*[ptr[10 + i] for i in range(_NPB * depth)])
         m.prompt_tok, m.prompt_pos, m.blocks = toks, poss, ctypes.cast(blks, _P(BlockParams))
         n_scratch = int(lib.act_prefix_vit_scratch_floats(ctypes.byref(m)))
-        cache = tok.__dict__["_act_vit_struct"] = (sig, m, n_scratch, (toks, poss, blks, ptr))
+        cache = _VIT_STRUCT[tok] = (sig, m, n_scratch, (toks, poss, blks, ptr))
     _, m, n_scratch, _ = cache
     m.drop_p, m.seed_base, m.seed_dev = float(drop_p), int(seed_base) & (2 ** 64 - 1), _p(seed_dev)
     scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)

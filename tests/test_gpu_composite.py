@@ -134,6 +134,46 @@ def test_block_stack_training_trajectory_is_bit_identical(dev):
             assert torch.equal(p, got[1][n]), n
 
 
+def test_host_caches_survive_deepcopy_and_follow_the_parameters(dev):
+    """the host-side caches of the composite path (leaf-module lists, the teacher's ~190-pointer ctypes struct) live in weak dictionaries OUTSIDE the
+    modules: a model that has run can still be deep-copied and pickled, the copy computes with ITS OWN parameters (perturbing them changes its loss, not the
+    original's), and a parameter that moves to a new address (re-assigned storage) is picked up on the next call."""
+    import io
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import EasyDict
+    from tests.golden.fill import fill_module, clouds, TINY_STAGE2, TINY_B, TINY_N
+    torch.manual_seed(0)
+    model = fill_module(build_model_from_cfg(EasyDict(copy.deepcopy(TINY_STAGE2))), "g4.").to(dev).train()
+    model.dvae_tokenizer.prompt_dropout.p = 0.0
+    pts = torch.from_numpy(clouds(70, TINY_B, TINY_N)).to(dev)
+
+    def loss_of(m):
+        torch.manual_seed(5)
+        with torch.no_grad():
+            return m(pts.clone()).item()
+    loss_of(model)                                                # warm-up: first-use GEMM tuning of an unlisted shape draws random operands
+    torch.manual_seed(5)
+    model(pts.clone()).backward()                                 # the training path too (stack backward, saved pointer arrays)
+    model.zero_grad(set_to_none=True)
+    base = loss_of(model)
+    assert loss_of(model) == base
+    twin = copy.deepcopy(model)
+    torch.save(model, io.BytesIO())
+    assert loss_of(twin) == base
+    with torch.no_grad():
+        twin.dvae_tokenizer.visual_embed[0][0].mlp.fc1.weight.mul_(1.7)       # frozen teacher: read through the cached struct
+    assert loss_of(twin) != base and loss_of(model) == base
+    twin2 = copy.deepcopy(model)
+    with torch.no_grad():
+        twin2.ACT_encoder.blocks.blocks[0].mlp.fc1.weight.mul_(1.7)           # student stack: read through the cached leaf list
+    assert loss_of(twin2) != base and loss_of(model) == base
+    # a parameter whose storage is re-assigned (what module.to() / .float() do to param.data): new address, same values -> same loss, no stale pointer
+    w = model.dvae_tokenizer.visual_embed[0][1].attn.qkv.weight
+    old_ptr = w.data_ptr()
+    w.data = w.data.clone()
+    assert w.data_ptr() != old_ptr and loss_of(model) == base
+
+
 def test_composite_shutdown_releases_the_fork_join_events(dev):
     """the library's only state are the fork / join events of streams that produced work for another stream: act_composite_shutdown destroys them,
     and a later call works (and gives the same bits) on fresh ones"""
