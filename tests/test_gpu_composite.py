@@ -147,10 +147,16 @@ def test_host_caches_survive_deepcopy_and_follow_the_parameters(dev):
     model.dvae_tokenizer.prompt_dropout.p = 0.0
     pts = torch.from_numpy(clouds(70, TINY_B, TINY_N)).to(dev)
 
-    def loss_of(m):
+    from act_amd.utils.draws import Draws
+    from act_amd.models.act import random_mask
+    torch.manual_seed(3)
+    mask = random_mask(TINY_B, 16, 12, dev).cpu()
+    gumbel = -torch.empty(TINY_B, 16, 64).exponential_().log()
+
+    def loss_of(m):                                               # every draw pinned: mask + teacher gumbel noise injected, DropPath gates from the seeded RNG
         torch.manual_seed(5)
         with torch.no_grad():
-            return m(pts.clone()).item()
+            return m(pts.clone(), draws=Draws({"mask": mask, "gumbel": gumbel}, device=dev)).item()
     loss_of(model)                                                # warm-up: first-use GEMM tuning of an unlisted shape draws random operands
     torch.manual_seed(5)
     model(pts.clone()).backward()                                 # the training path too (stack backward, saved pointer arrays)
