@@ -160,13 +160,20 @@ __global__ __launch_bounds__(256) void colsum_stage2_pair(const float* __restric
     float* __restrict__ out = blockIdx.y ? out1 : out0;
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
-    float a0 = 0.f, a1 = 0.f;
+    // eight loads in flight per thread (round 5: the fold of the student's 112 LayerNorm partial rows was a chain of 14 dependent L2 round trips, 8 us per
+    // launch, 30 launches per Stage-II step); fixed order -> deterministic
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
     if (c < C) {
+        const float* __restrict__ q = partial + c;
         int p = ry;
-        for (; p + 4 < nparts; p += 8) { a0 += partial[(size_t)p * C + c]; a1 += partial[(size_t)(p + 4) * C + c]; }
-        for (; p < nparts; p += 4) a0 += partial[(size_t)p * C + c];
+        for (; p + 28 < nparts; p += 32) {
+            a0 += q[(size_t)p * C];        a1 += q[(size_t)(p + 4) * C];  a2 += q[(size_t)(p + 8) * C];  a3 += q[(size_t)(p + 12) * C];
+            a4 += q[(size_t)(p + 16) * C]; a5 += q[(size_t)(p + 20) * C]; a6 += q[(size_t)(p + 24) * C]; a7 += q[(size_t)(p + 28) * C];
+        }
+        for (; p + 4 < nparts; p += 8) { a0 += q[(size_t)p * C]; a1 += q[(size_t)(p + 4) * C]; }
+        for (; p < nparts; p += 4) a0 += q[(size_t)p * C];
     }
-    sh[ry][cx] = a0 + a1;
+    sh[ry][cx] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
     __syncthreads();
     if (ry == 0 && c < C) {
         const float acc = (sh[0][cx] + sh[1][cx]) + (sh[2][cx] + sh[3][cx]);
