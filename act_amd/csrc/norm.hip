@@ -66,7 +66,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // dx = dres + rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) ; per-block partial dgamma/dbeta
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xin,
+// NW waves per workgroup, one row per wave and pass: with the 16-row workgroups of the small launches (T <= 16K rows) NW = 16 gives every row its own wave --
+// the 4-wave form walked four rows one after the other, each a load -> two wave reductions -> store round trip (round 5)
+// MAXV = float4 per lane and row (D <= 256 * MAXV): a template parameter so that the 1,024-thread form keeps its row in 128 registers
+template <int NW, int MAXV>
+__global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xin,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ dres,
                                                             float* __restrict__ dx, float* __restrict__ part_dg,
@@ -74,19 +78,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
     const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gamma);
-    float4 ag[LN_MAXV], ab[LN_MAXV];                   // this lane's dgamma / dbeta accumulators
+    float4 ag[MAXV], ab[MAXV];                   // this lane's dgamma / dbeta accumulators
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
+    for (int i = 0; i < MAXV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(T, r0 + rows_per_block);
-    for (int row = r0 + wave; row < r1; row += 4) {
+    for (int row = r0 + wave; row < r1; row += NW) {
         const float4* __restrict__ dyr = reinterpret_cast<const float4*>(dy + (size_t)row * D);
         const float4* __restrict__ xr = reinterpret_cast<const float4*>(xin + (size_t)row * D);
         const float mu = mean[row], rs = rstd[row];
-        float4 h[LN_MAXV], w[LN_MAXV];
+        float4 h[MAXV], w[MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
                 const float4 d = dyr[c], x = xr[c], g = g4[c];
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         float4* __restrict__ dxr = reinterpret_cast<float4*>(dx + (size_t)row * D);
         const float4* __restrict__ drr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * D) : nullptr;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
                 float4 o;
@@ -114,18 +118,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
-    // combine the 4 waves' partials in LDS (fixed order) -> one partial row per workgroup: [gridDim.x][D]
+    // combine the NW waves' partials in LDS (fixed order: groups of four, then ascending) -> one partial row per workgroup: [gridDim.x][D]
     if (part_dg) {
-        extern __shared__ __attribute__((aligned(16))) float sacc[];      // [2][4][D]
+        extern __shared__ __attribute__((aligned(16))) float sacc[];      // [2][NW][D]
         float4* sg = reinterpret_cast<float4*>(sacc) + (size_t)wave * nv;
-        float4* sb = reinterpret_cast<float4*>(sacc) + (size_t)(4 + wave) * nv;
+        float4* sb = reinterpret_cast<float4*>(sacc) + (size_t)(NW + wave) * nv;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) { const int c = lane + 64 * i; if (c < nv) { sg[c] = ag[i]; sb[c] = ab[i]; } }
+        for (int i = 0; i < MAXV; ++i) { const int c = lane + 64 * i; if (c < nv) { sg[c] = ag[i]; sb[c] = ab[i]; } }
         __syncthreads();
-        const float* fg = sacc; const float* fb = sacc + (size_t)4 * D;
-        for (int c = threadIdx.x; c < D; c += 256) {
-            part_dg[(size_t)blockIdx.x * D + c] = (fg[c] + fg[D + c]) + (fg[2 * D + c] + fg[3 * D + c]);
-            part_db[(size_t)blockIdx.x * D + c] = (fb[c] + fb[D + c]) + (fb[2 * D + c] + fb[3 * D + c]);
+        const float* fg = sacc; const float* fb = sacc + (size_t)NW * D;
+        for (int c = threadIdx.x; c < D; c += 64 * NW) {
+            float tg = 0.f, tb = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w += 4) {
+                const float qg = (fg[(size_t)w * D + c] + fg[(size_t)(w + 1) * D + c]) + (fg[(size_t)(w + 2) * D + c] + fg[(size_t)(w + 3) * D + c]);
+                const float qb = (fb[(size_t)w * D + c] + fb[(size_t)(w + 1) * D + c]) + (fb[(size_t)(w + 2) * D + c] + fb[(size_t)(w + 3) * D + c]);
+                tg = w ? tg + qg : qg; tb = w ? tb + qb : qb;
+            }
+            part_dg[(size_t)blockIdx.x * D + c] = tg;
+            part_db[(size_t)blockIdx.x * D + c] = tb;
         }
     }
 }
@@ -440,7 +451,20 @@ extern "C" int act_layernorm_bwd_f32(const float* dy, const float* xin, const fl
     ActProfScope ps(KID_LAYERNORM_BWD, s, 0.0, 4.0 * T * (double)D * (3 + (dres ? 1 : 0)));
     float* pg = params ? workspace : nullptr;
     float* pb = params ? workspace + (size_t)nblk * D : nullptr;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), params ? (size_t)8 * D * sizeof(float) : 0, s, dy, xin, gamma, mean, rstd, dres, dx, pg, pb, T, D, rpb);
+    // waves per workgroup: 4.  ACT_LN_BWD_WAVES = 8 / 16 (A/B): one row per wave shortens the kernel (Stage II: 0.54 -> 0.40 ms per step with the streams
+    // serialised) but the overlapped step does not move (26.19 / 26.21 vs 26.09 / 26.16 ms): a 1,024-thread workgroup needs a CU's wave slots all at once
+    // and queues behind the teacher's GEMM workgroups of the other stream.
+    static const int nw_env = [] { const char* e = getenv("ACT_LN_BWD_WAVES"); return e ? atoi(e) : 0; }();
+    int nw = 4;
+    if (nw_env == 4 || nw_env == 8 || nw_env == 16) nw = nw_env;
+    if (nw > rpb) nw = rpb >= 8 ? 8 : 4;
+    if (D > 1024) nw = 4; else if (D > 512 && nw > 8) nw = 8;
+    const size_t lds = params ? (size_t)2 * nw * D * sizeof(float) : 0;
+#define LNB(NW_, MV_) hipLaunchKernelGGL((layernorm_bwd_kernel<NW_, MV_>), dim3(nblk), dim3(64 * NW_), lds, s, dy, xin, gamma, mean, rstd, dres, dx, pg, pb, T, D, rpb)
+    if (D <= 512)       { if (nw == 16) LNB(16, 2); else if (nw == 8) LNB(8, 2); else LNB(4, 2); }
+    else if (D <= 1024) { if (nw == 8) LNB(8, 4); else LNB(4, 4); }
+    else                LNB(4, 8);
+#undef LNB
     ACT_LAUNCH_CHECK();
     if (params) {
         hipLaunchKernelGGL(colsum_stage2_pair, dim3((D + 63) / 64, 2), dim3(256), 0, s, pg, pb, nblk, D, dgamma, dbeta, accumulate_params);
