@@ -691,7 +691,9 @@ def pairwise_distill_loss(student, teacher, kind, num_mask, temperature=0.07, la
     restates them the same way; parity against the package itself is unpinned).  Not in any shipped recipe, so not a tuned path: the matrix products run
     on the library's GEMMs through K.linear (forward and both gradients), the row-wise pieces are a handful of elementwise / reduction ops.
       ntxent: the 2n x 2n similarity blocks of 16 clouds at a time are the diagonal blocks of ONE [16 * 2n, C] x [16 * 2n, C]^T product.
-      barlow: one [D, n] x [D, n]^T product per cloud."""
+      barlow: one [D, n] x [D, n]^T product per cloud -- O(B) launches plus a transposed copy per cloud (there is no batched GEMM entry point in the
+      library; acceptable for a loss that no shipped recipe selects, a cost to know about before selecting it at B = 128).
+    Returns a 0-dim tensor like every other loss of this module (the reference's ``loss.mean() / batch_size``)."""
     B, n, C = student.shape
     s = _f32c(student); t = _f32c(teacher)
     if kind == "ntxent":
