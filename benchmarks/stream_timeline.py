@@ -20,6 +20,8 @@ for n in ("ACT", "Transformer"):
 import bench
 
 cfg = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml"); cfg.model.dvae_config.ckpt = "none"
+if os.environ.get("DEPTH"):                                 # what-if: a shallower student (how much of the step do its small kernels really cost?)
+    cfg.model.transformer_config.depth = int(os.environ["DEPTH"])
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = build_model_from_cfg(cfg.model); freeze_unused_heads(model); model.to(dev).train()
