@@ -410,6 +410,10 @@ def block_stack(blocks, x, pos, gates, draws=None, tag="enc"):
     leaves = _stack_leaves(blocks)
     b0 = blocks[0]
     heads, eps, tw = b0.attn.num_heads, b0.norm1.eps, (2 if b0.overlap_wgrad else 1)
+    if any(l[6].attn.num_heads != heads or l[0].eps != eps or l[3].eps != eps or bool(l[6].overlap_wgrad) != bool(b0.overlap_wgrad) for l in leaves[1:]):
+        for i, blk in enumerate(blocks):                     # blocks that differ in more than their weights: one call each
+            x = blk(x, pos, None, f"{tag}.{i}", gates[i] if gates is not None else None)
+        return x
     chunk = STACK_CHUNK if STACK_CHUNK > 0 else n
     for c0 in range(0, n, chunk):
         params = []
