@@ -9,6 +9,7 @@ Differences forced by the hardware-first design, none of them visible in the con
   * the logged loss is all-reduced every step but read back only every ``log_every`` steps.
 """
 import time
+import os
 import weakref
 
 import torch
@@ -46,6 +47,11 @@ def freeze_unused_heads(model):
 
 def wrap_ddp(base_model, args):
     device_ids = [args.local_rank % torch.cuda.device_count()] if torch.cuda.is_available() and args.use_gpu else None
+    if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1 and "ACT_BLOCK_STACK_CHUNK" not in os.environ:
+        # a block stack hands its parameter gradients to DDP when its backward call returns: in chunks of 4 blocks the bucket all-reduces of the
+        # deeper blocks start while the shallower ones are still being differentiated (bit-identical to any other chunking, tests/test_gpu_composite.py)
+        from act_amd import composite
+        composite.STACK_CHUNK = 4
     return nn.parallel.DistributedDataParallel(base_model, device_ids=device_ids, broadcast_buffers=False,
                                                gradient_as_bucket_view=True, bucket_cap_mb=25)
 
