@@ -1,0 +1,204 @@
+// bf16x3_planes.hip -- NT GEMM on the bf16 matrix cores with operands PRE-SPLIT into TWO bf16 planes (x ~ h + l, 16 significand bits) and THREE products
+// h*h + h*l + l*h per tile (the l*l term, 2^-16 relative, is dropped): gate 1 of the split-bf16 teacher question (round-4 review item 9: >= 160 TFLOP/s-equivalent
+// on 8192 x 3072 x 768 before any product code).  Derived from bf16x6_planes.hip (three planes, six products); same staging, same fragment layout.
+// (original header follows)
+// bf16x6_planes.hip -- fp32-accurate NT GEMM on the bf16 matrix cores with PRE-SPLIT operands.
+// Operands arrive as three bf16 planes [3][rows][K] (x = h + m + l exactly, produced once per tensor by split3_kernel / by the
+// producing kernel's epilogue), so the GEMM main loop is copy-only staging + ds_read_b128 fragments + six v_mfma_f32_16x16x32_bf16
+// per (16x16 tile, 32-deep k-step).
+// build: hipcc --offload-arch=gfx950 -O3 -o bf16x3_planes bf16x3_planes.hip ; run: ./bf16x3_planes [M N K]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+// fp32 [rows][K] -> planes [3][rows][K] bf16, 4 elements per thread
+__global__ void split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, long long n4, long long plane_elems) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = bf16_rne(e[j]);
+            const float r1 = e[j] - __uint_as_float(h[j] << 16);
+            m[j] = bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float(m[j] << 16);
+            l[j] = bf16_rne(r2);
+        }
+        reinterpret_cast<uint2*>(planes)[i] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        reinterpret_cast<uint2*>(planes + plane_elems)[i] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));      // second plane = bf16(x - h)
+    }
+}
+
+constexpr int NP = 2;                      // planes per operand
+constexpr int BK = 32;
+constexpr int LROW = 40;                    // bf16 per LDS row: 32 + 8 pad (80-byte stride: conflict-free ds_read_b128)
+
+template <int BM, int BN, int OCC, int ABL = 0>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_planes(const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp,
+                                                           float* __restrict__ C, int M, int N, int K) {
+    constexpr int TM = BM / 32, TN = BN / 32;                 // 16x16 tiles per wave (2x2 waves)
+    constexpr int PA = BM * LROW, PB = BN * LROW;             // bf16 per plane-tile
+    constexpr int NA = BM / 64, NB = BN / 64;                 // 16-byte chunks per thread per plane
+    __shared__ __attribute__((aligned(16))) unsigned short As[NP * PA];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[NP * PB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = N / BN, tiles_m = M / BM;
+    int wg = blockIdx.x;
+    if (!(ABL & 8)) {                                         // XCD-aware remap (workgroup b runs on XCD b % 8) + grouped rasterisation
+        const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    int tile_m, tile_n;
+    if (ABL & 8) { tile_m = wg / tiles_n; tile_n = wg % tiles_n; }
+    else {
+        constexpr int GM = 8;
+        const int per_group = GM * tiles_n, group = wg / per_group, first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM), in_group = wg - group * per_group;
+        tile_m = first_m + in_group % gsz; tile_n = in_group / gsz;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int ntiles = K / BK;
+    const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int srow = tid >> 2, sch = tid & 3;                 // staging: (row, 16-byte chunk) of a [rows][32 bf16] plane-tile
+    const unsigned short* ga = Ap + (size_t)(m0 + srow) * K + sch * 8;
+    const unsigned short* gb = Bp + (size_t)(n0 + srow) * K + sch * 8;
+    uint4 ra[NP][NA], rb[NP][NB];
+    auto load_g = [&](int t) {
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[s][i] = *reinterpret_cast<const uint4*>(ga + s * planeA + (size_t)(64 * i) * K + t * BK);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[s][i] = *reinterpret_cast<const uint4*>(gb + s * planeB + (size_t)(64 * i) * K + t * BK);
+        }
+    };
+    const int s_off = srow * LROW + sch * 8;
+    auto store_lds = [&]() {
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(&As[s * PA + s_off + 64 * i * LROW]) = ra[s][i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(&Bs[s * PB + s_off + 64 * i * LROW]) = rb[s][i];
+        }
+    };
+
+    load_g(0); store_lds(); __syncthreads();
+    const int r = lane & 15, g = lane >> 4;
+    const int a_off = (wm * (BM / 2) + r) * LROW + g * 8, b_off = (wn * (BN / 2) + r) * LROW + g * 8;
+    for (int t = 0; t < ntiles; ++t) {
+        if (!(ABL & 1) && t + 1 < ntiles) load_g(t + 1);
+        bf16x8 af[TM][NP];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int s = 0; s < NP; ++s) af[i][s] = *reinterpret_cast<const bf16x8*>(&As[s * PA + a_off + i * 16 * LROW]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf16x8 bf[NP];
+#pragma unroll
+            for (int s = 0; s < NP; ++s) bf[s] = *reinterpret_cast<const bf16x8*>(&Bs[s * PB + b_off + j * 16 * LROW]);
+            // smallest terms first; the three products of one tile are spread over the TM independent accumulators
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[0], acc[i][j], 0, 0, 0);   // l h
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[1], acc[i][j], 0, 0, 0);   // h l
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[0], acc[i][j], 0, 0, 0);   // h h
+        }
+        if (!(ABL & 2)) {
+            __syncthreads();
+            if (t + 1 < ntiles) { if (!(ABL & 4)) store_lds(); __syncthreads(); }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 16 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) C[(size_t)(m0 + wm * (BM / 2) + i * 16 + g * 4 + q) * N + col] = acc[i][j][q];
+        }
+}
+
+#define HIPCHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int BM, int BN, int OCC, int ABL = 0>
+static void run(const char* name, const unsigned short* dAp, const unsigned short* dBp, float* dC, int M, int N, int K, const std::vector<float>& hA,
+                const std::vector<float>& hB) {
+    if (M % BM || N % BN) return;
+    dim3 grid((M / BM) * (N / BN));
+    hipLaunchKernelGGL((gemm_nt_planes<BM, BN, OCC, ABL>), grid, dim3(256), 0, 0, dAp, dBp, dC, M, N, K);
+    HIPCHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    const int reps = 20;
+    HIPCHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_nt_planes<BM, BN, OCC, ABL>), grid, dim3(256), 0, 0, dAp, dBp, dC, M, N, K);
+    HIPCHECK(hipEventRecord(e1)); HIPCHECK(hipEventSynchronize(e1));
+    float ms; HIPCHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const int rows = 48;
+    std::vector<float> hC((size_t)rows * N);
+    HIPCHECK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double emax = 0, e2 = 0, r2 = 0, rmax = 0;
+    for (int m = 0; m < rows; ++m)
+        for (int n = 0; n < N; n += 5) {
+            double ref = 0;
+            for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)m * K + k] * (double)hB[(size_t)n * K + k];
+            const double e = hC[(size_t)m * N + n] - ref;
+            emax = fmax(emax, fabs(e)); e2 += e * e; r2 += ref * ref; rmax = fmax(rmax, fabs(ref));
+        }
+    printf("  %-14s %4d WGs: %.3f ms  %.1f TFLOP/s algorithmic (%.0f executed bf16 TF)  | vs fp64: max|e|/max|ref| %.2e  ||e||/||ref|| %.2e\n", name,
+           grid.x, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12, 6.0 * M * N * K / (ms * 1e-3) / 1e12, emax / rmax, sqrt(e2 / r2));
+}
+
+int main(int argc, char** argv) {
+    int M = 8192, N = 3072, K = 768;
+    if (argc >= 4) { M = atoi(argv[1]); N = atoi(argv[2]); K = atoi(argv[3]); }
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+    unsigned s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) * (1.0f / 16777216.0f) - 0.5f); };
+    for (auto& v : hA) v = rnd() * 4.0f;
+    for (auto& v : hB) v = rnd() * 0.1f;
+    float *dA, *dB, *dC; unsigned short *dAp, *dBp;
+    HIPCHECK(hipMalloc(&dA, hA.size() * 4)); HIPCHECK(hipMalloc(&dB, hB.size() * 4)); HIPCHECK(hipMalloc(&dC, (size_t)M * N * 4));
+    HIPCHECK(hipMalloc(&dAp, hA.size() * 4)); HIPCHECK(hipMalloc(&dBp, hB.size() * 4));
+    HIPCHECK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, dB, dBp, (long long)hB.size() / 4, (long long)hB.size());
+    hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, dA, dAp, (long long)hA.size() / 4, (long long)hA.size());
+    HIPCHECK(hipEventRecord(e0));
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, dA, dAp, (long long)hA.size() / 4, (long long)hA.size());
+    HIPCHECK(hipEventRecord(e1)); HIPCHECK(hipEventSynchronize(e1));
+    float ms; HIPCHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+    printf("M=%d N=%d K=%d   split into 2 planes of A [%d,%d]: %.3f ms (%.0f GB/s)\n", M, N, K, M, K, ms, hA.size() * 8.0 / (ms * 1e-3) / 1e9);
+    run<128, 128, 2>("128x128 occ2", dAp, dBp, dC, M, N, K, hA, hB);
+    run<128, 128, 2, 8>("  row-major raster", dAp, dBp, dC, M, N, K, hA, hB);
+    run<128, 128, 2, 1>("  no gload", dAp, dBp, dC, M, N, K, hA, hB);
+    run<128, 128, 2, 5>("  no gload/lds st", dAp, dBp, dC, M, N, K, hA, hB);
+    run<128, 128, 2, 7>("  + no barriers", dAp, dBp, dC, M, N, K, hA, hB);
+    run<128, 128, 2, 4>("  no lds store", dAp, dBp, dC, M, N, K, hA, hB);
+    run<128, 64, 2>("128x64 occ2", dAp, dBp, dC, M, N, K, hA, hB);
+    run<128, 64, 3>("128x64 occ3", dAp, dBp, dC, M, N, K, hA, hB);
+    run<64, 64, 4>("64x64 occ4", dAp, dBp, dC, M, N, K, hA, hB);
+    return 0;
+}
