@@ -15,6 +15,7 @@
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {
     unsigned u = __float_as_uint(x);
@@ -140,6 +141,99 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_planes(const unsigned short*
         }
 }
 
+// ---- v2: double-buffered LDS (one barrier per K tile) + global prefetch distance 2 in registers (two staging sets), same fragment layout / products
+template <int BM, int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_planes2(const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp,
+                                                            float* __restrict__ C, int M, int N, int K) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int PA = BM * LROW, PB = BN * LROW;
+    constexpr int NA = BM / 64, NB = BN / 64;
+    constexpr int STAGE = NP * (PA + PB);
+    __shared__ __attribute__((aligned(16))) unsigned short L[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = N / BN, tiles_m = M / BM;
+    int wg = blockIdx.x;
+    {
+        const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7, xcd = wg & 7, loc = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    constexpr int GM = 8;
+    const int per_group = GM * tiles_n, group = wg / per_group, first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM), in_group = wg - group * per_group;
+    const int tile_m = first_m + in_group % gsz, tile_n = in_group / gsz;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int ntiles = K / BK;
+    const size_t planeA = (size_t)M * K, planeB = (size_t)N * K;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int srow = tid >> 2, sch = tid & 3;
+    const unsigned short* ga = Ap + (size_t)(m0 + srow) * K + sch * 8;
+    const unsigned short* gb = Bp + (size_t)(n0 + srow) * K + sch * 8;
+    u32x4v ra0[NP][NA], rb0[NP][NB], ra1[NP][NA], rb1[NP][NB];       // two staging sets as separate arrays, touched only by fully unrolled macro bodies
+    const int s_off = srow * LROW + sch * 8;
+    const int r = lane & 15, g = lane >> 4;
+    const int a_off = (wm * (BM / 2) + r) * LROW + g * 8, b_off = (wn * (BN / 2) + r) * LROW + g * 8;
+#define LOAD_G(RA, RB, T)                                                                                                             \
+    _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_) {                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) RA[s_][i_] = *reinterpret_cast<const u32x4v*>(ga + s_ * planeA + (size_t)(64 * i_) * K + (T) * BK); \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) RB[s_][i_] = *reinterpret_cast<const u32x4v*>(gb + s_ * planeB + (size_t)(64 * i_) * K + (T) * BK); \
+    }
+#define STORE_LDS(RA, RB, STG)                                                                                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_) {                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) *reinterpret_cast<u32x4v*>(&L[(STG) * STAGE + s_ * PA + s_off + 64 * i_ * LROW]) = RA[s_][i_];            \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) *reinterpret_cast<u32x4v*>(&L[(STG) * STAGE + NP * PA + s_ * PB + s_off + 64 * i_ * LROW]) = RB[s_][i_];  \
+    }
+#define COMPUTE(STG)                                                                                                                  \
+    {                                                                                                                                 \
+        const unsigned short* As_ = L + (STG) * STAGE; const unsigned short* Bs_ = As_ + NP * PA;                                     \
+        bf16x8 af[TM][NP];                                                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_)                                                                             \
+            _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_) af[i_][s_] = *reinterpret_cast<const bf16x8*>(&As_[s_ * PA + a_off + i_ * 16 * LROW]); \
+        _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) {                                                                           \
+            bf16x8 bf[NP];                                                                                                            \
+            _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_) bf[s_] = *reinterpret_cast<const bf16x8*>(&Bs_[s_ * PB + b_off + j_ * 16 * LROW]); \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_][1], bf[0], acc[i_][j_], 0, 0, 0); \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_][0], bf[1], acc[i_][j_], 0, 0, 0); \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_][0], bf[0], acc[i_][j_], 0, 0, 0); \
+        }                                                                                                                             \
+    }
+    // prologue: tile 0 -> LDS stage 0; tile 1 -> set 1 (in flight)
+    // (loads / stores are UNCONDITIONAL -- past the end they re-read the last tile and write a stage nobody reads: a conditionally written staging array is
+    //  left in scratch memory by the compiler, which is what the round-3 bf16x6 kernel suffered from: 144 B of scratch per thread)
+    const int last = ntiles - 1;                                  // ntiles even (K % 64 == 0) in this harness
+    LOAD_G(ra0, rb0, 0)
+    LOAD_G(ra1, rb1, min(1, last))
+    STORE_LDS(ra0, rb0, 0)
+    __syncthreads();
+    for (int t = 0; t < ntiles; t += 2) {
+        // even iteration: LDS stage 0 = tile t, set 1 = tile t+1 (in flight), request tile t+2 into set 0
+        LOAD_G(ra0, rb0, min(t + 2, last))
+        COMPUTE(0)
+        STORE_LDS(ra1, rb1, 1)
+        __syncthreads();
+        // odd iteration: LDS stage 1 = tile t+1, set 0 = tile t+2 (in flight), request tile t+3 into set 1
+        LOAD_G(ra1, rb1, min(t + 3, last))
+        COMPUTE(1)
+        STORE_LDS(ra0, rb0, 0)
+        __syncthreads();
+    }
+#undef LOAD_G
+#undef STORE_LDS
+#undef COMPUTE
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / 2) + j * 16 + r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) C[(size_t)(m0 + wm * (BM / 2) + i * 16 + g * 4 + q) * N + col] = acc[i][j][q];
+        }
+}
+
 #define HIPCHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 template <int BM, int BN, int OCC, int ABL = 0>
@@ -170,6 +264,34 @@ static void run(const char* name, const unsigned short* dAp, const unsigned shor
            grid.x, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12, 6.0 * M * N * K / (ms * 1e-3) / 1e12, emax / rmax, sqrt(e2 / r2));
 }
 
+template <int BM, int BN, int OCC>
+static void run2(const char* name, const unsigned short* dAp, const unsigned short* dBp, float* dC, int M, int N, int K, const std::vector<float>& hA,
+                 const std::vector<float>& hB) {
+    if (M % BM || N % BN) return;
+    dim3 grid((M / BM) * (N / BN));
+    hipLaunchKernelGGL((gemm_nt_planes2<BM, BN, OCC>), grid, dim3(256), 0, 0, dAp, dBp, dC, M, N, K);
+    HIPCHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    const int reps = 20;
+    HIPCHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_nt_planes2<BM, BN, OCC>), grid, dim3(256), 0, 0, dAp, dBp, dC, M, N, K);
+    HIPCHECK(hipEventRecord(e1)); HIPCHECK(hipEventSynchronize(e1));
+    float ms; HIPCHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const int rows = 48;
+    std::vector<float> hC((size_t)rows * N);
+    HIPCHECK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double emax = 0, e2 = 0, r2 = 0, rmax = 0;
+    for (int m = 0; m < rows; ++m)
+        for (int n = 0; n < N; n += 5) {
+            double ref = 0;
+            for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)m * K + k] * (double)hB[(size_t)n * K + k];
+            const double e = hC[(size_t)m * N + n] - ref;
+            emax = fmax(emax, fabs(e)); e2 += e * e; r2 += ref * ref; rmax = fmax(rmax, fabs(ref));
+        }
+    printf("  %-14s %4d WGs: %.3f ms  %.1f TFLOP/s algorithmic  | vs fp64: max|e|/max|ref| %.2e  ||e||/||ref|| %.2e\n", name,
+           grid.x, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12, emax / rmax, sqrt(e2 / r2));
+}
+
 int main(int argc, char** argv) {
     int M = 8192, N = 3072, K = 768;
     if (argc >= 4) { M = atoi(argv[1]); N = atoi(argv[2]); K = atoi(argv[3]); }
@@ -197,6 +319,10 @@ int main(int argc, char** argv) {
     run<128, 128, 2, 5>("  no gload/lds st", dAp, dBp, dC, M, N, K, hA, hB);
     run<128, 128, 2, 7>("  + no barriers", dAp, dBp, dC, M, N, K, hA, hB);
     run<128, 128, 2, 4>("  no lds store", dAp, dBp, dC, M, N, K, hA, hB);
+    run2<128, 128, 2>("v2 128x128 occ2", dAp, dBp, dC, M, N, K, hA, hB);
+    run2<128, 128, 1>("v2 128x128 occ1", dAp, dBp, dC, M, N, K, hA, hB);
+    run2<128, 64, 2>("v2 128x64 occ2", dAp, dBp, dC, M, N, K, hA, hB);
+    run2<128, 64, 3>("v2 128x64 occ3", dAp, dBp, dC, M, N, K, hA, hB);
     run<128, 64, 2>("128x64 occ2", dAp, dBp, dC, M, N, K, hA, hB);
     run<128, 64, 3>("128x64 occ3", dAp, dBp, dC, M, N, K, hA, hB);
     run<64, 64, 4>("64x64 occ4", dAp, dBp, dC, M, N, K, hA, hB);
