@@ -12,7 +12,7 @@ enum ActKernelId {
     KID_GEMM_NT, KID_GEMM_NN, KID_GEMM_TN, KID_LAYERNORM_FWD, KID_LAYERNORM_BWD, KID_ATTN_FWD, KID_ATTN_BWD,
     KID_COLSUM, KID_GELU_BWD, KID_COSINE_FWD, KID_COSINE_BWD, KID_BN_STATS, KID_BN_APPLY, KID_BN_BWD,
     KID_MAXPOOL, KID_MAXPOOL_BWD, KID_GN_LRELU_MAX, KID_GRAPH_FEATURE, KID_GUMBEL_ARGMAX, KID_ROW_GATHER,
-    KID_ROW_SCATTER, KID_ADAMW, KID_ELTWISE, KID_COUNT
+    KID_ROW_SCATTER, KID_ADAMW, KID_ELTWISE, KID_GEMM_BF16X3, KID_COUNT
 };
 
 void act_prof_begin(int kid, hipStream_t s, double flops, double bytes);

@@ -12,7 +12,7 @@ const char* kNames[KID_COUNT] = {
     "sgemm_nt", "sgemm_nn", "sgemm_tn", "layernorm_fwd", "layernorm_bwd", "attention_fwd", "attention_bwd",
     "colsum", "gelu_bwd", "cosine_loss_fwd", "cosine_loss_bwd", "bn_stats", "bn_apply", "bn_bwd",
     "group_maxpool", "group_maxpool_bwd", "gn_lrelu_max", "graph_feature", "gumbel_argmax", "row_gather",
-    "row_scatter", "adamw", "eltwise"};
+    "row_scatter", "adamw", "eltwise", "sgemm_nt_bf16x3"};
 
 struct Rec { int kid; hipEvent_t a, b; };
 struct State {

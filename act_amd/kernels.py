@@ -197,6 +197,42 @@ def gemm_tn_grouped(pairs, want_bias=True, splits=0):
     return dws, dbs
 
 
+# ---- OPT-IN split-bf16 products (csrc/gemm_bf16x3.hip): frozen teacher only, never the default -------------------------------------------------
+_C._declare({"act_split_bf16x2_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
+             "act_sgemm_nt_bf16x3_supported": [_i, _i, _i],
+             "act_sgemm_nt_bf16x3_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(GemmEpilogue), _vp]})
+for _n in ("act_split_bf16x2_f32", "act_sgemm_nt_bf16x3_supported", "act_sgemm_nt_bf16x3_f32"):
+    _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
+
+
+def split_bf16x2(x, out=None):
+    """fp32 [R, K] -> bf16 planes [2, R, K]: hi = bf16(x), lo = bf16(x - hi) (round to nearest even) -- the operand form of gemm_nt_bf16x3."""
+    x = _f32rows(x, "x")
+    R, Kd = x.shape
+    if out is None:
+        out = torch.empty(2, R, Kd, dtype=torch.bfloat16, device=x.device)
+    check(lib.act_split_bf16x2_f32(_C.ptr_rows(x), R, Kd, x.stride(0), ptr(out[0]), ptr(out[1]), stream()), "act_split_bf16x2_f32")
+    return out
+
+
+def gemm_nt_bf16x3(a_planes, b_planes, bias=None, act=EPI_NONE, res=None, out=None):
+    """C[M,N] = epilogue(a . b^T) with both operands given as (hi, lo) bf16 planes [2, rows, K] (split_bf16x2) and the three products hi.hi + hi.lo + lo.hi
+    on the bf16 matrix cores (fp32 accumulation): 4e-6 relative per product.  M, N % 128 == 0, K % 64 == 0.  Opt-in path of the frozen teacher."""
+    _, M, Kd = a_planes.shape
+    _, N, Kb = b_planes.shape
+    if Kd != Kb or a_planes.dtype != torch.bfloat16 or b_planes.dtype != torch.bfloat16 or not (a_planes.is_contiguous() and b_planes.is_contiguous()):
+        raise _C.ActHipError("gemm_nt_bf16x3: contiguous bf16 planes [2, rows, K] with equal K expected")
+    if not lib.act_sgemm_nt_bf16x3_supported(M, N, Kd):
+        raise _C.ActHipError(f"gemm_nt_bf16x3: unsupported shape {M} x {N} x {Kd} (M, N % 128, K % 64)")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a_planes.device)
+    e = GemmEpilogue(alpha=1.0, act=act, accumulate=0, rows_per_scale=0, ldr=(res.stride(0) if res is not None else 0), ldaux=0, res_row_div=0,
+                     bias=ptr(bias), rowscale=None, res=ptr(res), aux=None)
+    check(lib.act_sgemm_nt_bf16x3_f32(M, N, Kd, ptr(a_planes[0]), ptr(a_planes[1]), ptr(b_planes[0]), ptr(b_planes[1]), ptr(out), out.stride(0),
+                                      ctypes.byref(e), stream()), "act_sgemm_nt_bf16x3_f32")
+    return out
+
+
 # ---- GEMM autotuner: the step has ~40 distinct (layout, M, N, K) shapes; each is timed once (tile shape x split-K) on first
 # use -- i.e. during the warm-up steps -- and the winner is cached, so steady-state steps never synchronise.
 _GEMM_CACHE = {}

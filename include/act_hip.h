@@ -333,6 +333,17 @@ int act_kl_uniform_fwd_f32(const float* logits, int B, int G, int C, float* lse,
 int act_kl_uniform_bwd_f32(const float* logits, const float* lse, const float* qbar, const float* grad_klv, int B, int G, int C,
                            float* dlogits, act_stream_t stream);
 
+/* ---- OPT-IN: NT GEMM on the bf16 matrix cores with split operands ("bf16x3"), frozen teacher only (csrc/gemm_bf16x3.hip) -------------------------
+ * x ~ hi + lo with hi = bf16(x), lo = bf16(x - hi) (round to nearest even): C = epilogue(A_hi.B_hi^T + A_hi.B_lo^T + A_lo.B_hi^T), fp32 accumulation.
+ * 16 significand bits per operand: 4e-6 relative per product; NOT used by default (ACT_TEACHER_BF16X3=1 routes the teacher's ViT GEMMs here).
+ * act_split_bf16x2_f32: fp32 [R, K] (row stride ldx, K % 4 == 0, 16-byte aligned) -> planes hi / lo [R][K] (uint16 bf16 bit patterns).
+ * act_sgemm_nt_bf16x3_f32: planes of A [M][K] and B [N][K] (contiguous rows) -> C [M, ldc] fp32; M, N % 128 == 0, K % 64 == 0
+ * (act_sgemm_nt_bf16x3_supported); epilogue: alpha, bias, ACT_EPI_NONE | ACT_EPI_GELU (+ aux), rowscale, res -- no accumulate. */
+int act_split_bf16x2_f32(const float* x, int R, int K, int ldx, uint16_t* hi, uint16_t* lo, act_stream_t stream);
+int act_sgemm_nt_bf16x3_supported(int M, int N, int K);
+int act_sgemm_nt_bf16x3_f32(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
+                            float* C, int ldc, const act_gemm_epilogue_t* epilogue, act_stream_t stream);
+
 /* ---- GEMM launch-configuration table (host side) ------------------------------------------------------------------------
  * act_sgemm_f32 (no explicit configuration) first consults this table keyed by (a_kmajor, b_kmajor, M, N, K), then its built-in
  * cost model.  The Python host fills it from the shipped tune file and from first-use timing (act_amd/kernels.py); the composite

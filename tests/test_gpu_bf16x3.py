@@ -1,0 +1,125 @@
+"""The OPT-IN split-bf16 path of the frozen teacher (csrc/gemm_bf16x3.hip, ACT_TEACHER_BF16X3=1): never the default, never in a headline number.
+Kernel level: the plane split is exact (hi + lo reproduces the first 16 significand bits, round to nearest even), the three-product GEMM agrees with an
+fp64 product of the ORIGINAL fp32 operands to 2e-5 and with an fp32 emulation of its own arithmetic much closer, with every epilogue the teacher uses.
+Model level: the teacher's features with the switch on stay within the 1e-4 parity bar of the f32 path (measured ~7e-6) and of the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _rel(a, ref):
+    a, ref = a.double().cpu(), ref.double().cpu()
+    return ((a - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+def test_split_planes_are_the_rne_bf16_decomposition(dev):
+    import act_amd.kernels as K
+    torch.manual_seed(0)
+    x = torch.randn(256, 192, device=dev) * torch.logspace(-3, 3, 192, device=dev)
+    pl = K.split_bf16x2(x)
+    assert pl.dtype == torch.bfloat16 and tuple(pl.shape) == (2, 256, 192)
+    hi = x.bfloat16()                                             # torch rounds to nearest even as well
+    lo = (x - hi.float()).bfloat16()
+    assert torch.equal(pl[0], hi) and torch.equal(pl[1], lo)
+    # what the two planes keep: 16 significand bits
+    err = (pl[0].float() + pl[1].float() - x).abs() / x.abs().clamp_min(1e-30)
+    assert err.max().item() <= 2.0 ** -16
+    # a row-strided view (column slice of a wider tensor) splits like its contiguous copy
+    wide = torch.randn(128, 512, device=dev)
+    v = wide[:, 128:384]
+    assert torch.equal(K.split_bf16x2(v), K.split_bf16x2(v.contiguous()))
+
+
+@pytest.mark.parametrize("M,N,Kd,bias,act,res", [(256, 128, 64, False, 0, False), (8192, 768, 768, True, 0, True), (1024, 3072, 768, True, 1, False),
+                                                  (512, 768, 3072, True, 0, True), (384, 2304, 768, True, 0, False)])
+def test_bf16x3_gemm_against_fp64_and_its_own_arithmetic(dev, M, N, Kd, bias, act, res):
+    import act_amd.kernels as K
+    g = torch.Generator().manual_seed(M + N + Kd)
+    a = (torch.randn(M, Kd, generator=g) * 1.5).to(dev); w = (torch.randn(N, Kd, generator=g) * 0.05).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    r = torch.randn(M, N, generator=g).to(dev) if res else None
+    ap, wp = K.split_bf16x2(a), K.split_bf16x2(w)
+    out = K.gemm_nt_bf16x3(ap, wp, bias=b, act=(K.EPI_GELU if act else K.EPI_NONE), res=r)
+
+    def epi(y):
+        if b is not None:
+            y = y + b.double()
+        if act:
+            y = torch.nn.functional.gelu(y)
+        if r is not None:
+            y = y + r.double()
+        return y
+    exact = epi(a.double() @ w.double().t())
+    assert _rel(out, exact) <= 2e-5, _rel(out, exact)
+    # the kernel's own arithmetic in fp64: (hi.hi + hi.lo + lo.hi) of the planes -- what is left is fp32 accumulation order only
+    ah, al, wh, wl = (t.double() for t in (ap[0], ap[1], wp[0], wp[1]))
+    own = epi(al @ wh.t() + ah @ wl.t() + ah @ wh.t())
+    assert _rel(out, own) <= 2e-6, _rel(out, own)
+    # and it is the SAME fp32 epilogue as the f32 kernel's (bias, exact-erf GELU, residual): compare against the product path on the same operands
+    ref32 = K.gemm(a, w, True, True, bias=b, act=(K.EPI_GELU if act else K.EPI_NONE), res=r)
+    assert _rel(out, ref32) <= 2e-5
+
+
+def test_bf16x3_rejects_what_it_does_not_support(dev):
+    import act_amd.kernels as K
+    from act_amd._C import ActHipError
+    a = K.split_bf16x2(torch.randn(128, 64, device=dev)); w = K.split_bf16x2(torch.randn(128, 64, device=dev))
+    K.gemm_nt_bf16x3(a, w)
+    for bad_a, bad_w in ((K.split_bf16x2(torch.randn(96, 64, device=dev)), w), (K.split_bf16x2(torch.randn(128, 32, device=dev)), K.split_bf16x2(torch.randn(128, 32, device=dev)))):
+        with pytest.raises(ActHipError):
+            K.gemm_nt_bf16x3(bad_a, bad_w)
+    with pytest.raises(ActHipError):
+        K.gemm_nt_bf16x3(a.float(), w)
+
+
+def test_teacher_features_with_split_bf16_stay_inside_the_parity_bar(dev):
+    """ACT_TEACHER_BF16X3 semantics (composite.TEACHER_BF16X3 = True): the five Linear products of every ViT layer of the frozen teacher on the split-bf16
+    kernel.  Full configs[1] geometry, B = 8: features within 1e-4 of the f32 HIP path AND of the CPU oracle (max |e| / max |ref|; the oracle emulation
+    predicts 6e-6), the default path untouched (bit-identical before / after the switch was used)."""
+    import act_amd.composite as CP
+    if not hasattr(CP, "TEACHER_BF16X3"):
+        pytest.skip("the teacher-side switch is not wired in this build")
+    from oracle import models as OM, layers as OL
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import cfg_from_yaml_file
+    from act_amd.utils.draws import Draws
+    from tests.golden.fill import clouds
+    cfg = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml").model
+    cfg.dvae_config.ckpt = "none"
+    torch.manual_seed(2)
+    oracle = OM.ACT_PointDistillation(OM.edict(cfg)).train()
+    model = build_model_from_cfg(cfg)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model.to(dev).train()
+    oracle.dvae_tokenizer.prompt_p = 0.0; model.dvae_tokenizer.prompt_dropout.p = 0.0      # (the fused stack draws its prompt dropout in-kernel: switch it off)
+    pts = torch.from_numpy(clouds(6, 8, 1024))
+    with torch.no_grad():
+        nb_o, c_o = oracle.group_divider(pts)
+        rec = OL.Draws(record=True)
+        tf_o = oracle.dvae_tokenizer.forward_tokenizer_features(nb_o, c_o, rec)
+        nb, c = model.group_divider(pts.to(dev))
+        gum = Draws({"gumbel": rec.table["gumbel"]}, device=dev)
+        saved = CP.TEACHER_BF16X3
+        try:
+            CP.TEACHER_BF16X3 = False
+            f32_a = model.dvae_tokenizer.forward_tokenizer_features(nb, c, draws=Draws({"gumbel": rec.table["gumbel"]}, device=dev))
+            CP.TEACHER_BF16X3 = True
+            x3 = model.dvae_tokenizer.forward_tokenizer_features(nb, c, draws=Draws({"gumbel": rec.table["gumbel"]}, device=dev))
+            CP.TEACHER_BF16X3 = False
+            f32_b = model.dvae_tokenizer.forward_tokenizer_features(nb, c, draws=Draws({"gumbel": rec.table["gumbel"]}, device=dev))
+        finally:
+            CP.TEACHER_BF16X3 = saved
+    assert torch.equal(f32_a, f32_b)
+    assert not torch.equal(x3, f32_a)                             # the switch really took the other kernels
+    e32, eo = _rel(x3, f32_a), _rel(x3, tf_o)
+    print(f"split-bf16 teacher: max|e|/max|ref| vs f32 HIP path {e32:.2e}, vs CPU oracle {eo:.2e} (f32 path vs oracle {_rel(f32_a, tf_o):.2e})")
+    assert e32 <= 1e-4 and eo <= 1e-4
+    assert e32 <= 3e-5                                            # far inside the bar, as the oracle emulation predicts
