@@ -45,6 +45,10 @@ class PrefixVit(ctypes.Structure):
                 [("prompt_tok", ctypes.POINTER(_vp)), ("prompt_pos", ctypes.POINTER(_vp)), ("blocks", ctypes.POINTER(BlockParams))])
 
 
+class VitBf16x3(ctypes.Structure):
+    _fields_ = [("w_planes", _vp), ("a_planes", _vp), ("a_planes_elems", _sz)]
+
+
 class PointnetParams(ctypes.Structure):
     _fields_ = [(n, _vp) for n in ("c1_w", "c1_b", "bn1_w", "bn1_b", "c2_w", "c2_b", "c3_w", "c3_b", "bn2_w", "bn2_b", "c4_w", "c4_b",
                                    "bn1_mean", "bn1_var", "bn2_mean", "bn2_var")]
@@ -97,6 +101,7 @@ _SIGS = {
     "act_prefix_block_bwd_f32": [_P(BlockDims), _i, _P(BlockParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "act_prefix_vit_scratch_floats": [_P(PrefixVit)],
     "act_prefix_vit_fwd_f32": [_P(PrefixVit), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
+    "act_prefix_vit_fwd_bf16x3_f32": [_P(PrefixVit), _P(VitBf16x3), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "act_pointnet_saved_floats": [_P(PointnetDims)],
     "act_pointnet_bwd_scratch_floats": [_P(PointnetDims)],
     "act_pointnet_fwd_f32": [_P(PointnetDims), _P(PointnetParams), _vp, _i, _i, _vp, _vp, _vp, _sz, _vp],
@@ -385,6 +390,11 @@ class BlockStackFn(torch.autograd.Function):
 _LEAVES = weakref.WeakKeyDictionary()          # ModuleList of blocks -> [(norm1, qkv, proj, norm2, fc1, fc2, block)]
 _VIT_LEAVES = weakref.WeakKeyDictionary()      # tokenizer -> (blocks, pos0, pos2, proj_pre, proj_post, norm)
 _VIT_STRUCT = weakref.WeakKeyDictionary()      # tokenizer -> (signature, PrefixVit, scratch floats, keep-alive ctypes arrays)
+_VIT_PLANES = weakref.WeakKeyDictionary()      # tokenizer -> (signature incl. weight versions, [bf16 plane tensors], pointer array)   (opt-in split-bf16 teacher)
+# OPT-IN, default OFF: the Linear products of the FROZEN teacher's ViT blocks on the split-bf16 kernel (csrc/gemm_bf16x3.hip: hi + lo bf16 planes of both
+# operands, three products, fp32 accumulation; teacher features move by ~7e-6 of their range, parity bar 1e-4).  Never part of a headline number:
+# bench.py reports this configuration on a separate line.  Inference form of the teacher only (Stage II); Stage-I prompt tuning keeps the f32 kernels.
+TEACHER_BF16X3 = os.environ.get("ACT_TEACHER_BF16X3", "0") == "1"
 
 
 def _stack_leaves(blocks):
@@ -559,9 +569,31 @@ def prefix_vit_forward(tok, tokens, center, drop_p, seed_base, seed_dev):
     ws = K.workspace(dev)
     tokens, center = K._f32c(tokens), K._f32c(center)
     args = (ctypes.byref(m), _p(tokens), _p(center), _p(out), _p(scratch), _p(ws), ws.numel() * 4)
+    # (the f32 shapes are collected and tuned in either mode: a shape the split-bf16 kernel does not take falls back to them)
     ensure_tuned(("vit", B, m.P, G, m.D, m.heads, m.hidden, depth, td), lambda: lib.act_prefix_vit_fwd_f32(*args, _C.stream()), dev)
+    if TEACHER_BF16X3:
+        x3, keep = _vit_planes(tok, ts, depth, B * max(G, m.P) * m.hidden, dev)
+        check(lib.act_prefix_vit_fwd_bf16x3_f32(args[0], ctypes.byref(x3), *args[1:], _C.stream()), "act_prefix_vit_fwd_bf16x3_f32")
+        del keep
+        return out
     check(lib.act_prefix_vit_fwd_f32(*args, _C.stream()), "act_prefix_vit_fwd_f32")
     return out
+
+
+def _vit_planes(tok, ts, depth, act_elems, dev):
+    """(hi, lo) bf16 planes of the four Linear weights of every teacher block, split ONCE and cached per tokenizer; re-split when a weight moved or was
+    written to (address + version counter of every weight in the signature: load_state_dict copies in place).  -> (VitBf16x3, keep-alive)"""
+    ws_ = [ts[10 + _NPB * i + j] for i in range(depth) for j in (2, 4, 8, 10)]                    # qkv_w, proj_w, fc1_w, fc2_w
+    sig = tuple((w.data_ptr(), w._version) for w in ws_)
+    cache = _VIT_PLANES.get(tok)
+    if cache is None or cache[0] != sig:
+        with torch.no_grad():
+            planes = [K.split_bf16x2(w.detach()) for w in ws_]
+        parr = (_vp * len(planes))(*[pl.data_ptr() for pl in planes])
+        cache = _VIT_PLANES[tok] = (sig, planes, parr)
+    a_planes = torch.empty(2 * act_elems, dtype=torch.bfloat16, device=dev)
+    x3 = VitBf16x3(ctypes.cast(cache[2], _vp), a_planes.data_ptr(), a_planes.numel())
+    return x3, (a_planes, cache)
 
 
 # ---- mini-PointNet patch embedding ---------------------------------------------------------------------------------------

@@ -130,23 +130,37 @@ size_t carve_prefix_bwd(float* base, const act_block_dims_t& d, int P, PrefixBwd
 
 // the launch sequence of one prefix block given the LayerNorm'd prompt rows n1p (shared by the inference stack and the
 // differentiable forward)
+// OPT-IN (act_prefix_vit_fwd_bf16x3_f32): the bf16 (hi, lo) planes of one block's four weights + the scratch its activations are split into
+struct X3Block { const uint16_t *qkv, *proj, *fc1, *fc2; uint16_t* a_planes; size_t a_elems; };
+
 int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t& w, const float* x, const float* pos, const float* n1p,
-                      bool keep, PrefixSaved& sv, float* out, float* ws, size_t wsb, hipStream_t s) {
+                      bool keep, PrefixSaved& sv, float* out, float* ws, size_t wsb, hipStream_t s, const X3Block* x3 = nullptr) {
     const int B = d.B, G = d.S, D = d.D, H = d.heads, hd = D / H, Hd = d.hidden, TG = B * G, TP = B * P;
+    // C = epi(A . W^T): on the f32-input MFMA kernels -- or, for the frozen teacher with the split-bf16 switch on and a shape the kernel takes, A is split into
+    // (hi, lo) bf16 planes and multiplied with the weight's planes (W_hi = the sub-block of the plane image; lo plane `wplane` elements behind it)
+    auto linear = [&](int M, int N, int K, const float* A, const float* W, const uint16_t* W_hi, size_t wplane, float* C, const act_gemm_epilogue_t& e) -> int {
+        if (x3 && W_hi && !keep && act_sgemm_nt_bf16x3_supported(M, N, K) && (size_t)2 * M * K <= x3->a_elems) {
+            if (t_collect) return 0;
+            uint16_t* ah = x3->a_planes; uint16_t* al = ah + (size_t)M * K;
+            CK(act_split_bf16x2_f32(A, M, K, K, ah, al, s));
+            return act_sgemm_nt_bf16x3_f32(M, N, K, ah, al, W_hi, W_hi + wplane, C, N, &e, s);
+        }
+        return gemm_nt(M, N, K, A, K, W, K, C, N, e, ws, wsb, s);
+    };
     act_gemm_epilogue_t e = epi0();
     e.bias = w.qkv_b ? w.qkv_b + D : nullptr;                                                   // K,V rows of the qkv Linear
-    CK(gemm_nt(TP, 2 * D, D, n1p, D, w.qkv_w + (size_t)D * D, D, sv.kvp, 2 * D, e, ws, wsb, s));
+    CK(linear(TP, 2 * D, D, n1p, w.qkv_w + (size_t)D * D, x3 ? x3->qkv + (size_t)D * D : nullptr, (size_t)3 * D * D, sv.kvp, e));
     RUN(act_layernorm_fwd_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, sv.n1x, keep ? sv.mean1 : nullptr, keep ? sv.rstd1 : nullptr, TG, D, d.eps, s));
     e = epi0(); e.bias = w.qkv_b;
-    CK(gemm_nt(TG, 3 * D, D, sv.n1x, D, w.qkv_w, D, sv.qkvx, 3 * D, e, ws, wsb, s));
+    CK(linear(TG, 3 * D, D, sv.n1x, w.qkv_w, x3 ? x3->qkv : nullptr, (size_t)3 * D * D, sv.qkvx, e));
     RUN(act_attention_fwd_prefix_f32(sv.kvp, P, sv.qkvx, G, sv.att, keep ? sv.lse : nullptr, B, H, hd, attn_scale(hd), s));
     e = epi0(); e.bias = w.proj_b; e.res = sv.xin; e.ldr = D;
-    CK(gemm_nt(TG, D, D, sv.att, D, w.proj_w, D, sv.x1, D, e, ws, wsb, s));
+    CK(linear(TG, D, D, sv.att, w.proj_w, x3 ? x3->proj : nullptr, (size_t)D * D, sv.x1, e));
     RUN(act_layernorm_fwd_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, sv.n2, keep ? sv.mean2 : nullptr, keep ? sv.rstd2 : nullptr, TG, D, d.eps, s));
     e = epi0(); e.bias = w.fc1_b; e.act = ACT_EPI_GELU; e.aux = keep ? sv.hpre : nullptr; e.ldaux = Hd;
-    CK(gemm_nt(TG, Hd, D, sv.n2, D, w.fc1_w, D, sv.a, Hd, e, ws, wsb, s));
+    CK(linear(TG, Hd, D, sv.n2, w.fc1_w, x3 ? x3->fc1 : nullptr, (size_t)Hd * D, sv.a, e));
     e = epi0(); e.bias = w.fc2_b; e.res = sv.x1; e.ldr = D;
-    CK(gemm_nt(TG, D, Hd, sv.a, Hd, w.fc2_w, Hd, out, D, e, ws, wsb, s));
+    CK(linear(TG, D, Hd, sv.a, w.fc2_w, x3 ? x3->fc2 : nullptr, (size_t)D * Hd, out, e));
     return 0;
 }
 
@@ -409,8 +423,19 @@ size_t act_prefix_vit_scratch_floats(const act_prefix_vit_t* m) {
     return carve_vit(nullptr, *m, a, b, c, d, e, f, g);
 }
 
+static int prefix_vit_fwd(const act_prefix_vit_t* m, const act_vit_bf16x3_t* x3, const float* tokens, const float* center, float* out, float* scratch,
+                          float* ws, size_t wsb, act_stream_t stream);
 int act_prefix_vit_fwd_f32(const act_prefix_vit_t* m, const float* tokens, const float* center, float* out, float* scratch, float* ws,
                            size_t wsb, act_stream_t stream) {
+    return prefix_vit_fwd(m, nullptr, tokens, center, out, scratch, ws, wsb, stream);
+}
+int act_prefix_vit_fwd_bf16x3_f32(const act_prefix_vit_t* m, const act_vit_bf16x3_t* x3, const float* tokens, const float* center, float* out,
+                                  float* scratch, float* ws, size_t wsb, act_stream_t stream) {
+    if (!x3 || !x3->w_planes || !x3->a_planes) return ACT_E_NULLPTR;
+    return prefix_vit_fwd(m, x3, tokens, center, out, scratch, ws, wsb, stream);
+}
+static int prefix_vit_fwd(const act_prefix_vit_t* m, const act_vit_bf16x3_t* x3, const float* tokens, const float* center, float* out, float* scratch,
+                          float* ws, size_t wsb, act_stream_t stream) {
     if (bad_vit(m)) return ACT_E_BADARG;
     if (!tokens || !center || !out || !scratch || !m->blocks || !m->prompt_tok || !m->prompt_pos) return ACT_E_NULLPTR;
     hipStream_t s = (hipStream_t)stream;
@@ -432,7 +457,9 @@ int act_prefix_vit_fwd_f32(const act_prefix_vit_t* m, const float* tokens, const
         const uint64_t seed = (m->seed_base + 7919ull * (uint64_t)(i + 1)) & ((1ull << 62) - 1);
         RUN(act_prompt_layernorm_fwd_f32(m->prompt_tok[i], m->prompt_pos[i], m->B, m->P, D, m->drop_p, seed, m->seed_dev, w.norm1_w, w.norm1_b,
                                         m->eps, n1p, s));
-        CK(prefix_block_core(d, m->P, w, cur, pos, n1p, false, sv, nxt, ws, wsb, s));
+        X3Block xb{};
+        if (x3) xb = X3Block{x3->w_planes[4 * i], x3->w_planes[4 * i + 1], x3->w_planes[4 * i + 2], x3->w_planes[4 * i + 3], x3->a_planes, x3->a_planes_elems};
+        CK(prefix_block_core(d, m->P, w, cur, pos, n1p, false, sv, nxt, ws, wsb, s, x3 ? &xb : nullptr));
         float* t = cur; cur = nxt; nxt = t;
     }
     RUN(act_layernorm_fwd_f32(cur, nullptr, m->norm_w, m->norm_b, nullptr, feat, nullptr, nullptr, TG, D, m->eps, s));

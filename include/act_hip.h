@@ -452,6 +452,17 @@ typedef struct {
     const act_block_params_t* blocks;         /* [depth] */
 } act_prefix_vit_t;
 size_t act_prefix_vit_scratch_floats(const act_prefix_vit_t* m);
+/* OPT-IN variant (never the default; ACT_TEACHER_BF16X3=1 on the host side): the five Linear products of every block on the split-bf16 kernel
+ * (act_sgemm_nt_bf16x3_f32) wherever it takes the shape, everything else as act_prefix_vit_fwd_f32.  w_planes[4 i + {0,1,2,3}] = hi plane of block i's
+ * qkv_w [3D][D], proj_w [D][D], fc1_w [hidden][D], fc2_w [D][hidden] (the lo plane follows the hi plane: rows * cols elements further);
+ * a_planes: scratch the activations are split into, a_planes_elems >= 2 * max(B*G, B*P) * hidden.  Teacher features move by ~7e-6 of their range. */
+typedef struct {
+    const uint16_t* const* w_planes;          /* [4 * depth] */
+    uint16_t* a_planes;
+    size_t a_planes_elems;
+} act_vit_bf16x3_t;
+int act_prefix_vit_fwd_bf16x3_f32(const act_prefix_vit_t* m, const act_vit_bf16x3_t* x3, const float* tokens, const float* center, float* out,
+                                  float* scratch, float* workspace, size_t workspace_bytes, act_stream_t stream);
 int act_prefix_vit_fwd_f32(const act_prefix_vit_t* m, const float* tokens, const float* center, float* out, float* scratch,
                            float* workspace, size_t workspace_bytes, act_stream_t stream);
 
