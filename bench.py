@@ -28,6 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (only priced against in the opt-in split-bf16 teacher configuration)
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (6290 GB/s measured-achievable)
 
 
@@ -160,9 +161,14 @@ def other_workloads(timeout_s=100):
     final_loss, steps, workload}}; a failure is reported in place of the numbers, never raised."""
     import subprocess
     res = {}
-    for name, extra in (("stage1", ["--stage", "1", "--steps", "10", "--warmup", "3"]), ("c5", ["--config", "c5", "--steps", "6", "--warmup", "2"])):
+    for name, extra, xenv in (("stage1", ["--stage", "1", "--steps", "10", "--warmup", "3"], {}), ("c5", ["--config", "c5", "--steps", "6", "--warmup", "2"], {}),
+                              # NOT the headline: the same configs[1] step with the frozen teacher's ViT products on the split-bf16 kernel (opt-in, DESIGN section 4)
+                              ("stage2_teacher_split_bf16_OPT_IN", ["--steps", "20", "--warmup", "5"], {"ACT_TEACHER_BF16X3": "1"})):
+        if name.endswith("OPT_IN") and os.environ.get("ACT_TEACHER_BF16X3") == "1":
+            continue                                     # the parent already runs that configuration (and says so in its metric and dtype)
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline", "--no-instrument", "--no-other-workloads"] + extra
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(xenv)
         t0 = time.time()
         try:
             r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
@@ -171,7 +177,7 @@ def other_workloads(timeout_s=100):
                 res[name] = {"failed": (r.stderr or r.stdout)[-300:], "wall_s": time.time() - t0}
                 continue
             d = json.loads(line[-1])
-            res[name] = {"clouds_per_s": d["value"], "ms_per_step": d["ms_per_step"], "final_loss": d["config"]["final_loss"], "steps": d["steps"],
+            res[name] = {"clouds_per_s": d["value"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"], "final_loss": d["config"]["final_loss"], "steps": d["steps"],
                          "warmup": d["warmup"], "clouds_per_gpu": d["config"]["clouds_per_gpu"], "metric": d["metric"],
                          "workload": d["config"]["workload"], "wall_s": time.time() - t0}
         except Exception as e:
@@ -413,11 +419,14 @@ def main():
     if not math.isfinite(loss_val):                      # a diverged / NaN step would still be timed happily: refuse to report it
         raise RuntimeError(f"bench: non-finite loss {loss_val} after {args.warmup + args.steps + 3} steps")
 
+    import act_amd.composite as _CP
+    x3_on = bool(_CP.TEACHER_BF16X3) and args.stage == 2
     out = {
-        "metric": {1: "stage1_autoencoder_point_clouds_per_sec", 2: "stage2_pretrain_point_clouds_per_sec",
+        "metric": {1: "stage1_autoencoder_point_clouds_per_sec", 2: "stage2_pretrain_point_clouds_per_sec" + ("_teacher_split_bf16_opt_in" if x3_on else ""),
                    3: "finetune_cls_point_clouds_per_sec", 4: "inference_cls_point_clouds_per_sec"}[args.stage], "value": B * world * args.steps / elapsed, "unit": "clouds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not x3_on else "f32 + split-bf16 teacher products (OPT-IN, not the f32 headline)",
+        "data": "synthetic",
         "config": {"workload": ("configs[4] stress: ACT Stage-II pretrain step at N=8192 pts, 512 groups x 64 nbrs, 24L d=768 student + 2L decoder, "
                                 "frozen 12L ViT-B teacher on 64 prompts + 512 tokens (random init), B=%d clouds/GPU, aug+fwd+bwd+AdamW" % B) if c5 else
                                ("configs[1]: ACT Stage-II pretrain step (pretrain_act_distill.yaml geometry): "
@@ -452,6 +461,10 @@ def main():
                       if args.stage == 2 else {})},
     }
 
+    if x3_on:
+        out["config"]["teacher_products"] = ("OPT-IN ACT_TEACHER_BF16X3=1: the five Linear products of every ViT layer of the FROZEN teacher as hi + lo bf16 planes of both "
+                                             "operands, three bf16 MFMA products, fp32 accumulation (csrc/gemm_bf16x3.hip): teacher features move by ~7e-6 of their range "
+                                             "(parity bar 1e-4, tests/test_gpu_bf16x3.py); student, losses, gradients and every other teacher kernel are f32-input MFMA")
     out["config"]["parity_bar"] = ("loss and features within 1e-4 of the fp32 CPU oracle at this geometry and batch; FPS / kNN indices bit-exact; gradients "
                                    "flip-tolerant: <= 1e-3 of a gradient's elements may exceed 1e-4 (the reference's own fp32 summation-order noise through the "
                                    "hard arg-max / max-pool choices), L2 error <= 5e-3 (tests/test_gpu_model.py)")
@@ -499,8 +512,10 @@ def main():
         dv = table[dom]
         if dv["flops"] > 0:
             ach = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            # (opt-in runs only: the split-bf16 kernel executes three bf16 products per algorithmic product -> its ceiling is a third of the dense bf16 peak)
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if dom == "sgemm_nt_bf16x3" else PEAK_F32_MFMA_TFLOPS
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None,
                                "avg_launch_us": 1e3 * dv["ms"] / dv["launches"], "launches_per_step": dv["launches"] / nprof,
                                "note": "hipEvents per launch, auxiliary stream serialised (ACT_OVERLAP_TEACHER=0 ACT_OVERLAP_DW=0); "
                                        "the timed region runs the two streams concurrently"}
