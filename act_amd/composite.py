@@ -572,7 +572,7 @@ def prefix_vit_forward(tok, tokens, center, drop_p, seed_base, seed_dev):
     # (the f32 shapes are collected and tuned in either mode: a shape the split-bf16 kernel does not take falls back to them)
     ensure_tuned(("vit", B, m.P, G, m.D, m.heads, m.hidden, depth, td), lambda: lib.act_prefix_vit_fwd_f32(*args, _C.stream()), dev)
     if TEACHER_BF16X3:
-        x3, keep = _vit_planes(tok, ts, depth, B * max(G, m.P) * m.hidden, dev)
+        x3, keep = _vit_planes(tok, ts, depth, B * G * m.hidden + B * max(G, m.P) * m.D, dev)
         check(lib.act_prefix_vit_fwd_bf16x3_f32(args[0], ctypes.byref(x3), *args[1:], _C.stream()), "act_prefix_vit_fwd_bf16x3_f32")
         del keep
         return out

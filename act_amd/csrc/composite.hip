@@ -138,15 +138,27 @@ int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t
     const int B = d.B, G = d.S, D = d.D, H = d.heads, hd = D / H, Hd = d.hidden, TG = B * G, TP = B * P;
     // C = epi(A . W^T): on the f32-input MFMA kernels -- or, for the frozen teacher with the split-bf16 switch on and a shape the kernel takes, A is split into
     // (hi, lo) bf16 planes and multiplied with the weight's planes (W_hi = the sub-block of the plane image; lo plane `wplane` elements behind it)
-    auto linear = [&](int M, int N, int K, const float* A, const float* W, const uint16_t* W_hi, size_t wplane, float* C, const act_gemm_epilogue_t& e) -> int {
-        if (x3 && W_hi && !keep && act_sgemm_nt_bf16x3_supported(M, N, K) && (size_t)2 * M * K <= x3->a_elems) {
+    // scratch of the split-bf16 path: [0, 2 TG Hd) the planes of the MLP's hidden activation (written by fc1's epilogue, read by fc2), then the planes of
+    // whichever other activation is being multiplied (2 max(TG, TP) D)
+    uint16_t* hid_planes = x3 ? x3->a_planes : nullptr;
+    uint16_t* tmp_planes = x3 ? x3->a_planes + (size_t)2 * TG * Hd : nullptr;
+    const bool x3_ok = x3 && !keep && x3->a_elems >= (size_t)2 * TG * Hd + (size_t)2 * (TG > TP ? TG : TP) * D;
+    // `pre`: A is already there as planes (hi at pre, lo M*K further); `emit`: write the result as planes there instead of fp32 C
+    auto linear = [&](int M, int N, int K, const float* A, const float* W, const uint16_t* W_hi, size_t wplane, float* C, const act_gemm_epilogue_t& e,
+                      const uint16_t* pre = nullptr, uint16_t* emit = nullptr) -> int {
+        if (x3_ok && W_hi && act_sgemm_nt_bf16x3_supported(M, N, K)) {
             if (t_collect) return 0;
-            uint16_t* ah = x3->a_planes; uint16_t* al = ah + (size_t)M * K;
-            CK(act_split_bf16x2_f32(A, M, K, K, ah, al, s));
-            return act_sgemm_nt_bf16x3_f32(M, N, K, ah, al, W_hi, W_hi + wplane, C, N, &e, s);
+            const uint16_t* ah = pre; const uint16_t* al = pre ? pre + (size_t)M * K : nullptr;
+            if (!pre) {
+                CK(act_split_bf16x2_f32(A, M, K, K, tmp_planes, tmp_planes + (size_t)M * K, s));
+                ah = tmp_planes; al = tmp_planes + (size_t)M * K;
+            }
+            return act_sgemm_nt_bf16x3_planes_f32(M, N, K, ah, al, W_hi, W_hi + wplane, emit ? nullptr : C, N, emit, emit ? emit + (size_t)M * N : nullptr, &e, s);
         }
         return gemm_nt(M, N, K, A, K, W, K, C, N, e, ws, wsb, s);
     };
+    // the MLP pair goes through planes only when BOTH products take the split-bf16 kernel
+    const bool mlp_planes = x3_ok && x3->fc1 && x3->fc2 && act_sgemm_nt_bf16x3_supported(TG, Hd, D) && act_sgemm_nt_bf16x3_supported(TG, D, Hd);
     act_gemm_epilogue_t e = epi0();
     e.bias = w.qkv_b ? w.qkv_b + D : nullptr;                                                   // K,V rows of the qkv Linear
     CK(linear(TP, 2 * D, D, n1p, w.qkv_w + (size_t)D * D, x3 ? x3->qkv + (size_t)D * D : nullptr, (size_t)3 * D * D, sv.kvp, e));
@@ -158,9 +170,9 @@ int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t
     CK(linear(TG, D, D, sv.att, w.proj_w, x3 ? x3->proj : nullptr, (size_t)D * D, sv.x1, e));
     RUN(act_layernorm_fwd_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, sv.n2, keep ? sv.mean2 : nullptr, keep ? sv.rstd2 : nullptr, TG, D, d.eps, s));
     e = epi0(); e.bias = w.fc1_b; e.act = ACT_EPI_GELU; e.aux = keep ? sv.hpre : nullptr; e.ldaux = Hd;
-    CK(linear(TG, Hd, D, sv.n2, w.fc1_w, x3 ? x3->fc1 : nullptr, (size_t)Hd * D, sv.a, e));
+    CK(linear(TG, Hd, D, sv.n2, w.fc1_w, x3 ? x3->fc1 : nullptr, (size_t)Hd * D, sv.a, e, nullptr, mlp_planes ? hid_planes : nullptr));
     e = epi0(); e.bias = w.fc2_b; e.res = sv.x1; e.ldr = D;
-    CK(linear(TG, D, Hd, sv.a, w.fc2_w, x3 ? x3->fc2 : nullptr, (size_t)D * Hd, out, e));
+    CK(linear(TG, D, Hd, sv.a, w.fc2_w, x3 ? x3->fc2 : nullptr, (size_t)D * Hd, out, e, mlp_planes ? hid_planes : nullptr));
     return 0;
 }
 

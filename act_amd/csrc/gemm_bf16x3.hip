@@ -51,12 +51,13 @@ constexpr int LROW = 40;                    // bf16 per LDS row: 32 + 8 pad (80-
 
 struct X3Params {
     const unsigned short *Ah, *Al, *Bh, *Bl;   // planes, row-major [rows][K]
-    float* C; int ldc;
+    float* C; int ldc;                         // fp32 result (nullable when the planes below are given)
+    unsigned short *Oh, *Ol;                   // optional: the result ALSO / INSTEAD as (hi, lo) bf16 planes [M][N] -- the A operand of the next split-bf16 product
     int M, N, K;
     act_gemm_epilogue_t epi;
 };
 
-template <int BM, int BN, int ACT>
+template <int BM, int BN, int ACT, bool PLANES>
 __global__ __launch_bounds__(256, 2) void sgemm_nt_bf16x3_kernel(const X3Params p) {
     constexpr int TM = BM / 32, TN = BN / 32;                 // 16 x 16 tiles per wave (2 x 2 waves)
     constexpr int PA = BM * LROW, PB = BN * LROW;             // bf16 per plane image
@@ -141,10 +142,31 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_bf16x3_kernel(const X3Params 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * (BN / 2) + j * 16 + r;
+            float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int row = m0 + wm * (BM / 2) + i * 16 + g * 4 + q;
-                p.C[(size_t)row * p.ldc + col] = epilogue_apply<ACT>(p.epi, acc[i][j][q], row, col);
+                v[q] = epilogue_apply<ACT>(p.epi, acc[i][j][q], row, col);
+                if (!PLANES || p.C) p.C[(size_t)row * p.ldc + col] = v[q];
+            }
+            if constexpr (PLANES) {
+                // (hi, lo) planes of the result.  A lane owns ONE column of four rows: neighbouring lanes (columns col, col ^ 1) trade two rows each so that
+                // every lane stores packed pairs of bf16 (4-byte stores: even lanes rows 4g + 0, 1; odd lanes rows 4g + 2, 3)
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { h[q] = bf16_rne(v[q]); l[q] = bf16_rne(v[q] - __uint_as_float(h[q] << 16)); }
+                const bool odd = r & 1;
+                const unsigned sh0 = odd ? h[0] : h[2], sh1 = odd ? h[1] : h[3], sl0 = odd ? l[0] : l[2], sl1 = odd ? l[1] : l[3];   // what the neighbour stores
+                const unsigned gh0 = __shfl_xor(sh0, 1), gh1 = __shfl_xor(sh1, 1), gl0 = __shfl_xor(sl0, 1), gl1 = __shfl_xor(sl1, 1);
+                const int rbase = m0 + wm * (BM / 2) + i * 16 + g * 4 + (odd ? 2 : 0), c2 = col & ~1;
+                const unsigned mh0 = odd ? h[2] : h[0], mh1 = odd ? h[3] : h[1], ml0 = odd ? l[2] : l[0], ml1 = odd ? l[3] : l[1];   // my own values of the rows I store
+                // pair = (column c2, column c2 + 1): low half = even column
+                const unsigned ph0 = odd ? (gh0 | (mh0 << 16)) : (mh0 | (gh0 << 16)), ph1 = odd ? (gh1 | (mh1 << 16)) : (mh1 | (gh1 << 16));
+                const unsigned pl0 = odd ? (gl0 | (ml0 << 16)) : (ml0 | (gl0 << 16)), pl1 = odd ? (gl1 | (ml1 << 16)) : (ml1 | (gl1 << 16));
+                *reinterpret_cast<unsigned*>(p.Oh + (size_t)rbase * p.N + c2) = ph0;
+                *reinterpret_cast<unsigned*>(p.Oh + (size_t)(rbase + 1) * p.N + c2) = ph1;
+                *reinterpret_cast<unsigned*>(p.Ol + (size_t)rbase * p.N + c2) = pl0;
+                *reinterpret_cast<unsigned*>(p.Ol + (size_t)(rbase + 1) * p.N + c2) = pl1;
             }
         }
 }
@@ -152,9 +174,16 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_bf16x3_kernel(const X3Params 
 template <int BM, int BN>
 int launch_x3(const X3Params& p, hipStream_t s) {
     const dim3 grid((p.M / BM) * (p.N / BN));
+    const bool planes = p.Oh != nullptr;
     switch (p.epi.act) {
-        case ACT_EPI_NONE: hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_NONE>), grid, dim3(256), 0, s, p); break;
-        case ACT_EPI_GELU: hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_GELU>), grid, dim3(256), 0, s, p); break;
+        case ACT_EPI_NONE:
+            if (planes) hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_NONE, true>), grid, dim3(256), 0, s, p);
+            else        hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_NONE, false>), grid, dim3(256), 0, s, p);
+            break;
+        case ACT_EPI_GELU:
+            if (planes) hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_GELU, true>), grid, dim3(256), 0, s, p);
+            else        hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_GELU, false>), grid, dim3(256), 0, s, p);
+            break;
         default: return ACT_E_BADARG;
     }
     ACT_LAUNCH_CHECK();
@@ -178,11 +207,17 @@ extern "C" int act_sgemm_nt_bf16x3_supported(int M, int N, int K) { return M > 0
 
 extern "C" int act_sgemm_nt_bf16x3_f32(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
                                        float* C, int ldc, const act_gemm_epilogue_t* epilogue, act_stream_t stream) {
-    if (!a_hi || !a_lo || !b_hi || !b_lo || !C) return ACT_E_NULLPTR;
-    if (!act_sgemm_nt_bf16x3_supported(M, N, K) || ldc < N) return ACT_E_BADARG;
-    if ((((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)b_hi | (uintptr_t)b_lo) & 15)) return ACT_E_BADARG;
+    return act_sgemm_nt_bf16x3_planes_f32(M, N, K, a_hi, a_lo, b_hi, b_lo, C, ldc, nullptr, nullptr, epilogue, stream);
+}
+
+extern "C" int act_sgemm_nt_bf16x3_planes_f32(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
+                                              float* C, int ldc, uint16_t* out_hi, uint16_t* out_lo, const act_gemm_epilogue_t* epilogue,
+                                              act_stream_t stream) {
+    if (!a_hi || !a_lo || !b_hi || !b_lo || (!C && !out_hi) || ((out_hi == nullptr) != (out_lo == nullptr))) return ACT_E_NULLPTR;
+    if (!act_sgemm_nt_bf16x3_supported(M, N, K) || (C && ldc < N)) return ACT_E_BADARG;
+    if ((((uintptr_t)a_hi | (uintptr_t)a_lo | (uintptr_t)b_hi | (uintptr_t)b_lo | (uintptr_t)out_hi | (uintptr_t)out_lo) & 15)) return ACT_E_BADARG;
     X3Params p{};
-    p.Ah = a_hi; p.Al = a_lo; p.Bh = b_hi; p.Bl = b_lo; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    p.Ah = a_hi; p.Al = a_lo; p.Bh = b_hi; p.Bl = b_lo; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.Oh = out_hi; p.Ol = out_lo;
     if (epilogue) p.epi = *epilogue; else { p.epi = act_gemm_epilogue_t{}; p.epi.alpha = 1.0f; }
     if (p.epi.accumulate || (p.epi.act != ACT_EPI_NONE && p.epi.act != ACT_EPI_GELU)) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;

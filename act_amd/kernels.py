@@ -200,8 +200,9 @@ def gemm_tn_grouped(pairs, want_bias=True, splits=0):
 # ---- OPT-IN split-bf16 products (csrc/gemm_bf16x3.hip): frozen teacher only, never the default -------------------------------------------------
 _C._declare({"act_split_bf16x2_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
              "act_sgemm_nt_bf16x3_supported": [_i, _i, _i],
-             "act_sgemm_nt_bf16x3_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(GemmEpilogue), _vp]})
-for _n in ("act_split_bf16x2_f32", "act_sgemm_nt_bf16x3_supported", "act_sgemm_nt_bf16x3_f32"):
+             "act_sgemm_nt_bf16x3_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(GemmEpilogue), _vp],
+             "act_sgemm_nt_bf16x3_planes_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(GemmEpilogue), _vp]})
+for _n in ("act_split_bf16x2_f32", "act_sgemm_nt_bf16x3_supported", "act_sgemm_nt_bf16x3_f32", "act_sgemm_nt_bf16x3_planes_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
 
 
@@ -215,7 +216,7 @@ def split_bf16x2(x, out=None):
     return out
 
 
-def gemm_nt_bf16x3(a_planes, b_planes, bias=None, act=EPI_NONE, res=None, out=None):
+def gemm_nt_bf16x3(a_planes, b_planes, bias=None, act=EPI_NONE, res=None, out=None, planes_out=None):
     """C[M,N] = epilogue(a . b^T) with both operands given as (hi, lo) bf16 planes [2, rows, K] (split_bf16x2) and the three products hi.hi + hi.lo + lo.hi
     on the bf16 matrix cores (fp32 accumulation): 4e-6 relative per product.  M, N % 128 == 0, K % 64 == 0.  Opt-in path of the frozen teacher."""
     _, M, Kd = a_planes.shape
@@ -228,6 +229,12 @@ def gemm_nt_bf16x3(a_planes, b_planes, bias=None, act=EPI_NONE, res=None, out=No
         out = torch.empty(M, N, dtype=torch.float32, device=a_planes.device)
     e = GemmEpilogue(alpha=1.0, act=act, accumulate=0, rows_per_scale=0, ldr=(res.stride(0) if res is not None else 0), ldaux=0, res_row_div=0,
                      bias=ptr(bias), rowscale=None, res=ptr(res), aux=None)
+    if planes_out is not None:                               # the result also as (hi, lo) planes [2, M, N] -- the A operand of a following product
+        if planes_out.dtype != torch.bfloat16 or tuple(planes_out.shape) != (2, M, N) or not planes_out.is_contiguous():
+            raise _C.ActHipError("gemm_nt_bf16x3: planes_out must be a contiguous bf16 tensor [2, M, N]")
+        check(lib.act_sgemm_nt_bf16x3_planes_f32(M, N, Kd, ptr(a_planes[0]), ptr(a_planes[1]), ptr(b_planes[0]), ptr(b_planes[1]), ptr(out), out.stride(0),
+                                                 ptr(planes_out[0]), ptr(planes_out[1]), ctypes.byref(e), stream()), "act_sgemm_nt_bf16x3_planes_f32")
+        return out
     check(lib.act_sgemm_nt_bf16x3_f32(M, N, Kd, ptr(a_planes[0]), ptr(a_planes[1]), ptr(b_planes[0]), ptr(b_planes[1]), ptr(out), out.stride(0),
                                       ctypes.byref(e), stream()), "act_sgemm_nt_bf16x3_f32")
     return out

@@ -343,6 +343,10 @@ int act_split_bf16x2_f32(const float* x, int R, int K, int ldx, uint16_t* hi, ui
 int act_sgemm_nt_bf16x3_supported(int M, int N, int K);
 int act_sgemm_nt_bf16x3_f32(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
                             float* C, int ldc, const act_gemm_epilogue_t* epilogue, act_stream_t stream);
+/* the same product with the result ALSO (C != NULL) or ONLY (C == NULL) written as (hi, lo) bf16 planes [M][N]: the A operand of the next split-bf16
+ * product comes straight out of this epilogue (teacher MLP: fc1 + GELU -> planes -> fc2) */
+int act_sgemm_nt_bf16x3_planes_f32(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
+                                   float* C, int ldc, uint16_t* out_hi, uint16_t* out_lo, const act_gemm_epilogue_t* epilogue, act_stream_t stream);
 
 /* ---- GEMM launch-configuration table (host side) ------------------------------------------------------------------------
  * act_sgemm_f32 (no explicit configuration) first consults this table keyed by (a_kmajor, b_kmajor, M, N, K), then its built-in
@@ -455,7 +459,8 @@ size_t act_prefix_vit_scratch_floats(const act_prefix_vit_t* m);
 /* OPT-IN variant (never the default; ACT_TEACHER_BF16X3=1 on the host side): the five Linear products of every block on the split-bf16 kernel
  * (act_sgemm_nt_bf16x3_f32) wherever it takes the shape, everything else as act_prefix_vit_fwd_f32.  w_planes[4 i + {0,1,2,3}] = hi plane of block i's
  * qkv_w [3D][D], proj_w [D][D], fc1_w [hidden][D], fc2_w [D][hidden] (the lo plane follows the hi plane: rows * cols elements further);
- * a_planes: scratch the activations are split into, a_planes_elems >= 2 * max(B*G, B*P) * hidden.  Teacher features move by ~7e-6 of their range. */
+ * a_planes: scratch for activation planes, a_planes_elems >= 2 * B*G * hidden + 2 * max(B*G, B*P) * D (the MLP's hidden activation leaves fc1's epilogue
+ * as planes and never exists in fp32; the other activations are split by a pass).  Teacher features move by ~7e-6 of their range. */
 typedef struct {
     const uint16_t* const* w_planes;          /* [4 * depth] */
     uint16_t* a_planes;

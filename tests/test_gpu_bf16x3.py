@@ -68,6 +68,19 @@ def test_bf16x3_gemm_against_fp64_and_its_own_arithmetic(dev, M, N, Kd, bias, ac
     assert _rel(out, ref32) <= 2e-5
 
 
+def test_bf16x3_planes_output_is_the_split_of_the_fp32_output(dev):
+    """the epilogue can hand its result on as (hi, lo) planes (teacher MLP: fc1 + GELU -> planes -> fc2, the hidden activation never exists in fp32):
+    bit-identical to splitting the fp32 result afterwards"""
+    import act_amd.kernels as K
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(384, 768, generator=g).to(dev); w = (torch.randn(3072, 768, generator=g) * 0.05).to(dev); b = torch.randn(3072, generator=g).to(dev)
+    ap, wp = K.split_bf16x2(a), K.split_bf16x2(w)
+    planes = torch.empty(2, 384, 3072, dtype=torch.bfloat16, device=dev)
+    out = K.gemm_nt_bf16x3(ap, wp, bias=b, act=K.EPI_GELU, planes_out=planes)
+    assert torch.equal(out, K.gemm_nt_bf16x3(ap, wp, bias=b, act=K.EPI_GELU))
+    assert torch.equal(planes, K.split_bf16x2(out))
+
+
 def test_bf16x3_rejects_what_it_does_not_support(dev):
     import act_amd.kernels as K
     from act_amd._C import ActHipError
