@@ -131,18 +131,23 @@ size_t carve_prefix_bwd(float* base, const act_block_dims_t& d, int P, PrefixBwd
 // the launch sequence of one prefix block given the LayerNorm'd prompt rows n1p (shared by the inference stack and the
 // differentiable forward)
 // OPT-IN (act_prefix_vit_fwd_bf16x3_f32): the bf16 (hi, lo) planes of one block's four weights + the scratch its activations are split into
-struct X3Block { const uint16_t *qkv, *proj, *fc1, *fc2; uint16_t* a_planes; size_t a_elems; };
+struct X3Block { const uint16_t *qkv, *proj, *fc1, *fc2; uint16_t* a_planes; size_t a_elems; bool n1p_is_planes; };
+// scratch layout of the split-bf16 path: [0, 2 TG Hd) the planes of the MLP's hidden activation (written by fc1's epilogue, read by fc2), then ONE region of
+// 2 max(TG, TP) D for the planes of whichever other activation is multiplied next (prompt rows -> n1x -> attention output -> n2: each is consumed by the
+// product that follows it on the stream before the next producer overwrites it)
+inline bool x3_fits(const act_block_dims_t& d, int P, size_t a_elems) {
+    const size_t TG = (size_t)d.B * d.S, TP = (size_t)d.B * P;
+    return a_elems >= 2 * TG * d.hidden + 2 * (TG > TP ? TG : TP) * d.D;
+}
 
 int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t& w, const float* x, const float* pos, const float* n1p,
                       bool keep, PrefixSaved& sv, float* out, float* ws, size_t wsb, hipStream_t s, const X3Block* x3 = nullptr) {
     const int B = d.B, G = d.S, D = d.D, H = d.heads, hd = D / H, Hd = d.hidden, TG = B * G, TP = B * P;
     // C = epi(A . W^T): on the f32-input MFMA kernels -- or, for the frozen teacher with the split-bf16 switch on and a shape the kernel takes, A is split into
     // (hi, lo) bf16 planes and multiplied with the weight's planes (W_hi = the sub-block of the plane image; lo plane `wplane` elements behind it)
-    // scratch of the split-bf16 path: [0, 2 TG Hd) the planes of the MLP's hidden activation (written by fc1's epilogue, read by fc2), then the planes of
-    // whichever other activation is being multiplied (2 max(TG, TP) D)
     uint16_t* hid_planes = x3 ? x3->a_planes : nullptr;
     uint16_t* tmp_planes = x3 ? x3->a_planes + (size_t)2 * TG * Hd : nullptr;
-    const bool x3_ok = x3 && !keep && x3->a_elems >= (size_t)2 * TG * Hd + (size_t)2 * (TG > TP ? TG : TP) * D;
+    const bool x3_ok = x3 && !keep && x3_fits(d, P, x3->a_elems);
     // `pre`: A is already there as planes (hi at pre, lo M*K further); `emit`: write the result as planes there instead of fp32 C
     auto linear = [&](int M, int N, int K, const float* A, const float* W, const uint16_t* W_hi, size_t wplane, float* C, const act_gemm_epilogue_t& e,
                       const uint16_t* pre = nullptr, uint16_t* emit = nullptr) -> int {
@@ -161,16 +166,22 @@ int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t
     const bool mlp_planes = x3_ok && x3->fc1 && x3->fc2 && act_sgemm_nt_bf16x3_supported(TG, Hd, D) && act_sgemm_nt_bf16x3_supported(TG, D, Hd);
     act_gemm_epilogue_t e = epi0();
     e.bias = w.qkv_b ? w.qkv_b + D : nullptr;                                                   // K,V rows of the qkv Linear
-    CK(linear(TP, 2 * D, D, n1p, w.qkv_w + (size_t)D * D, x3 ? x3->qkv + (size_t)D * D : nullptr, (size_t)3 * D * D, sv.kvp, e));
-    RUN(act_layernorm_fwd_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, sv.n1x, keep ? sv.mean1 : nullptr, keep ? sv.rstd1 : nullptr, TG, D, d.eps, s));
+    // (n1p_is_planes: the caller's prompt LayerNorm already left the rows as planes in the activation region)
+    CK(linear(TP, 2 * D, D, n1p, w.qkv_w + (size_t)D * D, x3 ? x3->qkv + (size_t)D * D : nullptr, (size_t)3 * D * D, sv.kvp, e,
+              (x3_ok && x3->n1p_is_planes) ? tmp_planes : nullptr));
+    const bool ln1_planes = x3_ok && x3->qkv && act_sgemm_nt_bf16x3_supported(TG, 3 * D, D);          // LayerNorm-1 hands n1x on as planes (xin stays fp32: residual)
+    if (ln1_planes) RUN(act_layernorm_fwd_planes_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, TG, D, d.eps, s));
+    else RUN(act_layernorm_fwd_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, sv.n1x, keep ? sv.mean1 : nullptr, keep ? sv.rstd1 : nullptr, TG, D, d.eps, s));
     e = epi0(); e.bias = w.qkv_b;
-    CK(linear(TG, 3 * D, D, sv.n1x, w.qkv_w, x3 ? x3->qkv : nullptr, (size_t)3 * D * D, sv.qkvx, e));
+    CK(linear(TG, 3 * D, D, sv.n1x, w.qkv_w, x3 ? x3->qkv : nullptr, (size_t)3 * D * D, sv.qkvx, e, ln1_planes ? tmp_planes : nullptr));
     RUN(act_attention_fwd_prefix_f32(sv.kvp, P, sv.qkvx, G, sv.att, keep ? sv.lse : nullptr, B, H, hd, attn_scale(hd), s));
     e = epi0(); e.bias = w.proj_b; e.res = sv.xin; e.ldr = D;
     CK(linear(TG, D, D, sv.att, w.proj_w, x3 ? x3->proj : nullptr, (size_t)D * D, sv.x1, e));
-    RUN(act_layernorm_fwd_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, sv.n2, keep ? sv.mean2 : nullptr, keep ? sv.rstd2 : nullptr, TG, D, d.eps, s));
+    const bool ln2_planes = x3_ok && x3->fc1 && act_sgemm_nt_bf16x3_supported(TG, Hd, D);
+    if (ln2_planes) RUN(act_layernorm_fwd_planes_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, TG, D, d.eps, s));
+    else RUN(act_layernorm_fwd_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, sv.n2, keep ? sv.mean2 : nullptr, keep ? sv.rstd2 : nullptr, TG, D, d.eps, s));
     e = epi0(); e.bias = w.fc1_b; e.act = ACT_EPI_GELU; e.aux = keep ? sv.hpre : nullptr; e.ldaux = Hd;
-    CK(linear(TG, Hd, D, sv.n2, w.fc1_w, x3 ? x3->fc1 : nullptr, (size_t)Hd * D, sv.a, e, nullptr, mlp_planes ? hid_planes : nullptr));
+    CK(linear(TG, Hd, D, sv.n2, w.fc1_w, x3 ? x3->fc1 : nullptr, (size_t)Hd * D, sv.a, e, ln2_planes ? tmp_planes : nullptr, mlp_planes ? hid_planes : nullptr));
     e = epi0(); e.bias = w.fc2_b; e.res = sv.x1; e.ldr = D;
     CK(linear(TG, D, Hd, sv.a, w.fc2_w, x3 ? x3->fc2 : nullptr, (size_t)D * Hd, out, e, mlp_planes ? hid_planes : nullptr));
     return 0;
@@ -467,10 +478,16 @@ static int prefix_vit_fwd(const act_prefix_vit_t* m, const act_vit_bf16x3_t* x3,
     for (int i = 0; i < m->depth; ++i) {
         const act_block_params_t& w = m->blocks[i];
         const uint64_t seed = (m->seed_base + 7919ull * (uint64_t)(i + 1)) & ((1ull << 62) - 1);
+        X3Block xb{};
+        if (x3) xb = X3Block{x3->w_planes[4 * i], x3->w_planes[4 * i + 1], x3->w_planes[4 * i + 2], x3->w_planes[4 * i + 3], x3->a_planes, x3->a_planes_elems, false};
+        if (x3 && xb.qkv && x3_fits(d, m->P, x3->a_planes_elems) && act_sgemm_nt_bf16x3_supported(m->B * m->P, 2 * D, D)) {
+            uint16_t* tp = x3->a_planes + (size_t)2 * TG * m->hidden;                         // the activation region (x3_fits)
+            RUN(act_prompt_layernorm_fwd_planes_f32(m->prompt_tok[i], m->prompt_pos[i], m->B, m->P, D, m->drop_p, seed, m->seed_dev, w.norm1_w, w.norm1_b,
+                                                   m->eps, tp, tp + (size_t)m->B * m->P * D, s));
+            xb.n1p_is_planes = true;
+        } else
         RUN(act_prompt_layernorm_fwd_f32(m->prompt_tok[i], m->prompt_pos[i], m->B, m->P, D, m->drop_p, seed, m->seed_dev, w.norm1_w, w.norm1_b,
                                         m->eps, n1p, s));
-        X3Block xb{};
-        if (x3) xb = X3Block{x3->w_planes[4 * i], x3->w_planes[4 * i + 1], x3->w_planes[4 * i + 2], x3->w_planes[4 * i + 3], x3->a_planes, x3->a_planes_elems};
         CK(prefix_block_core(d, m->P, w, cur, pos, n1p, false, sv, nxt, ws, wsb, s, x3 ? &xb : nullptr));
         float* t = cur; cur = nxt; nxt = t;
     }

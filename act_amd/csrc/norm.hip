@@ -10,12 +10,26 @@
 
 #define LN_MAXV 8          // float4 per lane: D <= 64*4*8 = 2048
 
+// (hi, lo) bf16 planes of four consecutive values (round to nearest even; lo = bf16(x - hi)): the operand form of the opt-in split-bf16 GEMM
+// (gemm_bf16x3.hip) -- same rounding as its split_bf16x2_kernel, so a producer that writes planes is bit-identical to producing fp32 and splitting it
+__device__ __forceinline__ unsigned ln_bf16_rne(float x) { unsigned u = __float_as_uint(x); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; }
+__device__ __forceinline__ void store_planes4(unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, size_t i4, const float4& o) {
+    const float e[4] = {o.x, o.y, o.z, o.w};
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = ln_bf16_rne(e[j]); l[j] = ln_bf16_rne(e[j] - __uint_as_float(h[j] << 16)); }
+    reinterpret_cast<uint2*>(hi)[i4] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    reinterpret_cast<uint2*>(lo)[i4] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
 // y = LN(x + pos) * gamma + beta ; optionally stores xin = x + pos (needed for the residual) ; mean/rstd for backward.
+// y_hi / y_lo (optional): y also (or, with y == NULL, only) as bf16 planes.
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ pos,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ xin_out, float* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int T, int D, float eps) {
+                                                            int T, int D, float eps, unsigned short* __restrict__ y_hi = nullptr,
+                                                            unsigned short* __restrict__ y_lo = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -58,7 +72,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             float4 o;
             o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            yr[c] = o;
+            if (y) yr[c] = o;
+            if (y_hi) store_planes4(y_hi, y_lo, (size_t)row * nv + c, o);
             if (xo) xo[c] = v[i];
         }
     }
@@ -266,7 +281,17 @@ extern "C" int act_layernorm_fwd_f32(const float* x, const float* pos, const flo
     if (T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_LAYERNORM_FWD, s, 0.0, 4.0 * T * (double)D * (2 + (pos ? 1 : 0) + (xin_out ? 1 : 0)));
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, pos, gamma, beta, xin_out, y, mean, rstd, T, D, eps);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, pos, gamma, beta, xin_out, y, mean, rstd, T, D, eps, nullptr, nullptr);
+    ACT_LAUNCH_CHECK(); return 0;
+}
+extern "C" int act_layernorm_fwd_planes_f32(const float* x, const float* pos, const float* gamma, const float* beta, float* xin_out, float* y,
+                                            uint16_t* y_hi, uint16_t* y_lo, int T, int D, float eps, act_stream_t stream) {
+    if (!x || !gamma || !beta || !y_hi || !y_lo) return ACT_E_NULLPTR;
+    if (T < 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV || (((uintptr_t)y_hi | (uintptr_t)y_lo) & 7)) return ACT_E_BADARG;
+    if (T == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_LAYERNORM_FWD, s, 0.0, 4.0 * T * (double)D * (2 + (pos ? 1 : 0) + (xin_out ? 1 : 0)));
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, pos, gamma, beta, xin_out, y, nullptr, nullptr, T, D, eps, y_hi, y_lo);
     ACT_LAUNCH_CHECK(); return 0;
 }
 
@@ -277,7 +302,8 @@ __global__ __launch_bounds__(256) void prompt_layernorm_fwd_kernel(const float* 
                                                                    float drop_p, uint64_t seed, const uint64_t* __restrict__ seed_dev,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float* __restrict__ y, int T, int D,
-                                                                   float eps) {
+                                                                   float eps, unsigned short* __restrict__ y_hi = nullptr,
+                                                                   unsigned short* __restrict__ y_lo = nullptr) {
     if (seed_dev) seed ^= seed_dev[0] * 0x9E3779B97F4A7C15ull;      // device-resident step counter (replayable from a hipGraph)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -328,9 +354,24 @@ __global__ __launch_bounds__(256) void prompt_layernorm_fwd_kernel(const float* 
             float4 o;
             o.x = (v[i].x - mean) * rstd * g.x + b.x; o.y = (v[i].y - mean) * rstd * g.y + b.y;
             o.z = (v[i].z - mean) * rstd * g.z + b.z; o.w = (v[i].w - mean) * rstd * g.w + b.w;
-            yr[c] = o;
+            if (y) yr[c] = o;
+            if (y_hi) store_planes4(y_hi, y_lo, (size_t)row * nv + c, o);
         }
     }
+}
+
+extern "C" int act_prompt_layernorm_fwd_planes_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
+                                                   const uint64_t* seed_dev, const float* gamma, const float* beta, float eps, uint16_t* y_hi,
+                                                   uint16_t* y_lo, act_stream_t stream) {
+    if (!tok || !ppos || !gamma || !beta || !y_hi || !y_lo) return ACT_E_NULLPTR;
+    if (B < 0 || P <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV || drop_p < 0.f || drop_p >= 1.f || (((uintptr_t)y_hi | (uintptr_t)y_lo) & 7)) return ACT_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = B * P;
+    ActProfScope ps(KID_LAYERNORM_FWD, s, 0.0, 4.0 * T * (double)D);
+    hipLaunchKernelGGL(prompt_layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, tok, ppos, P, drop_p, seed, seed_dev, gamma, beta,
+                       (float*)nullptr, T, D, eps, y_hi, y_lo);
+    ACT_LAUNCH_CHECK(); return 0;
 }
 
 extern "C" int act_prompt_layernorm_fwd_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
@@ -342,7 +383,8 @@ extern "C" int act_prompt_layernorm_fwd_f32(const float* tok, const float* ppos,
     hipStream_t s = (hipStream_t)stream;
     const int T = B * P;
     ActProfScope ps(KID_LAYERNORM_FWD, s, 0.0, 4.0 * T * (double)D);
-    hipLaunchKernelGGL(prompt_layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, tok, ppos, P, drop_p, seed, seed_dev, gamma, beta, y, T, D, eps);
+    hipLaunchKernelGGL(prompt_layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, tok, ppos, P, drop_p, seed, seed_dev, gamma, beta, y, T, D, eps,
+                       nullptr, nullptr);
     ACT_LAUNCH_CHECK(); return 0;
 }
 

@@ -343,6 +343,13 @@ int act_split_bf16x2_f32(const float* x, int R, int K, int ldx, uint16_t* hi, ui
 int act_sgemm_nt_bf16x3_supported(int M, int N, int K);
 int act_sgemm_nt_bf16x3_f32(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
                             float* C, int ldc, const act_gemm_epilogue_t* epilogue, act_stream_t stream);
+/* producers that hand their result on as planes (y nullable: planes only): LayerNorm of x + pos, and the prompt rows' dropout + position + LayerNorm;
+ * bit-identical to producing fp32 and splitting it with act_split_bf16x2_f32 */
+int act_layernorm_fwd_planes_f32(const float* x, const float* pos, const float* gamma, const float* beta, float* xin_out, float* y,
+                                 uint16_t* y_hi, uint16_t* y_lo, int T, int D, float eps, act_stream_t stream);
+int act_prompt_layernorm_fwd_planes_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
+                                        const uint64_t* seed_dev, const float* gamma, const float* beta, float eps, uint16_t* y_hi, uint16_t* y_lo,
+                                        act_stream_t stream);
 /* the same product with the result ALSO (C != NULL) or ONLY (C == NULL) written as (hi, lo) bf16 planes [M][N]: the A operand of the next split-bf16
  * product comes straight out of this epilogue (teacher MLP: fc1 + GELU -> planes -> fc2) */
 int act_sgemm_nt_bf16x3_planes_f32(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
