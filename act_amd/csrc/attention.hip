@@ -26,6 +26,7 @@ struct AttnFwdArgs {
     int B, H, Sq, S0, S1;
     float scale;
     float* out; float* lse;              // out [B, Sq, H*HD]; lse [B, H, Sq] or null
+    unsigned short* out_hi; unsigned short* out_lo;   // optional: out ALSO / ONLY (out == null) as (hi, lo) bf16 planes of the same layout (opt-in split-bf16 teacher)
 };
 
 // JT = 32-key tiles per LDS-resident key chunk (Sk <= 128: one chunk; longer sequences: chunks of 128 keys with an online
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
     }
     if (active && q < a.Sq) {
         const float inv_l = 1.0f / l;
-        float* op = a.out + ((size_t)b * a.Sq + q) * (H * HD) + h * HD;
+        const size_t obase = ((size_t)b * a.Sq + q) * (H * HD) + h * HD;
+        float* op = a.out ? a.out + obase : nullptr;
 #pragma unroll
         for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
@@ -283,7 +285,19 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
                 float4 t;
                 t.x = o[dt][g * 4 + 0] * inv_l; t.y = o[dt][g * 4 + 1] * inv_l;
                 t.z = o[dt][g * 4 + 2] * inv_l; t.w = o[dt][g * 4 + 3] * inv_l;
-                *reinterpret_cast<float4*>(op + dt * 32 + 8 * g + 4 * half) = t;
+                if (op) *reinterpret_cast<float4*>(op + dt * 32 + 8 * g + 4 * half) = t;
+                if (a.out_hi) {                                   // same rounding as split_bf16x2_kernel (gemm_bf16x3.hip): bit-identical to splitting `out`
+                    const float e[4] = {t.x, t.y, t.z, t.w};
+                    unsigned hh[4], ll[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        unsigned w_ = __float_as_uint(e[u]); w_ += 0x7FFFu + ((w_ >> 16) & 1u); hh[u] = w_ >> 16;
+                        unsigned x_ = __float_as_uint(e[u] - __uint_as_float(hh[u] << 16)); x_ += 0x7FFFu + ((x_ >> 16) & 1u); ll[u] = x_ >> 16;
+                    }
+                    const size_t oi = obase + dt * 32 + 8 * g + 4 * half;
+                    *reinterpret_cast<uint2*>(a.out_hi + oi) = make_uint2(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16));
+                    *reinterpret_cast<uint2*>(a.out_lo + oi) = make_uint2(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16));
+                }
             }
         if (a.lse && half == 0) a.lse[((size_t)b * H + h) * a.Sq + q] = scale * m + __logf(l);
     }
@@ -1276,7 +1290,7 @@ extern "C" int act_attention_fwd_f32(const float* qkv, float* out, float* lse, i
         r.B = B; r.H = H; r.Sq = S; r.S0 = 0; r.S1 = S; r.scale = scale; r.o = out; r.lse_out = lse;
         return launch_attn_fwd_reg(r, head_dim, s);
     }
-    AttnFwdArgs a;
+    AttnFwdArgs a{};
     a.q = qkv; a.k0 = nullptr; a.v0 = nullptr; a.k1 = qkv + D; a.v1 = qkv + 2 * D;
     a.q_bs = (long long)S * 3 * D; a.kv0_bs = 0; a.kv1_bs = a.q_bs; a.ldq = 3 * D; a.ld0 = 0; a.ld1 = 3 * D;
     a.B = B; a.H = H; a.Sq = S; a.S0 = 0; a.S1 = S; a.scale = scale; a.out = out; a.lse = lse;
@@ -1301,10 +1315,27 @@ extern "C" int act_attention_fwd_prefix_f32(const float* kv0, int S0, const floa
         r.B = B; r.H = H; r.Sq = Sq; r.S0 = S0; r.S1 = Sq; r.scale = scale; r.o = out; r.lse_out = lse;
         return launch_attn_fwd_reg(r, head_dim, s);
     }
-    AttnFwdArgs a;
+    AttnFwdArgs a{};
     a.q = qkv1; a.k0 = kv0; a.v0 = kv0 + D; a.k1 = qkv1 + D; a.v1 = qkv1 + 2 * D;
     a.q_bs = (long long)Sq * 3 * D; a.kv0_bs = (long long)S0 * 2 * D; a.kv1_bs = a.q_bs; a.ldq = 3 * D; a.ld0 = 2 * D; a.ld1 = 3 * D;
     a.B = B; a.H = H; a.Sq = Sq; a.S0 = S0; a.S1 = Sq; a.scale = scale; a.out = out; a.lse = lse;
+    return head_dim == 64 ? launch_attn_fwd<64>(a, s) : launch_attn_fwd<32>(a, s);
+}
+
+// the same forward with the output ALSO (out != NULL) or ONLY (out == NULL) as (hi, lo) bf16 planes [B*Sq][H*hd]: the A operand of a split-bf16 projection
+// (opt-in teacher path, gemm_bf16x3.hip).  LDS-staged kernel only.
+extern "C" int act_attention_fwd_prefix_planes_f32(const float* kv0, int S0, const float* qkv1, int Sq, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                                                   float* lse, int B, int H, int head_dim, float scale, act_stream_t stream) {
+    if (!kv0 || !qkv1 || !out_hi || !out_lo) return ACT_E_NULLPTR;
+    if (B < 0 || Sq <= 0 || S0 < 0 || H <= 0 || (head_dim != 64 && head_dim != 32) || (((uintptr_t)out_hi | (uintptr_t)out_lo) & 7)) return ACT_E_BADARG;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    ActProfScope ps(KID_ATTN_FWD, s, 4.0 * B * H * (double)Sq * (S0 + Sq) * head_dim, 4.0 * B * (double)H * head_dim * (4.0 * Sq + 2.0 * S0));
+    const int D = H * head_dim;
+    AttnFwdArgs a{};
+    a.q = qkv1; a.k0 = kv0; a.v0 = kv0 + D; a.k1 = qkv1 + D; a.v1 = qkv1 + 2 * D;
+    a.q_bs = (long long)Sq * 3 * D; a.kv0_bs = (long long)S0 * 2 * D; a.kv1_bs = a.q_bs; a.ldq = 3 * D; a.ld0 = 2 * D; a.ld1 = 3 * D;
+    a.B = B; a.H = H; a.Sq = Sq; a.S0 = S0; a.S1 = Sq; a.scale = scale; a.out = out; a.lse = lse; a.out_hi = out_hi; a.out_lo = out_lo;
     return head_dim == 64 ? launch_attn_fwd<64>(a, s) : launch_attn_fwd<32>(a, s);
 }
 

@@ -174,9 +174,11 @@ int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t
     else RUN(act_layernorm_fwd_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, sv.n1x, keep ? sv.mean1 : nullptr, keep ? sv.rstd1 : nullptr, TG, D, d.eps, s));
     e = epi0(); e.bias = w.qkv_b;
     CK(linear(TG, 3 * D, D, sv.n1x, w.qkv_w, x3 ? x3->qkv : nullptr, (size_t)3 * D * D, sv.qkvx, e, ln1_planes ? tmp_planes : nullptr));
-    RUN(act_attention_fwd_prefix_f32(sv.kvp, P, sv.qkvx, G, sv.att, keep ? sv.lse : nullptr, B, H, hd, attn_scale(hd), s));
+    const bool att_planes = x3_ok && x3->proj && act_sgemm_nt_bf16x3_supported(TG, D, D);       // the attention output leaves its kernel as planes
+    if (att_planes) RUN(act_attention_fwd_prefix_planes_f32(sv.kvp, P, sv.qkvx, G, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, nullptr, B, H, hd, attn_scale(hd), s));
+    else RUN(act_attention_fwd_prefix_f32(sv.kvp, P, sv.qkvx, G, sv.att, keep ? sv.lse : nullptr, B, H, hd, attn_scale(hd), s));
     e = epi0(); e.bias = w.proj_b; e.res = sv.xin; e.ldr = D;
-    CK(linear(TG, D, D, sv.att, w.proj_w, x3 ? x3->proj : nullptr, (size_t)D * D, sv.x1, e));
+    CK(linear(TG, D, D, sv.att, w.proj_w, x3 ? x3->proj : nullptr, (size_t)D * D, sv.x1, e, att_planes ? tmp_planes : nullptr));
     const bool ln2_planes = x3_ok && x3->fc1 && act_sgemm_nt_bf16x3_supported(TG, Hd, D);
     if (ln2_planes) RUN(act_layernorm_fwd_planes_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, TG, D, d.eps, s));
     else RUN(act_layernorm_fwd_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, sv.n2, keep ? sv.mean2 : nullptr, keep ? sv.rstd2 : nullptr, TG, D, d.eps, s));

@@ -350,6 +350,8 @@ int act_layernorm_fwd_planes_f32(const float* x, const float* pos, const float* 
 int act_prompt_layernorm_fwd_planes_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
                                         const uint64_t* seed_dev, const float* gamma, const float* beta, float eps, uint16_t* y_hi, uint16_t* y_lo,
                                         act_stream_t stream);
+int act_attention_fwd_prefix_planes_f32(const float* kv0, int S0, const float* qkv1, int Sq, float* out, uint16_t* out_hi, uint16_t* out_lo, float* lse,
+                                        int B, int H, int head_dim, float scale, act_stream_t stream);
 /* the same product with the result ALSO (C != NULL) or ONLY (C == NULL) written as (hi, lo) bf16 planes [M][N]: the A operand of the next split-bf16
  * product comes straight out of this epilogue (teacher MLP: fc1 + GELU -> planes -> fc2) */
 int act_sgemm_nt_bf16x3_planes_f32(int M, int N, int K, const uint16_t* a_hi, const uint16_t* a_lo, const uint16_t* b_hi, const uint16_t* b_lo,
