@@ -81,6 +81,25 @@ def test_bf16x3_planes_output_is_the_split_of_the_fp32_output(dev):
     assert torch.equal(planes, K.split_bf16x2(out))
 
 
+def test_producers_that_emit_planes_equal_a_split_of_their_fp32_result(dev):
+    """LayerNorm writing planes == split(LayerNorm) bit for bit; the prefix attention forward writing planes == split(its fp32 output)"""
+    import ctypes
+    import act_amd.kernels as K
+    from act_amd import _C
+    torch.manual_seed(3)
+    x = torch.randn(512, 768, device=dev); pos = 0.1 * torch.randn(512, 768, device=dev)
+    g = 1 + 0.1 * torch.randn(768, device=dev); b = 0.1 * torch.randn(768, device=dev)
+    y, _, _, _ = K.layernorm_fwd(x, pos, g, b, 1e-6, want_stats=False)
+    assert torch.equal(K.layernorm_planes(x, g, b, 1e-6, pos=pos), K.split_bf16x2(y))
+    B, S0, Sq, H, hd = 4, 64, 64, 12, 64
+    kv0 = torch.randn(B * S0, 2 * H * hd, device=dev); qkv = torch.randn(B * Sq, 3 * H * hd, device=dev)
+    out = K.attention_fwd_prefix(kv0, S0, qkv, Sq, B, H, hd)
+    planes = torch.empty(2, B * Sq, H * hd, dtype=torch.bfloat16, device=dev)
+    _C.check(_C.lib.act_attention_fwd_prefix_planes_f32(_C.ptr(kv0), S0, _C.ptr(qkv), Sq, None, _C.ptr(planes[0]), _C.ptr(planes[1]), None, B, H, hd,
+                                                        float(hd) ** -0.5, _C.stream()), "act_attention_fwd_prefix_planes_f32")
+    assert torch.equal(planes, K.split_bf16x2(out))
+
+
 def test_bf16x3_rejects_what_it_does_not_support(dev):
     import act_amd.kernels as K
     from act_amd._C import ActHipError

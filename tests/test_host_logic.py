@@ -339,3 +339,15 @@ def test_announced_batch_marker_does_not_break_pickling():
     t.add_(1)
     assert not _Announced.is_marked(m, t)
     torch.save(m, io.BytesIO())
+
+
+def test_split_bf16_teacher_is_off_unless_asked_for():
+    """the opt-in split-bf16 path of the frozen teacher (ACT_TEACHER_BF16X3) must never be on by default: every headline number is f32-input MFMA"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import act_amd.composite as CP; print(int(CP.TEACHER_BF16X3))"
+    env = {k: v for k, v in os.environ.items() if k != "ACT_TEACHER_BF16X3"}
+    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300).stdout.strip() == "0"
+    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, ACT_TEACHER_BF16X3="1"), capture_output=True, text=True,
+                          timeout=300).stdout.strip() == "1"
