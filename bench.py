@@ -554,6 +554,9 @@ def main():
                                    "reference_formulation_tflops_equiv": (ref_tflop / step_s) if ref_tflop else None,
                                    "note": "executed = sum over every GEMM / attention launch of one step of 2mnk as launched (per GPU); "
                                            "reference_formulation = SURVEY 8(d) FLOPs of the reference's own graph for this batch"}
+        if x3_on:
+            out["roofline"]["step"]["note"] += ("; OPT-IN run: the teacher's ViT products (%.2f TFLOP of the step) ran on the bf16 matrix cores as three products each, "
+                                                 "so `frac` against the f32-input peak is NOT a utilisation figure here" % (table.get("sgemm_nt_bf16x3", {"flops": 0})["flops"] / nprof / 1e12))
         for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma_util_%s.json" % tag)), reverse=True):
             try:
                 pm = json.load(open(pf))
