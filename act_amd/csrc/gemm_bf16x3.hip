@@ -112,10 +112,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_bf16x3_kernel(const X3Params 
         _Pragma("unroll") for (int j_ = 0; j_ < TN; ++j_) {                                                                            \
             bf16x8 bf[2];                                                                                                              \
             _Pragma("unroll") for (int s_ = 0; s_ < 2; ++s_) bf[s_] = *reinterpret_cast<const bf16x8*>(&Bs_[s_ * PB + b_off + j_ * 16 * LROW]); \
-            /* smallest terms first: lo.hi, hi.lo, hi.hi */                                                                            \
-            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_][1], bf[0], acc[i_][j_], 0, 0, 0); \
-            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_][0], bf[1], acc[i_][j_], 0, 0, 0); \
-            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i_][0], bf[0], acc[i_][j_], 0, 0, 0); \
+            /* smallest terms first: lo.hi, hi.lo, hi.hi.  The B fragment is the MFMA's FIRST operand: the 16 x 16 result block comes out transposed in the   */ \
+            /* register layout (lane (r, g) holds row r, columns 4g .. 4g+3), i.e. every lane owns FOUR CONSECUTIVE COLUMNS of one row -> vector epilogue  */ \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[i_][1], acc[i_][j_], 0, 0, 0); \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[1], af[i_][0], acc[i_][j_], 0, 0, 0); \
+            _Pragma("unroll") for (int i_ = 0; i_ < TM; ++i_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[0], af[i_][0], acc[i_][j_], 0, 0, 0); \
         }                                                                                                                              \
     }
     // loads / stores are unconditional: past the end they re-read the last K tile and fill a stage nobody reads (no divergent code around the staging registers)
@@ -136,37 +137,34 @@ __global__ __launch_bounds__(256, 2) void sgemm_nt_bf16x3_kernel(const X3Params 
 #undef X3_LOAD
 #undef X3_STORE
 #undef X3_COMPUTE
-    // epilogue: lane (r, g) holds rows i*16 + 4g + q, column j*16 + r of its wave's 64 x 64 block; same per-element arithmetic and order as the f32 kernels
+    // epilogue: lane (r, g) holds row i*16 + r, columns j*16 + 4g .. 4g+3 of its wave's 64 x 64 block (operands swapped above): one float4 of bias / residual /
+    // result and one 8-byte store per plane, per 16 x 16 block; same per-element arithmetic and order as the f32 kernels (epilogue_apply4_act)
+    const bool vec = (((uintptr_t)p.C | (uintptr_t)p.epi.bias | (uintptr_t)p.epi.res | (uintptr_t)p.epi.aux) & 15) == 0 &&
+                     ((p.ldc | (p.epi.res ? p.epi.ldr : 0) | (p.epi.aux ? p.epi.ldaux : 0)) & 3) == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 16 + r;
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = m0 + wm * (BM / 2) + i * 16 + g * 4 + q;
-                v[q] = epilogue_apply<ACT>(p.epi, acc[i][j][q], row, col);
-                if (!PLANES || p.C) p.C[(size_t)row * p.ldc + col] = v[q];
+            const int row = m0 + wm * (BM / 2) + i * 16 + r;
+            const int col = n0 + wn * (BN / 2) + j * 16 + g * 4;
+            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            if (vec) v = epilogue_apply4_act<ACT>(p.epi, v, row, col);
+            else {
+                v.x = epilogue_apply<ACT>(p.epi, v.x, row, col); v.y = epilogue_apply<ACT>(p.epi, v.y, row, col + 1);
+                v.z = epilogue_apply<ACT>(p.epi, v.z, row, col + 2); v.w = epilogue_apply<ACT>(p.epi, v.w, row, col + 3);
+            }
+            if (!PLANES || p.C) {
+                float* cp = p.C + (size_t)row * p.ldc + col;
+                if (vec) *reinterpret_cast<float4*>(cp) = v; else { cp[0] = v.x; cp[1] = v.y; cp[2] = v.z; cp[3] = v.w; }
             }
             if constexpr (PLANES) {
-                // (hi, lo) planes of the result.  A lane owns ONE column of four rows: neighbouring lanes (columns col, col ^ 1) trade two rows each so that
-                // every lane stores packed pairs of bf16 (4-byte stores: even lanes rows 4g + 0, 1; odd lanes rows 4g + 2, 3)
+                const float e[4] = {v.x, v.y, v.z, v.w};
                 unsigned h[4], l[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { h[q] = bf16_rne(v[q]); l[q] = bf16_rne(v[q] - __uint_as_float(h[q] << 16)); }
-                const bool odd = r & 1;
-                const unsigned sh0 = odd ? h[0] : h[2], sh1 = odd ? h[1] : h[3], sl0 = odd ? l[0] : l[2], sl1 = odd ? l[1] : l[3];   // what the neighbour stores
-                const unsigned gh0 = __shfl_xor(sh0, 1), gh1 = __shfl_xor(sh1, 1), gl0 = __shfl_xor(sl0, 1), gl1 = __shfl_xor(sl1, 1);
-                const int rbase = m0 + wm * (BM / 2) + i * 16 + g * 4 + (odd ? 2 : 0), c2 = col & ~1;
-                const unsigned mh0 = odd ? h[2] : h[0], mh1 = odd ? h[3] : h[1], ml0 = odd ? l[2] : l[0], ml1 = odd ? l[3] : l[1];   // my own values of the rows I store
-                // pair = (column c2, column c2 + 1): low half = even column
-                const unsigned ph0 = odd ? (gh0 | (mh0 << 16)) : (mh0 | (gh0 << 16)), ph1 = odd ? (gh1 | (mh1 << 16)) : (mh1 | (gh1 << 16));
-                const unsigned pl0 = odd ? (gl0 | (ml0 << 16)) : (ml0 | (gl0 << 16)), pl1 = odd ? (gl1 | (ml1 << 16)) : (ml1 | (gl1 << 16));
-                *reinterpret_cast<unsigned*>(p.Oh + (size_t)rbase * p.N + c2) = ph0;
-                *reinterpret_cast<unsigned*>(p.Oh + (size_t)(rbase + 1) * p.N + c2) = ph1;
-                *reinterpret_cast<unsigned*>(p.Ol + (size_t)rbase * p.N + c2) = pl0;
-                *reinterpret_cast<unsigned*>(p.Ol + (size_t)(rbase + 1) * p.N + c2) = pl1;
+                for (int q = 0; q < 4; ++q) { h[q] = bf16_rne(e[q]); l[q] = bf16_rne(e[q] - __uint_as_float(h[q] << 16)); }
+                const size_t o = (size_t)row * p.N + col;                 // N % 128 == 0, col % 4 == 0: 8-byte aligned
+                *reinterpret_cast<uint2*>(p.Oh + o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(p.Ol + o) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
             }
         }
 }
