@@ -142,16 +142,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_planes(const unsigned short*
 }
 
 // ---- v2: double-buffered LDS (one barrier per K tile) + global prefetch distance 2 in registers (two staging sets), same fragment layout / products
-template <int BM, int BN, int OCC>
-__global__ __launch_bounds__(256, OCC) void gemm_nt_planes2(const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp,
+template <int BM, int BN, int OCC, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void gemm_nt_planes2(const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp,
                                                             float* __restrict__ C, int M, int N, int K) {
-    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int NT = 64 * WM * WN, RPP = NT / 4;               // threads, staged rows per pass
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);
     constexpr int PA = BM * LROW, PB = BN * LROW;
-    constexpr int NA = BM / 64, NB = BN / 64;
+    constexpr int NA = BM / RPP, NB = BN / RPP;
     constexpr int STAGE = NP * (PA + PB);
     __shared__ __attribute__((aligned(16))) unsigned short L[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = N / BN, tiles_m = M / BM;
     int wg = blockIdx.x;
     {
@@ -176,16 +177,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_planes2(const unsigned short
     u32x4v ra0[NP][NA], rb0[NP][NB], ra1[NP][NA], rb1[NP][NB];       // two staging sets as separate arrays, touched only by fully unrolled macro bodies
     const int s_off = srow * LROW + sch * 8;
     const int r = lane & 15, g = lane >> 4;
-    const int a_off = (wm * (BM / 2) + r) * LROW + g * 8, b_off = (wn * (BN / 2) + r) * LROW + g * 8;
+    const int a_off = (wm * (BM / WM) + r) * LROW + g * 8, b_off = (wn * (BN / WN) + r) * LROW + g * 8;
 #define LOAD_G(RA, RB, T)                                                                                                             \
     _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_) {                                                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) RA[s_][i_] = *reinterpret_cast<const u32x4v*>(ga + s_ * planeA + (size_t)(64 * i_) * K + (T) * BK); \
-        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) RB[s_][i_] = *reinterpret_cast<const u32x4v*>(gb + s_ * planeB + (size_t)(64 * i_) * K + (T) * BK); \
+        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) RA[s_][i_] = *reinterpret_cast<const u32x4v*>(ga + s_ * planeA + (size_t)(RPP * i_) * K + (T) * BK); \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) RB[s_][i_] = *reinterpret_cast<const u32x4v*>(gb + s_ * planeB + (size_t)(RPP * i_) * K + (T) * BK); \
     }
 #define STORE_LDS(RA, RB, STG)                                                                                                        \
     _Pragma("unroll") for (int s_ = 0; s_ < NP; ++s_) {                                                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) *reinterpret_cast<u32x4v*>(&L[(STG) * STAGE + s_ * PA + s_off + 64 * i_ * LROW]) = RA[s_][i_];            \
-        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) *reinterpret_cast<u32x4v*>(&L[(STG) * STAGE + NP * PA + s_ * PB + s_off + 64 * i_ * LROW]) = RB[s_][i_];  \
+        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) *reinterpret_cast<u32x4v*>(&L[(STG) * STAGE + s_ * PA + s_off + RPP * i_ * LROW]) = RA[s_][i_];            \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) *reinterpret_cast<u32x4v*>(&L[(STG) * STAGE + NP * PA + s_ * PB + s_off + RPP * i_ * LROW]) = RB[s_][i_];  \
     }
 #define COMPUTE(STG)                                                                                                                  \
     {                                                                                                                                 \
@@ -228,9 +229,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_planes2(const unsigned short
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * (BN / 2) + j * 16 + r;
+            const int col = n0 + wn * (BN / WN) + j * 16 + r;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) C[(size_t)(m0 + wm * (BM / 2) + i * 16 + g * 4 + q) * N + col] = acc[i][j][q];
+            for (int q = 0; q < 4; ++q) C[(size_t)(m0 + wm * (BM / WM) + i * 16 + g * 4 + q) * N + col] = acc[i][j][q];
         }
 }
 
@@ -264,17 +265,17 @@ static void run(const char* name, const unsigned short* dAp, const unsigned shor
            grid.x, ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12, 6.0 * M * N * K / (ms * 1e-3) / 1e12, emax / rmax, sqrt(e2 / r2));
 }
 
-template <int BM, int BN, int OCC>
+template <int BM, int BN, int OCC, int WM = 2, int WN = 2>
 static void run2(const char* name, const unsigned short* dAp, const unsigned short* dBp, float* dC, int M, int N, int K, const std::vector<float>& hA,
                  const std::vector<float>& hB) {
     if (M % BM || N % BN) return;
     dim3 grid((M / BM) * (N / BN));
-    hipLaunchKernelGGL((gemm_nt_planes2<BM, BN, OCC>), grid, dim3(256), 0, 0, dAp, dBp, dC, M, N, K);
+    hipLaunchKernelGGL((gemm_nt_planes2<BM, BN, OCC, WM, WN>), grid, dim3(64 * WM * WN), 0, 0, dAp, dBp, dC, M, N, K);
     HIPCHECK(hipDeviceSynchronize());
     hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
     const int reps = 20;
     HIPCHECK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_nt_planes2<BM, BN, OCC>), grid, dim3(256), 0, 0, dAp, dBp, dC, M, N, K);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((gemm_nt_planes2<BM, BN, OCC, WM, WN>), grid, dim3(64 * WM * WN), 0, 0, dAp, dBp, dC, M, N, K);
     HIPCHECK(hipEventRecord(e1)); HIPCHECK(hipEventSynchronize(e1));
     float ms; HIPCHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     const int rows = 48;
@@ -321,6 +322,9 @@ int main(int argc, char** argv) {
     run<128, 128, 2, 4>("  no lds store", dAp, dBp, dC, M, N, K, hA, hB);
     run2<128, 128, 2>("v2 128x128 occ2", dAp, dBp, dC, M, N, K, hA, hB);
     run2<128, 128, 1>("v2 128x128 occ1", dAp, dBp, dC, M, N, K, hA, hB);
+    run2<256, 128, 1, 4, 2>("v2 256x128 8w", dAp, dBp, dC, M, N, K, hA, hB);
+    run2<128, 256, 1, 2, 4>("v2 128x256 8w", dAp, dBp, dC, M, N, K, hA, hB);
+    run2<256, 256, 1, 4, 4>("v2 256x256 16w", dAp, dBp, dC, M, N, K, hA, hB);
     run2<128, 64, 2>("v2 128x64 occ2", dAp, dBp, dC, M, N, K, hA, hB);
     run2<128, 64, 3>("v2 128x64 occ3", dAp, dBp, dC, M, N, K, hA, hB);
     run<128, 64, 2>("128x64 occ2", dAp, dBp, dC, M, N, K, hA, hB);

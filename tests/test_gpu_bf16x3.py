@@ -155,3 +155,41 @@ def test_teacher_features_with_split_bf16_stay_inside_the_parity_bar(dev):
     print(f"split-bf16 teacher: max|e|/max|ref| vs f32 HIP path {e32:.2e}, vs CPU oracle {eo:.2e} (f32 path vs oracle {_rel(f32_a, tf_o):.2e})")
     assert e32 <= 1e-4 and eo <= 1e-4
     assert e32 <= 3e-5                                            # far inside the bar, as the oracle emulation predicts
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_split_bf16_teacher_at_the_stress_geometry_and_with_mixed_kernels(dev, B):
+    """configs[4] geometry (64 prompts + 512 tokens, d = 768): at B = 1 the prompt rows (64) are not a multiple of the kernel's 128-row tile, so the K / V product of
+    the prompts stays on the f32 kernel while the other four go to the split-bf16 kernel (the per-product fallback inside one block); at B = 2 all five go.
+    Features within 1e-4 of the f32 path either way."""
+    import act_amd.composite as CP
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import cfg_from_yaml_file
+    from act_amd.utils.draws import Draws
+    from tests.golden.fill import clouds
+    cfg = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml").model
+    cfg.dvae_config.ckpt = "none"
+    for k in ("encoder_dims", "tokens_dims", "decoder_dims"):
+        cfg.dvae_config[k] = 768
+    cfg.dvae_config.num_group = 512; cfg.dvae_config.group_size = 64
+    cfg.transformer_config.embed_dim = 768; cfg.transformer_config.encoder_dims = 768; cfg.transformer_config.depth = 2
+    cfg.transformer_config.num_heads = 12; cfg.transformer_config.decoder_num_heads = 12
+    torch.manual_seed(4)
+    model = build_model_from_cfg(cfg).to(dev).train()
+    model.dvae_tokenizer.prompt_dropout.p = 0.0
+    pts = torch.from_numpy(clouds(9, B, 8192)).to(dev)
+    gum = -torch.empty(B, 512, 8192).exponential_().log()
+    saved = CP.TEACHER_BF16X3
+    try:
+        with torch.no_grad():
+            nb, c = model.group_divider(pts)
+            CP.TEACHER_BF16X3 = False
+            f32 = model.dvae_tokenizer.forward_tokenizer_features(nb, c, draws=Draws({"gumbel": gum}, device=dev))
+            CP.TEACHER_BF16X3 = True
+            x3 = model.dvae_tokenizer.forward_tokenizer_features(nb, c, draws=Draws({"gumbel": gum}, device=dev))
+    finally:
+        CP.TEACHER_BF16X3 = saved
+    assert not torch.equal(x3, f32)
+    e = _rel(x3, f32)
+    print(f"stress geometry B={B}: split-bf16 teacher vs f32 path {e:.2e}")
+    assert e <= 3e-5
