@@ -98,6 +98,7 @@ _SIGS = {
     "act_prefix_block_saved_floats": [_P(BlockDims), _i],
     "act_prefix_block_bwd_scratch_floats": [_P(BlockDims), _i],
     "act_prefix_block_fwd_f32": [_P(BlockDims), _i, _P(BlockParams), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_prefix_block_fwd_bf16x3_f32": [_P(BlockDims), _i, _P(BlockParams), _P(VitBf16x3), _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
     "act_prefix_block_bwd_f32": [_P(BlockDims), _i, _P(BlockParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "act_prefix_vit_scratch_floats": [_P(PrefixVit)],
     "act_prefix_vit_fwd_f32": [_P(PrefixVit), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -467,7 +468,13 @@ class PrefixBlockFn(torch.autograd.Function):
         ws = K.workspace(dev)
         args = (ctypes.byref(dims), P, ctypes.byref(prm), _p(x2d), _p(pos2d), _p(prm2d), None, 1, _p(saved), _p(out), _p(ws), ws.numel() * 4)
         ensure_tuned(("pfx_fwd", B, G, D, heads, w1.shape[0], P), lambda: lib.act_prefix_block_fwd_f32(*args, _C.stream()), dev)
-        check(lib.act_prefix_block_fwd_f32(*args, _C.stream()), "act_prefix_block_fwd_f32")
+        if TEACHER_BF16X3 and not any(w.requires_grad for w in (wqkv, wproj, w1, w2)):
+            # OPT-IN: the frozen block's products in split-bf16 (the backward stays f32: it reads only what this forward still writes in fp32)
+            x3, keep = _block_planes((wqkv, wproj, w1, w2), B * G * w1.shape[0] + B * max(G, P) * D, dev)
+            check(lib.act_prefix_block_fwd_bf16x3_f32(*args[:3], ctypes.byref(x3), *args[3:6], 1, *args[8:], _C.stream()), "act_prefix_block_fwd_bf16x3_f32")
+            del keep
+        else:
+            check(lib.act_prefix_block_fwd_f32(*args, _C.stream()), "act_prefix_block_fwd_f32")
         ctx.save_for_backward(saved, prm2d, n1w, wqkv, wproj, n2w, w1, w2)
         ctx.dims = (B, P, G, D, heads, w1.shape[0], eps)
         return out
@@ -578,6 +585,24 @@ def prefix_vit_forward(tok, tokens, center, drop_p, seed_base, seed_dev):
         return out
     check(lib.act_prefix_vit_fwd_f32(*args, _C.stream()), "act_prefix_vit_fwd_f32")
     return out
+
+
+_BLOCK_PLANES = {}     # id(qkv weight Parameter) -> (weak reference to it, signature, planes, pointer array) of ONE frozen block; the entry dies with the Parameter
+#                        (not a WeakKeyDictionary: tensors as dictionary keys compare element-wise on a hash collision)
+
+
+def _block_planes(ws_, act_elems, dev):
+    """Same for the four weights of one frozen block of the differentiable Stage-I forward (PrefixBlockFn), cached on the qkv Parameter."""
+    sig = tuple((w.data_ptr(), w._version) for w in ws_)
+    key = id(ws_[0])
+    cache = _BLOCK_PLANES.get(key)
+    if cache is None or cache[0]() is not ws_[0] or cache[1] != sig:
+        with torch.no_grad():
+            planes = [K.split_bf16x2(w.detach()) for w in ws_]
+        parr = (_vp * 4)(*[pl.data_ptr() for pl in planes])
+        cache = _BLOCK_PLANES[key] = (weakref.ref(ws_[0], lambda _, k=key: _BLOCK_PLANES.pop(k, None)), sig, planes, parr)
+    a_planes = torch.empty(2 * act_elems, dtype=torch.bfloat16, device=dev)
+    return VitBf16x3(ctypes.cast(cache[3], _vp), a_planes.data_ptr(), a_planes.numel()), (a_planes, cache)
 
 
 def _vit_planes(tok, ts, depth, act_elems, dev):

@@ -147,7 +147,9 @@ int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t
     // (hi, lo) bf16 planes and multiplied with the weight's planes (W_hi = the sub-block of the plane image; lo plane `wplane` elements behind it)
     uint16_t* hid_planes = x3 ? x3->a_planes : nullptr;
     uint16_t* tmp_planes = x3 ? x3->a_planes + (size_t)2 * TG * Hd : nullptr;
-    const bool x3_ok = x3 && !keep && x3_fits(d, P, x3->a_elems);
+    // (keep: the differentiable forward of Stage-I prompt tuning.  Its backward never needs n1x / n2 / a in fp32 -- the block weights are frozen, no dW --, only the
+    //  LayerNorm statistics, the pre-GELU values, xin, x1, qkvx, kvp, att and lse, all of which are still written)
+    const bool x3_ok = x3 && x3_fits(d, P, x3->a_elems);
     // `pre`: A is already there as planes (hi at pre, lo M*K further); `emit`: write the result as planes there instead of fp32 C
     auto linear = [&](int M, int N, int K, const float* A, const float* W, const uint16_t* W_hi, size_t wplane, float* C, const act_gemm_epilogue_t& e,
                       const uint16_t* pre = nullptr, uint16_t* emit = nullptr) -> int {
@@ -170,17 +172,20 @@ int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t
     CK(linear(TP, 2 * D, D, n1p, w.qkv_w + (size_t)D * D, x3 ? x3->qkv + (size_t)D * D : nullptr, (size_t)3 * D * D, sv.kvp, e,
               (x3_ok && x3->n1p_is_planes) ? tmp_planes : nullptr));
     const bool ln1_planes = x3_ok && x3->qkv && act_sgemm_nt_bf16x3_supported(TG, 3 * D, D);          // LayerNorm-1 hands n1x on as planes (xin stays fp32: residual)
-    if (ln1_planes) RUN(act_layernorm_fwd_planes_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, TG, D, d.eps, s));
+    if (ln1_planes) RUN(act_layernorm_fwd_planes_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, keep ? sv.mean1 : nullptr,
+                                                     keep ? sv.rstd1 : nullptr, TG, D, d.eps, s));
     else RUN(act_layernorm_fwd_f32(x, pos, w.norm1_w, w.norm1_b, sv.xin, sv.n1x, keep ? sv.mean1 : nullptr, keep ? sv.rstd1 : nullptr, TG, D, d.eps, s));
     e = epi0(); e.bias = w.qkv_b;
     CK(linear(TG, 3 * D, D, sv.n1x, w.qkv_w, x3 ? x3->qkv : nullptr, (size_t)3 * D * D, sv.qkvx, e, ln1_planes ? tmp_planes : nullptr));
     const bool att_planes = x3_ok && x3->proj && act_sgemm_nt_bf16x3_supported(TG, D, D);       // the attention output leaves its kernel as planes
-    if (att_planes) RUN(act_attention_fwd_prefix_planes_f32(sv.kvp, P, sv.qkvx, G, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, nullptr, B, H, hd, attn_scale(hd), s));
+    if (att_planes) RUN(act_attention_fwd_prefix_planes_f32(sv.kvp, P, sv.qkvx, G, keep ? sv.att : nullptr, tmp_planes, tmp_planes + (size_t)TG * D, keep ? sv.lse : nullptr,
+                                                            B, H, hd, attn_scale(hd), s));
     else RUN(act_attention_fwd_prefix_f32(sv.kvp, P, sv.qkvx, G, sv.att, keep ? sv.lse : nullptr, B, H, hd, attn_scale(hd), s));
     e = epi0(); e.bias = w.proj_b; e.res = sv.xin; e.ldr = D;
     CK(linear(TG, D, D, sv.att, w.proj_w, x3 ? x3->proj : nullptr, (size_t)D * D, sv.x1, e, att_planes ? tmp_planes : nullptr));
     const bool ln2_planes = x3_ok && x3->fc1 && act_sgemm_nt_bf16x3_supported(TG, Hd, D);
-    if (ln2_planes) RUN(act_layernorm_fwd_planes_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, TG, D, d.eps, s));
+    if (ln2_planes) RUN(act_layernorm_fwd_planes_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, nullptr, tmp_planes, tmp_planes + (size_t)TG * D, keep ? sv.mean2 : nullptr,
+                                                     keep ? sv.rstd2 : nullptr, TG, D, d.eps, s));
     else RUN(act_layernorm_fwd_f32(sv.x1, nullptr, w.norm2_w, w.norm2_b, nullptr, sv.n2, keep ? sv.mean2 : nullptr, keep ? sv.rstd2 : nullptr, TG, D, d.eps, s));
     e = epi0(); e.bias = w.fc1_b; e.act = ACT_EPI_GELU; e.aux = keep ? sv.hpre : nullptr; e.ldaux = Hd;
     CK(linear(TG, Hd, D, sv.n2, w.fc1_w, x3 ? x3->fc1 : nullptr, (size_t)Hd * D, sv.a, e, ln2_planes ? tmp_planes : nullptr, mlp_planes ? hid_planes : nullptr));
@@ -404,6 +409,28 @@ int act_prefix_block_fwd_f32(const act_block_dims_t* d, int P, const act_block_p
         n1p = sv.n1p;
     }
     return prefix_block_core(*d, P, *w, x, pos, n1p, keep, sv, out, ws, wsb, s);
+}
+
+// OPT-IN: the same forward with the block's four (frozen) weights given as (hi, lo) bf16 planes: every product whose shape the split-bf16 kernel takes runs there
+// (w_planes[0..3] = hi planes of qkv_w, proj_w, fc1_w, fc2_w, lo plane behind each; a_planes as in act_vit_bf16x3_t).  The backward is unchanged (f32).
+int act_prefix_block_fwd_bf16x3_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const act_vit_bf16x3_t* x3, const float* x, const float* pos,
+                                    const float* prm, int keep_for_backward, float* saved, float* out, float* ws, size_t wsb, act_stream_t stream) {
+    if (!w || !x || !saved || !out || !prm || !x3 || !x3->w_planes || !x3->a_planes) return ACT_E_NULLPTR;
+    if (bad_dims(d) || P <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bool keep = keep_for_backward != 0;
+    PrefixSaved sv; carve_prefix(saved, *d, P, sv);
+    X3Block xb{x3->w_planes[0], x3->w_planes[1], x3->w_planes[2], x3->w_planes[3], x3->a_planes, x3->a_planes_elems, false};
+    const int TP = d->B * P, D = d->D;
+    if (xb.qkv && x3_fits(*d, P, xb.a_elems) && act_sgemm_nt_bf16x3_supported(TP, 2 * D, D)) {
+        uint16_t* tp = xb.a_planes + (size_t)2 * d->B * d->S * d->hidden;
+        RUN(act_layernorm_fwd_planes_f32(prm, nullptr, w->norm1_w, w->norm1_b, nullptr, nullptr, tp, tp + (size_t)TP * D, keep ? sv.meanp : nullptr,
+                                        keep ? sv.rstdp : nullptr, TP, D, d->eps, s));
+        xb.n1p_is_planes = true;
+    } else {
+        RUN(act_layernorm_fwd_f32(prm, nullptr, w->norm1_w, w->norm1_b, nullptr, sv.n1p, keep ? sv.meanp : nullptr, keep ? sv.rstdp : nullptr, TP, D, d->eps, s));
+    }
+    return prefix_block_core(*d, P, *w, x, pos, sv.n1p, keep, sv, out, ws, wsb, s, &xb);
 }
 
 int act_prefix_block_bwd_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const float* prm, const float* saved,

@@ -285,13 +285,13 @@ extern "C" int act_layernorm_fwd_f32(const float* x, const float* pos, const flo
     ACT_LAUNCH_CHECK(); return 0;
 }
 extern "C" int act_layernorm_fwd_planes_f32(const float* x, const float* pos, const float* gamma, const float* beta, float* xin_out, float* y,
-                                            uint16_t* y_hi, uint16_t* y_lo, int T, int D, float eps, act_stream_t stream) {
+                                            uint16_t* y_hi, uint16_t* y_lo, float* mean, float* rstd, int T, int D, float eps, act_stream_t stream) {
     if (!x || !gamma || !beta || !y_hi || !y_lo) return ACT_E_NULLPTR;
     if (T < 0 || D <= 0 || (D & 3) || D > 64 * 4 * LN_MAXV || (((uintptr_t)y_hi | (uintptr_t)y_lo) & 7)) return ACT_E_BADARG;
     if (T == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_LAYERNORM_FWD, s, 0.0, 4.0 * T * (double)D * (2 + (pos ? 1 : 0) + (xin_out ? 1 : 0)));
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, pos, gamma, beta, xin_out, y, nullptr, nullptr, T, D, eps, y_hi, y_lo);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, s, x, pos, gamma, beta, xin_out, y, mean, rstd, T, D, eps, y_hi, y_lo);
     ACT_LAUNCH_CHECK(); return 0;
 }
 

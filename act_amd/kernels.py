@@ -203,7 +203,7 @@ _C._declare({"act_split_bf16x2_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
              "act_sgemm_nt_bf16x3_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, ctypes.POINTER(GemmEpilogue), _vp],
              "act_sgemm_nt_bf16x3_planes_f32": [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, ctypes.POINTER(GemmEpilogue), _vp],
              # producers that emit planes (used from C by the teacher composite; declared here so the binding covers the whole header)
-             "act_layernorm_fwd_planes_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+             "act_layernorm_fwd_planes_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
              "act_prompt_layernorm_fwd_planes_f32": [_vp, _vp, _i, _i, _i, _f, ctypes.c_uint64, _vp, _vp, _vp, _f, _vp, _vp, _vp],
              "act_attention_fwd_prefix_planes_f32": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]})
 for _n in ("act_split_bf16x2_f32", "act_sgemm_nt_bf16x3_supported", "act_sgemm_nt_bf16x3_f32", "act_sgemm_nt_bf16x3_planes_f32",
@@ -227,7 +227,7 @@ def layernorm_planes(x, gamma, beta, eps, pos=None):
     T, D = x.shape
     planes = torch.empty(2, T, D, dtype=torch.bfloat16, device=x.device)
     check(lib.act_layernorm_fwd_planes_f32(ptr(x), ptr(_f32c(pos)) if pos is not None else None, ptr(gamma), ptr(beta), None, None, ptr(planes[0]), ptr(planes[1]),
-                                           T, D, float(eps), stream()), "act_layernorm_fwd_planes_f32")
+                                           None, None, T, D, float(eps), stream()), "act_layernorm_fwd_planes_f32")
     return planes
 
 

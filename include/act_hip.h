@@ -346,7 +346,8 @@ int act_sgemm_nt_bf16x3_f32(int M, int N, int K, const uint16_t* a_hi, const uin
 /* producers that hand their result on as planes (y nullable: planes only): LayerNorm of x + pos, and the prompt rows' dropout + position + LayerNorm;
  * bit-identical to producing fp32 and splitting it with act_split_bf16x2_f32 */
 int act_layernorm_fwd_planes_f32(const float* x, const float* pos, const float* gamma, const float* beta, float* xin_out, float* y,
-                                 uint16_t* y_hi, uint16_t* y_lo, int T, int D, float eps, act_stream_t stream);
+                                 uint16_t* y_hi, uint16_t* y_lo, float* mean /* nullable */, float* rstd /* nullable */, int T, int D, float eps,
+                                 act_stream_t stream);
 int act_prompt_layernorm_fwd_planes_f32(const float* tok, const float* ppos, int B, int P, int D, float drop_p, uint64_t seed,
                                         const uint64_t* seed_dev, const float* gamma, const float* beta, float eps, uint16_t* y_hi, uint16_t* y_lo,
                                         act_stream_t stream);
@@ -477,6 +478,11 @@ typedef struct {
 } act_vit_bf16x3_t;
 int act_prefix_vit_fwd_bf16x3_f32(const act_prefix_vit_t* m, const act_vit_bf16x3_t* x3, const float* tokens, const float* center, float* out,
                                   float* scratch, float* workspace, size_t workspace_bytes, act_stream_t stream);
+/* ... and the differentiable forward of ONE prefix block (Stage-I prompt tuning) the same way: x3->w_planes[0..3] = this block's four weights; the backward
+ * (act_prefix_block_bwd_f32) is unchanged, everything it reads is still written. */
+int act_prefix_block_fwd_bf16x3_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const act_vit_bf16x3_t* x3, const float* x, const float* pos,
+                                    const float* prm, int keep_for_backward, float* saved, float* out, float* workspace, size_t workspace_bytes,
+                                    act_stream_t stream);
 int act_prefix_vit_fwd_f32(const act_prefix_vit_t* m, const float* tokens, const float* center, float* out, float* scratch,
                            float* workspace, size_t workspace_bytes, act_stream_t stream);
 

@@ -193,3 +193,93 @@ def test_split_bf16_teacher_at_the_stress_geometry_and_with_mixed_kernels(dev, B
     e = _rel(x3, f32)
     print(f"stress geometry B={B}: split-bf16 teacher vs f32 path {e:.2e}")
     assert e <= 3e-5
+
+
+@pytest.mark.parametrize("B,P,G", [(4, 32, 64), (2, 24, 64)])
+def test_stage1_prefix_block_forward_in_split_bf16_keeps_the_f32_backward_exact_enough(dev, B, P, G):
+    """The differentiable prefix block of Stage-I prompt tuning (composite.PrefixBlockFn) with the switch on: the frozen block's forward products run on the
+    split-bf16 kernel (B=4, P=32: all five; B=2, P=24: the prompt K/V product -- 48 rows -- stays f32), the backward is the unchanged f32 one reading what the
+    forward still writes in fp32.  Output and the gradients w.r.t. tokens, positions and prompts within 3e-5 of the all-f32 path (bar 1e-4)."""
+    import act_amd.composite as CP
+    D, H, Hd = 768, 12, 3072
+    g = torch.Generator().manual_seed(31)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    prm_ = [1 + rn(D, sc=0.1), rn(D, sc=0.1), rn(3 * D, D, sc=D ** -0.5), rn(3 * D, sc=0.02), rn(D, D, sc=D ** -0.5), rn(D, sc=0.02),
+            1 + rn(D, sc=0.1), rn(D, sc=0.1), rn(Hd, D, sc=D ** -0.5), rn(Hd, sc=0.02), rn(D, Hd, sc=Hd ** -0.5), rn(D, sc=0.02)]
+    x0, p0, m0, w = rn(B * G, D), rn(B * G, D, sc=0.2), rn(B * P, D, sc=0.3), rn(B * G, D)
+
+    def run(on):
+        saved = CP.TEACHER_BF16X3
+        CP.TEACHER_BF16X3 = on
+        try:
+            x, p, m = (t.clone().requires_grad_(True) for t in (x0, p0, m0))
+            y = CP.PrefixBlockFn.apply(x, p, m, B, P, G, *prm_, H, 1e-6)
+            (y * w).sum().backward()
+            return y.detach(), x.grad, p.grad, m.grad
+        finally:
+            CP.TEACHER_BF16X3 = saved
+    ref, got = run(False), run(True)
+    assert not torch.equal(got[0], ref[0])                        # the split-bf16 kernel really ran
+    for name, a, b in zip(("out", "dx", "dpos", "dprompt"), got, ref):
+        e = _rel(a, b)
+        print(f"stage-I prefix block B={B} P={P} {name}: split-bf16 forward vs f32 {e:.2e}")
+        assert e <= 3e-5, (name, e)
+    # a block whose weights train is never routed there
+    prm_[2].requires_grad_(True)
+    try:
+        again = run(True)
+    finally:
+        prm_[2].requires_grad_(False)
+    assert torch.equal(again[0], ref[0])
+
+
+def test_stage1_step_with_split_bf16_forward_matches_the_f32_step(dev):
+    """One Stage-I step of the shipped configs[2] model at B=8 with the switch on vs off, every draw replayed: losses, fine reconstruction within 1e-4.  The
+    gradients of this graph are discontinuous in its activations (Chamfer arg-min, max-pool and ReLU decisions reroute whole gradient rows: the same reason the
+    oracle comparison of tests/test_gpu_model.py is noise-aware), so they are held to a CONTROL: the all-f32 step with proj_pre.bias moved by 1e-5 -- a
+    perturbation of the Transformer's input of the size of the split-bf16 error.  The split-bf16 step's gradients may differ from the f32 step's by at most
+    3x what that control differs (or 1e-4 relative L2, whichever is larger)."""
+    import act_amd.composite as CP
+    from act_amd.models import build_model_from_cfg
+    from act_amd.utils.config import cfg_from_yaml_file
+    from act_amd.utils.draws import Draws
+    from tests.golden.fill import clouds
+    cfg = cfg_from_yaml_file("cfgs/autoencoder/act_dvae_with_pretrained_transformer.yaml").model
+    torch.manual_seed(5)
+    vae = build_model_from_cfg(cfg).to(dev).train()
+    vae.prompt_dropout.p = 0.0
+    B = 8
+    pts = torch.from_numpy(clouds(11, B, 1024)).to(dev)
+    gum = -torch.empty(B, 64, 8192).exponential_().log()
+    names = ["deep_prompt_tokens", "visual_prompt_token", "visual_prompt_pos", "proj_pre.weight", "proj_post.weight", "encoder.first_conv.0.weight", "codebook"]
+    bias0 = vae.proj_pre.bias.detach().clone()
+    nudge = 1e-5 * torch.randn(bias0.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+
+    def step(on, nudged):
+        saved = CP.TEACHER_BF16X3
+        CP.TEACHER_BF16X3 = on
+        try:
+            with torch.no_grad():
+                vae.proj_pre.bias.copy_(bias0 + nudge if nudged else bias0)
+            vae.zero_grad(set_to_none=True)
+            r = vae(pts, temperature=0.6, hard=False, draws=Draws({"gumbel": gum}, device=dev))
+            lr, lk = vae.get_loss(r, pts)
+            (lr + 0.05 * lk).backward()
+            pd = dict(vae.named_parameters())
+            return lr.item(), lk.item(), r[3].detach().clone(), {n: pd[n].grad.double().clone() for n in names}
+        finally:
+            CP.TEACHER_BF16X3 = saved
+            with torch.no_grad():
+                vae.proj_pre.bias.copy_(bias0)
+    f32, x3, ctl = step(False, False), step(True, False), step(False, True)
+    assert abs(x3[0] - f32[0]) <= 1e-4 and abs(x3[1] - f32[1]) <= 1e-4, (x3[:2], f32[:2])
+    assert _rel(x3[2], f32[2]) <= 1e-4
+    assert not torch.equal(x3[2], f32[2])                         # the reconstruction comes from after the Transformer: the split-bf16 kernel really ran
+    l2 = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    bad = []
+    for n in names:
+        e, c = l2(x3[3][n], f32[3][n]), l2(ctl[3][n], f32[3][n])
+        print(f"stage-I step gradient {n}: split-bf16 forward vs f32 {e:.2e}; control (f32, Transformer input moved by 1e-5) {c:.2e}")
+        if e > max(1e-4, 3 * c):
+            bad.append((n, e, c))
+    assert not bad, bad
