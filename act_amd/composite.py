@@ -99,6 +99,7 @@ _SIGS = {
     "act_prefix_block_bwd_scratch_floats": [_P(BlockDims), _i],
     "act_prefix_block_fwd_f32": [_P(BlockDims), _i, _P(BlockParams), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
     "act_prefix_block_fwd_bf16x3_f32": [_P(BlockDims), _i, _P(BlockParams), _P(VitBf16x3), _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
+    "act_prefix_block_bwd_bf16x3_f32": [_P(BlockDims), _i, _P(BlockParams), _P(VitBf16x3), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "act_prefix_block_bwd_f32": [_P(BlockDims), _i, _P(BlockParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     "act_prefix_vit_scratch_floats": [_P(PrefixVit)],
     "act_prefix_vit_fwd_f32": [_P(PrefixVit), _vp, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -394,8 +395,10 @@ _VIT_STRUCT = weakref.WeakKeyDictionary()      # tokenizer -> (signature, Prefix
 _VIT_PLANES = weakref.WeakKeyDictionary()      # tokenizer -> (signature incl. weight versions, [bf16 plane tensors], pointer array)   (opt-in split-bf16 teacher)
 # OPT-IN, default OFF: the Linear products of the FROZEN teacher's ViT blocks on the split-bf16 kernel (csrc/gemm_bf16x3.hip: hi + lo bf16 planes of both
 # operands, three products, fp32 accumulation; teacher features move by ~7e-6 of their range, parity bar 1e-4).  Never part of a headline number:
-# bench.py reports this configuration on a separate line.  Inference form of the teacher only (Stage II); Stage-I prompt tuning keeps the f32 kernels.
+# bench.py reports this configuration on a separate line.  Covers the inference form of the teacher (Stage II) and the same frozen ViT inside the Stage-I
+# prompt-tuning graph (PrefixBlockFn: forward products, and -- unless ACT_TEACHER_BF16X3_BWD=0 -- the five input-gradient products of its backward).
 TEACHER_BF16X3 = os.environ.get("ACT_TEACHER_BF16X3", "0") == "1"
+TEACHER_BF16X3_BWD = os.environ.get("ACT_TEACHER_BF16X3_BWD", "1") == "1"
 
 
 def _stack_leaves(blocks):
@@ -473,8 +476,10 @@ class PrefixBlockFn(torch.autograd.Function):
             x3, keep = _block_planes((wqkv, wproj, w1, w2), B * G * w1.shape[0] + B * max(G, P) * D, dev)
             check(lib.act_prefix_block_fwd_bf16x3_f32(*args[:3], ctypes.byref(x3), *args[3:6], 1, *args[8:], _C.stream()), "act_prefix_block_fwd_bf16x3_f32")
             del keep
+            ctx.x3 = True
         else:
             check(lib.act_prefix_block_fwd_f32(*args, _C.stream()), "act_prefix_block_fwd_f32")
+            ctx.x3 = False
         ctx.save_for_backward(saved, prm2d, n1w, wqkv, wproj, n2w, w1, w2)
         ctx.dims = (B, P, G, D, heads, w1.shape[0], eps)
         return out
@@ -493,6 +498,11 @@ class PrefixBlockFn(torch.autograd.Function):
         ws = K.workspace(dev)
         args = (ctypes.byref(dims), P, ctypes.byref(prm), _p(prm2d), _p(saved), _p(dout), _p(dx), _p(dprm), _p(scratch), _p(ws), ws.numel() * 4)
         ensure_tuned(("pfx_bwd", B, G, D, heads, hidden, P), lambda: lib.act_prefix_block_bwd_f32(*args, _C.stream()), dev)
+        if ctx.x3 and TEACHER_BF16X3_BWD:
+            x3, keep = _block_planes((wqkv, wproj, w1, w2), B * G * hidden + B * max(G, P) * D, dev, transposed=True)
+            check(lib.act_prefix_block_bwd_bf16x3_f32(*args[:3], ctypes.byref(x3), *args[3:], _C.stream()), "act_prefix_block_bwd_bf16x3_f32")
+            del keep
+            return (dx, dx, dprm) + (None,) * 17
         check(lib.act_prefix_block_bwd_f32(*args, _C.stream()), "act_prefix_block_bwd_f32")
         return (dx, dx, dprm) + (None,) * 17
 
@@ -587,19 +597,26 @@ def prefix_vit_forward(tok, tokens, center, drop_p, seed_base, seed_dev):
     return out
 
 
-_BLOCK_PLANES = {}     # id(qkv weight Parameter) -> (weak reference to it, signature, planes, pointer array) of ONE frozen block; the entry dies with the Parameter
+_BLOCK_PLANES = {}     # (id(qkv weight Parameter), transposed) -> (weak reference to it, signature, planes, pointer array) of ONE frozen block; the entry dies with the Parameter
 #                        (not a WeakKeyDictionary: tensors as dictionary keys compare element-wise on a hash collision)
 
 
-def _block_planes(ws_, act_elems, dev):
-    """Same for the four weights of one frozen block of the differentiable Stage-I forward (PrefixBlockFn), cached on the qkv Parameter."""
+def _block_planes(ws_, act_elems, dev, transposed=False):
+    """Same for the four weights (qkv, proj, fc1, fc2) of one frozen block of the differentiable Stage-I forward (PrefixBlockFn), cached on the qkv Parameter.
+    ``transposed``: the planes its backward multiplies with instead -- fc2^T, fc1^T, proj^T, qkv^T and (qkv rows D..3D)^T (act_prefix_block_bwd_bf16x3_f32)."""
     sig = tuple((w.data_ptr(), w._version) for w in ws_)
-    key = id(ws_[0])
+    key = (id(ws_[0]), transposed)
     cache = _BLOCK_PLANES.get(key)
     if cache is None or cache[0]() is not ws_[0] or cache[1] != sig:
         with torch.no_grad():
-            planes = [K.split_bf16x2(w.detach()) for w in ws_]
-        parr = (_vp * 4)(*[pl.data_ptr() for pl in planes])
+            if transposed:
+                wqkv, wproj, w1, w2 = (w.detach() for w in ws_)
+                D = wqkv.shape[1]
+                src = [w2.t(), w1.t(), wproj.t(), wqkv.t(), wqkv[D:].t()]
+            else:
+                src = [w.detach() for w in ws_]
+            planes = [K.split_bf16x2(w.contiguous()) for w in src]
+        parr = (_vp * len(planes))(*[pl.data_ptr() for pl in planes])
         cache = _BLOCK_PLANES[key] = (weakref.ref(ws_[0], lambda _, k=key: _BLOCK_PLANES.pop(k, None)), sig, planes, parr)
     a_planes = torch.empty(2 * act_elems, dtype=torch.bfloat16, device=dev)
     return VitBf16x3(ctypes.cast(cache[3], _vp), a_planes.data_ptr(), a_planes.numel()), (a_planes, cache)

@@ -454,6 +454,48 @@ int act_prefix_block_bwd_f32(const act_block_dims_t* d, int P, const act_block_p
     return 0;
 }
 
+// OPT-IN: the same backward with the five input-gradient products on the split-bf16 kernel.  wT_planes[0..4] = hi planes (lo plane `numel` behind each) of the
+// TRANSPOSED frozen weights, which is what turns dY . W into the kernel's A . B^T form: fc2_w^T [Hd][D], fc1_w^T [D][Hd], proj_w^T [D][D], qkv_w^T [D][3D] and
+// (qkv_w rows D..3D)^T [D][2D].  Each incoming gradient is split into planes first (dh leaves the fc2 product's epilogue as planes); LayerNorm / attention
+// backward are the f32 kernels.  A product whose shape the kernel does not take stays on the f32 kernels.
+int act_prefix_block_bwd_bf16x3_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const act_vit_bf16x3_t* x3, const float* prm, const float* saved,
+                                    const float* dout, float* dx, float* dprm, float* scratch, float* ws, size_t wsb, act_stream_t stream) {
+    if (!w || !prm || !saved || !dout || !dx || !dprm || !scratch || !x3 || !x3->w_planes || !x3->a_planes) return ACT_E_NULLPTR;
+    if (bad_dims(d) || P <= 0) return ACT_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int B = d->B, G = d->S, D = d->D, H = d->heads, hd = D / H, Hd = d->hidden, TG = B * G, TP = B * P;
+    if (!x3_fits(*d, P, x3->a_planes_elems) || (size_t)TP * 2 * D > (size_t)TG * Hd || 3 * D > Hd)               // the staging regions below would not hold it
+        return act_prefix_block_bwd_f32(d, P, w, prm, saved, dout, dx, dprm, scratch, ws, wsb, stream);
+    PrefixSaved sv; carve_prefix(const_cast<float*>(saved), *d, P, sv);
+    PrefixBwdScratch sc; carve_prefix_bwd(scratch, *d, P, sc);
+    const uint16_t *fc2T = x3->w_planes[0], *fc1T = x3->w_planes[1], *projT = x3->w_planes[2], *qkvT = x3->w_planes[3], *kvT = x3->w_planes[4];
+    uint16_t* big = x3->a_planes;                                   // 2 TG Hd: planes of dh, later of dqkvx [TG, 3D], later of dkvp [TP, 2D]
+    uint16_t* small = x3->a_planes + (size_t)2 * TG * Hd;           // 2 max(TG, TP) D: planes of dout, later of dx1
+    // dIn [M, N] = dOut [M, K] . W [K, N]  (W^T as planes [N][K]); `pre`: dOut is already planes at `stage`; `emit`: the result leaves as planes only
+    auto dgrad = [&](int M, int N, int K, const float* dOut, const float* W, const uint16_t* WT, float* dIn, const act_gemm_epilogue_t& e, uint16_t* stage,
+                     bool pre = false, uint16_t* emit = nullptr) -> int {
+        if (WT && act_sgemm_nt_bf16x3_supported(M, N, K)) {
+            if (t_collect) return 0;
+            if (!pre) CK(act_split_bf16x2_f32(dOut, M, K, K, stage, stage + (size_t)M * K, s));
+            return act_sgemm_nt_bf16x3_planes_f32(M, N, K, stage, stage + (size_t)M * K, WT, WT + (size_t)N * K, emit ? nullptr : dIn, N, emit,
+                                                  emit ? emit + (size_t)M * N : nullptr, &e, s);
+        }
+        return gemm_nn(M, N, K, dOut, K, W, N, dIn, N, e, ws, wsb, s);
+    };
+    const bool mlp_planes = fc2T && fc1T && act_sgemm_nt_bf16x3_supported(TG, Hd, D) && act_sgemm_nt_bf16x3_supported(TG, D, Hd);
+    act_gemm_epilogue_t e = epi0(); e.act = ACT_EPI_MUL_GELU_GRAD; e.aux = sv.hpre; e.ldaux = Hd;
+    CK(dgrad(TG, Hd, D, dout, w->fc2_w, fc2T, sc.dh, e, small, false, mlp_planes ? big : nullptr));
+    CK(dgrad(TG, D, Hd, sc.dh, w->fc1_w, fc1T, sc.dn2, epi0(), big, mlp_planes));
+    RUN(act_layernorm_bwd_f32(sc.dn2, sv.x1, w->norm2_w, sv.mean2, sv.rstd2, dout, sc.dx1, nullptr, nullptr, 0, nullptr, 0, TG, D, s));
+    CK(dgrad(TG, D, D, sc.dx1, w->proj_w, projT, sc.datt, epi0(), small));
+    RUN(act_attention_bwd_prefix_f32(sv.kvp, P, sv.qkvx, G, sv.att, sc.datt, sv.lse, sc.dkvp, sc.dqkvx, B, H, hd, attn_scale(hd), s));
+    CK(dgrad(TG, D, 3 * D, sc.dqkvx, w->qkv_w, qkvT, sc.dn1x, epi0(), big));
+    RUN(act_layernorm_bwd_f32(sc.dn1x, sv.xin, w->norm1_w, sv.mean1, sv.rstd1, sc.dx1, dx, nullptr, nullptr, 0, nullptr, 0, TG, D, s));
+    CK(dgrad(TP, D, 2 * D, sc.dkvp, w->qkv_w + (size_t)D * D, kvT, sc.dn1p, epi0(), big));
+    RUN(act_layernorm_bwd_f32(sc.dn1p, prm, w->norm1_w, sv.meanp, sv.rstdp, nullptr, dprm, nullptr, nullptr, 0, nullptr, 0, TP, D, s));
+    return 0;
+}
+
 // ============================================================================================== frozen prompt-tuned Transformer (teacher)
 static size_t carve_vit(float* base, const act_prefix_vit_t& m, float*& pos_h, float*& pos, float*& xa, float*& xb, float*& n1p, float*& blk,
                         float*& feat) {

@@ -182,6 +182,10 @@ int launch_x3(const X3Params& p, hipStream_t s) {
             if (planes) hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_GELU, true>), grid, dim3(256), 0, s, p);
             else        hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_GELU, false>), grid, dim3(256), 0, s, p);
             break;
+        case ACT_EPI_MUL_GELU_GRAD:                                  // (the MLP's backward through GELU: aux = the saved pre-activation)
+            if (planes) hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_MUL_GELU_GRAD, true>), grid, dim3(256), 0, s, p);
+            else        hipLaunchKernelGGL((sgemm_nt_bf16x3_kernel<BM, BN, ACT_EPI_MUL_GELU_GRAD, false>), grid, dim3(256), 0, s, p);
+            break;
         default: return ACT_E_BADARG;
     }
     ACT_LAUNCH_CHECK();
@@ -217,7 +221,7 @@ extern "C" int act_sgemm_nt_bf16x3_planes_f32(int M, int N, int K, const uint16_
     X3Params p{};
     p.Ah = a_hi; p.Al = a_lo; p.Bh = b_hi; p.Bl = b_lo; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.Oh = out_hi; p.Ol = out_lo;
     if (epilogue) p.epi = *epilogue; else { p.epi = act_gemm_epilogue_t{}; p.epi.alpha = 1.0f; }
-    if (p.epi.accumulate || (p.epi.act != ACT_EPI_NONE && p.epi.act != ACT_EPI_GELU)) return ACT_E_BADARG;
+    if (p.epi.accumulate || (p.epi.act != ACT_EPI_NONE && p.epi.act != ACT_EPI_GELU && p.epi.act != ACT_EPI_MUL_GELU_GRAD)) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     ActProfScope ps(KID_GEMM_BF16X3, s, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     return launch_x3<128, 128>(p, s);

@@ -483,6 +483,11 @@ int act_prefix_vit_fwd_bf16x3_f32(const act_prefix_vit_t* m, const act_vit_bf16x
 int act_prefix_block_fwd_bf16x3_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const act_vit_bf16x3_t* x3, const float* x, const float* pos,
                                     const float* prm, int keep_for_backward, float* saved, float* out, float* workspace, size_t workspace_bytes,
                                     act_stream_t stream);
+/* ... and its backward: x3->w_planes[0..4] = planes of the TRANSPOSED weights fc2_w^T [hidden][D], fc1_w^T [D][hidden], proj_w^T [D][D], qkv_w^T [D][3D],
+ * (qkv_w rows D..3D)^T [D][2D]; the five input-gradient products run on the split-bf16 kernel, LayerNorm / attention backward stay f32. */
+int act_prefix_block_bwd_bf16x3_f32(const act_block_dims_t* d, int P, const act_block_params_t* w, const act_vit_bf16x3_t* x3, const float* prm,
+                                    const float* saved, const float* dout, float* dx, float* dprm, float* scratch, float* workspace,
+                                    size_t workspace_bytes, act_stream_t stream);
 int act_prefix_vit_fwd_f32(const act_prefix_vit_t* m, const float* tokens, const float* center, float* out, float* scratch,
                            float* workspace, size_t workspace_bytes, act_stream_t stream);
 

@@ -198,8 +198,9 @@ def test_split_bf16_teacher_at_the_stress_geometry_and_with_mixed_kernels(dev, B
 @pytest.mark.parametrize("B,P,G", [(4, 32, 64), (2, 24, 64)])
 def test_stage1_prefix_block_forward_in_split_bf16_keeps_the_f32_backward_exact_enough(dev, B, P, G):
     """The differentiable prefix block of Stage-I prompt tuning (composite.PrefixBlockFn) with the switch on: the frozen block's forward products run on the
-    split-bf16 kernel (B=4, P=32: all five; B=2, P=24: the prompt K/V product -- 48 rows -- stays f32), the backward is the unchanged f32 one reading what the
-    forward still writes in fp32.  Output and the gradients w.r.t. tokens, positions and prompts within 3e-5 of the all-f32 path (bar 1e-4)."""
+    split-bf16 kernel (B=4, P=32: all five; B=2, P=24: the prompt K/V product -- 48 rows -- stays f32); the backward either the unchanged f32 one
+    (ACT_TEACHER_BF16X3_BWD=0) reading what the forward still writes in fp32, or with its five input-gradient products on the split-bf16 kernel too (default
+    when the switch is on).  Output and the gradients w.r.t. tokens, positions and prompts within 3e-5 of the all-f32 path (bar 1e-4)."""
     import act_amd.composite as CP
     D, H, Hd = 768, 12, 3072
     g = torch.Generator().manual_seed(31)
@@ -208,22 +209,24 @@ def test_stage1_prefix_block_forward_in_split_bf16_keeps_the_f32_backward_exact_
             1 + rn(D, sc=0.1), rn(D, sc=0.1), rn(Hd, D, sc=D ** -0.5), rn(Hd, sc=0.02), rn(D, Hd, sc=Hd ** -0.5), rn(D, sc=0.02)]
     x0, p0, m0, w = rn(B * G, D), rn(B * G, D, sc=0.2), rn(B * P, D, sc=0.3), rn(B * G, D)
 
-    def run(on):
-        saved = CP.TEACHER_BF16X3
-        CP.TEACHER_BF16X3 = on
+    def run(on, bwd=False):
+        saved = CP.TEACHER_BF16X3, CP.TEACHER_BF16X3_BWD
+        CP.TEACHER_BF16X3, CP.TEACHER_BF16X3_BWD = on, bwd
         try:
             x, p, m = (t.clone().requires_grad_(True) for t in (x0, p0, m0))
             y = CP.PrefixBlockFn.apply(x, p, m, B, P, G, *prm_, H, 1e-6)
             (y * w).sum().backward()
             return y.detach(), x.grad, p.grad, m.grad
         finally:
-            CP.TEACHER_BF16X3 = saved
-    ref, got = run(False), run(True)
+            CP.TEACHER_BF16X3, CP.TEACHER_BF16X3_BWD = saved
+    ref, got, both = run(False), run(True), run(True, True)
     assert not torch.equal(got[0], ref[0])                        # the split-bf16 kernel really ran
-    for name, a, b in zip(("out", "dx", "dpos", "dprompt"), got, ref):
-        e = _rel(a, b)
-        print(f"stage-I prefix block B={B} P={P} {name}: split-bf16 forward vs f32 {e:.2e}")
-        assert e <= 3e-5, (name, e)
+    assert torch.equal(both[0], got[0]) and not torch.equal(both[1], got[1])     # ... and so did the split-bf16 backward products
+    for tag, res in (("forward", got), ("forward + backward", both)):
+        for name, a, b in zip(("out", "dx", "dpos", "dprompt"), res, ref):
+            e = _rel(a, b)
+            print(f"stage-I prefix block B={B} P={P} {name}: split-bf16 {tag} vs f32 {e:.2e}")
+            assert e <= 3e-5, (tag, name, e)
     # a block whose weights train is never routed there
     prm_[2].requires_grad_(True)
     try:
@@ -257,7 +260,7 @@ def test_stage1_step_with_split_bf16_forward_matches_the_f32_step(dev):
 
     def step(on, nudged):
         saved = CP.TEACHER_BF16X3
-        CP.TEACHER_BF16X3 = on
+        CP.TEACHER_BF16X3 = on                                     # (TEACHER_BF16X3_BWD at its default: on -> forward AND backward products)
         try:
             with torch.no_grad():
                 vae.proj_pre.bias.copy_(bias0 + nudge if nudged else bias0)
