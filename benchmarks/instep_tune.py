@@ -1,103 +1,153 @@
 #!/usr/bin/env python3
-"""In-step tile selection for the GEMM shapes of the Stage-II step (dev tool; round 4).
+"""IN-STEP choice of the GEMM launch configuration (tile id, split-K) for the biggest products of the production Stage-II step.
 
-The shipped table is built from ISOLATED timings (benchmarks/tune_table.py).  Inside the step two HIP streams share the chip, and a tile's LDS / register
-footprint decides how well the other stream's kernels fit next to it: the teacher's fc2 / proj measured 0.33 ms per step faster on the 64x64 tile than on the
-128x64 tile that wins in isolation.  This script walks the hot shapes, tries the other tiles of the SAME bit-identical family (NT: 30 / 31 / 32, NN: 33..36 --
-results do not change, kernels.stable_candidates) at the tabled split-K, times the whole overlapped step, and keeps a change only when two independent
-timings both beat the incumbent by more than the noise margin.
+The shipped table (act_amd/gemm_tune_gfx950.json) holds the winners of ISOLATED timings; in the overlapped step two or three streams share the chip, and a
+tile that wins alone (more LDS, more waves) can lose there (round 4 found that for two shapes by hand).  This script does the comparison where it
+counts: coordinate descent over the largest products of the step -- for each shape, every candidate configuration is registered with both host paths
+(kernels._GEMM_CACHE and the C-side table of the composites), the overlapped step is timed (hipEvents over windows of steps, interleaved with the
+incumbent), and a candidate replaces the incumbent only if it wins by more than the measurement noise, twice.
 
-    python benchmarks/instep_tune.py [out.json]            # prints the decisions, writes the refreshed table (default gpurun_out/gemm_tune_instep.json)
-    INSTEP_SPLITS=1 python benchmarks/instep_tune.py ...   # additionally tries other split-K counts (NOT bit-identical to the incumbent: a table change then
-                                                           # changes fp32 summation order -- fixed per table, so still run-to-run deterministic)
-"""
-import json, os, sys, time
+    python benchmarks/instep_tune.py [--stage 2] [--top 24] [--window 24] > gpurun_out/instep_tune.txt
+Prints the accepted changes as JSON (key -> [tile, split]) for benchmarks/merge_tuned.py / a hand edit of the table."""
+import os, sys, json, logging, argparse, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import argparse
+sys.path.insert(0, ROOT); os.chdir(ROOT)
 import torch
 import act_amd.kernels as K
 import act_amd.composite as CP
 from act_amd.models import build_model_from_cfg
 from act_amd.tools import builder
-from act_amd.tools.runner_pretrain import freeze_unused_heads, train_step, _Single
+from act_amd.tools.runner_pretrain import freeze_unused_heads, train_transforms, _Single, _Announced
 from act_amd.utils.config import cfg_from_yaml_file
-from bench import synthetic_clouds
+from act_amd.utils.logger import get_logger
+for n in ("ACT", "Transformer"):
+    get_logger(n).setLevel(logging.ERROR)
+import bench
 
-MARGIN_MS = float(os.environ.get("INSTEP_MARGIN_MS", "0.06"))
+ap = argparse.ArgumentParser()
+ap.add_argument("--top", type=int, default=24)
+ap.add_argument("--window", type=int, default=24)
+ap.add_argument("--margin", type=float, default=0.04, help="ms per step a candidate must win by")
+args = ap.parse_args()
+
+seen = {}
+_orig = CP._tune_shape
+
+
+def _spy(ak, bk, M, N, Kd, device):
+    seen[(int(ak), int(bk), M, N, Kd)] = seen.get((int(ak), int(bk), M, N, Kd), 0) + 1
+    return _orig(ak, bk, M, N, Kd, device)
+
+
+CP._tune_shape = _spy
+
+cfg = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml"); cfg.model.dvae_config.ckpt = "none"
 dev = torch.device("cuda:0")
-config = cfg_from_yaml_file("cfgs/pretrain/pretrain_act_distill.yaml")
-config.model.dvae_config.ckpt = "none"
 torch.manual_seed(0)
-model = build_model_from_cfg(config.model)
-freeze_unused_heads(model)
-model.to(dev).train()
-wrapped = _Single(model)
-optimizer, _ = builder.build_opti_sche(wrapped, config)
-pool = [synthetic_clouds(128, 1024, 1234 + i, dev) for i in range(4)]
-state = {"next": None}
+model = build_model_from_cfg(cfg.model); freeze_unused_heads(model); model.to(dev).train()
+w = _Single(model); opt, _ = builder.build_opti_sche(w, cfg)
+pool = [bench.synthetic_clouds(128, 1024, 1 + i, dev) for i in range(4)]
+main = torch.cuda.current_stream(dev)
+side = K.side_stream(dev)
+state = {"nxt": None, "i": 0}
 
 
-def step(i):
-    cur = state["next"] if state["next"] is not None else pool[i % 4].clone()
-    state["next"] = pool[(i + 1) % 4].clone()
-    return train_step(wrapped, optimizer, cur, config, next_points=state["next"])
+def step():
+    i = state["i"]; state["i"] += 1
+    cur = state["nxt"] if state["nxt"] is not None else train_transforms(pool[i % 4].clone())
+    nxt = pool[(i + 1) % 4].clone()
+    loss = w(cur)
+    nxt = train_transforms(nxt)
+    _Announced.mark(model, nxt)
+    side.wait_stream(main)
+    model.prefetch_teacher(nxt)
+    state["nxt"] = nxt
+    loss.backward()
+    opt.step(); opt.zero_grad(set_to_none=True)
 
 
-def measure(steps=25, warm=4):
-    for i in range(warm):
-        step(i)
+def window(n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(main)
+    for _ in range(n):
+        step()
+    e1.record(main)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0) / steps
+    return e0.elapsed_time(e1) / n
 
 
-def apply(key, cfg):
-    K._GEMM_TABLE[key] = tuple(cfg)
-    K._GEMM_CACHE.clear()
-    CP.reset_tuning()
+for _ in range(8):
+    step()
+torch.cuda.synchronize()
+for key in K._GEMM_CACHE:                                      # products launched through the Python path
+    seen.setdefault(tuple(key[:5]), 1)
 
 
-for i in range(6):
-    step(i)                                               # first-use work out of the way
-base = min(measure(), measure())
+def current(key):
+    c = K._GEMM_CACHE.get(key + (dev.index,)) or K._GEMM_TABLE.get(key)
+    return tuple(c) if c else None
+
+
+def apply(key, cfgv):
+    K._GEMM_CACHE[key + (dev.index,)] = tuple(cfgv)
+    CP.lib.act_gemm_tune_set(*key, int(cfgv[0]), int(cfgv[1]))
+
+
+def candidates(key):
+    ak, bk, M, N, Kd = key
+    sp_list = [1] + [s for s in (2, 3, 4, 6, 8) if Kd // s >= 256 and -(-M // 64) * -(-N // 64) * s <= 8192 and -(-M // 128) * -(-N // 128) < 512]
+    if ak and bk:
+        tiles = [t for t, bn in ((30, 128), (31, 64), (32, 64), (10, 128), (11, 64), (12, 64), (20, 128), (21, 64)) if N % bn == 0 and (t < 20 or M % 128 == 0)]
+    elif ak and not bk:
+        tiles = [t for t, bn in ((33, 128), (34, 128), (36, 64), (35, 64)) if N % bn == 0]
+    elif not ak and not bk and M % 128 == 0 and N % 128 == 0:
+        tiles = [33, 13]
+    else:
+        tiles = []
+    return [(t, s) for t in tiles for s in sp_list]
+
+
+ranked = sorted((k for k in seen if k[2] * k[3] * k[4] >= (1 << 28)), key=lambda k: -k[2] * k[3] * k[4])[:args.top]
+print(f"{len(seen)} GEMM shapes seen in the step; tuning the {len(ranked)} largest in-step", flush=True)
+base = statistics.median(window(args.window) for _ in range(3))
 print(f"incumbent table: {base:.3f} ms / step", flush=True)
-
-FAM = {(1, 1): ((30, 128), (31, 64), (32, 64)), (1, 0): ((33, 128), (34, 128), (35, 64), (36, 64))}
-hot = [k for k, c in K._GEMM_TABLE.items() if (k[0], k[1]) in FAM and k[2] in (1792, 8192) and 2.0 * k[2] * k[3] * k[4] >= 1.0e9
-       and c[0] in [t for t, _ in FAM[(k[0], k[1])]]]
-hot.sort(key=lambda k: -k[2] * k[3] * k[4])
-changes = {}
-for key in hot:
-    inc = K._GEMM_TABLE[key]
-    best, best_t = inc, base
-    alts = [(tile, inc[1]) for tile, bn in FAM[(key[0], key[1])] if tile != inc[0] and key[3] % bn == 0]
-    if os.environ.get("INSTEP_SPLITS") == "1" and key[2] <= 8192:
-        alts += [(inc[0], sp) for sp in (1, 2, 3, 4, 6) if sp != inc[1] and key[4] // sp >= 128 and (key[4] // sp) % 32 == 0 and key[4] % sp == 0]
-    for tile, sp_ in alts:
-        apply(key, (tile, sp_))
-        try:
-            t1 = measure()
-        except Exception as e:                            # a tile the library refuses for this shape
-            print(f"  {key}: tile {tile} refused ({e})")
+accepted = {}
+for key in ranked:
+    inc = current(key)
+    if inc is None:
+        continue
+    ws = K.workspace(dev)
+    rows = []
+    for c in candidates(key):
+        if c == inc or c[1] * key[2] * key[3] * 4 > ws.numel() * 4:
             continue
-        if t1 < best_t - MARGIN_MS:
-            t2 = measure()
-            if t2 < best_t - MARGIN_MS:
-                best, best_t = (tile, sp_), max(t1, t2)
-    apply(key, best)
-    tag = "" if best == inc else f"   <-- {inc} -> {best}"
-    print(f"{key}: {best_t:.3f} ms{tag}", flush=True)
-    if best != inc:
-        changes[key] = best
-        base = min(best_t, measure())                     # re-anchor the incumbent time (drift)
-
-dst = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "gemm_tune_instep.json")
-table = json.load(open(K._TUNE_FILE))
-for k, c in changes.items():
-    table["configs"][",".join(str(v) for v in k)] = list(c)
-json.dump(table, open(dst, "w"), indent=0)
-print(f"{len(changes)} change(s) of {len(hot)} shapes; final {min(measure(), measure()):.3f} ms / step; table -> {dst}")
+        apply(key, c)
+        try:
+            step(); torch.cuda.synchronize()
+        except Exception as ex:                                  # a configuration the kernel family rejects for this shape
+            apply(key, inc)
+            rows.append((c, None)); continue
+        t = window(args.window)
+        apply(key, inc)
+        tb = window(args.window)
+        rows.append((c, t - tb))
+    rows = [(c, d) for c, d in rows if d is not None]
+    if not rows:
+        continue
+    best, d = min(rows, key=lambda r: r[1])
+    line = f"{key} incumbent {inc}: " + "  ".join(f"{c}:{dd:+.3f}" for c, dd in sorted(rows, key=lambda r: r[1])[:5])
+    if d < -args.margin:                                         # confirm: two more interleaved pairs
+        ds = []
+        for _ in range(2):
+            apply(key, best); t = window(args.window)
+            apply(key, inc); tb = window(args.window)
+            ds.append(t - tb)
+        line += f"   confirm {best}: {ds[0]:+.3f} {ds[1]:+.3f}"
+        if max(ds) < -args.margin / 2:
+            apply(key, best)
+            accepted[",".join(str(v) for v in key)] = list(best)
+            line += "  ACCEPTED"
+    print(line, flush=True)
+final = statistics.median(window(args.window) for _ in range(3))
+print(f"after: {final:.3f} ms / step (before {base:.3f})")
+print("ACCEPTED " + json.dumps(accepted))
