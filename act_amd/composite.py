@@ -93,7 +93,7 @@ _SIGS = {
     "act_block_stack_saved_floats": [_P(BlockDims), _i, _i],
     "act_block_stack_bwd_scratch_floats": [_P(BlockDims), _i],
     "act_block_stack_fwd_f32": [_P(BlockDims), _P(BlockStack), _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp],
-    "act_block_stack_bwd_f32": [_P(BlockDims), _P(BlockStack), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp],
+    "act_block_stack_bwd_f32": [_P(BlockDims), _P(BlockStack), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp],
     "act_add_f32": [_vp, _vp, _vp, ctypes.c_longlong, _vp],
     "act_prefix_block_saved_floats": [_P(BlockDims), _i],
     "act_prefix_block_bwd_scratch_floats": [_P(BlockDims), _i],
@@ -322,10 +322,14 @@ class BlockStackFn(torch.autograd.Function):
     """x = blk_l(x + pos) for the blocks of a TransformerEncoder / TransformerDecoder (models/act.py:109-112,140-143) as ONE host call per
     direction (act_block_stack_fwd_f32 / act_block_stack_bwd_f32): the same launches in the same order as ``depth`` BlockFn calls -- bit-identical,
     gradient of ``pos`` included (accumulated in the order an autograd engine folds the per-block gradients) -- for 1/depth of the host work.
-    ``gates``: list of (gate_attn, gate_mlp) / None per block; ``params``: 12 tensors per block in BlockParams order (qkv bias may be None)."""
+    ``gates``: list of (gate_attn, gate_mlp) / None per block; ``params``: 12 tensors per block in BlockParams order (qkv bias may be None).
+
+    ``emit_pos`` (a stack differentiated in chunks, round 6): the call also returns ``pos`` itself; the NEXT chunk takes that alias as its pos input, so
+    its accumulated pos gradient arrives here as the gradient of the second output and the fold continues through it,
+    ((dpos_deeper + dx_{L-1}) + dx_{L-2}) + ... -- the association of the unchunked stack, not (s_2 + s_1) + s_0 of independent chunk sums."""
 
     @staticmethod
-    def forward(ctx, x, pos, gates, heads, eps, train_w, *params):
+    def forward(ctx, x, pos, gates, heads, eps, train_w, emit_pos, *params):
         B, S, D = x.shape
         dev = x.device
         depth = len(params) // _NPB
@@ -350,25 +354,41 @@ class BlockStackFn(torch.autograd.Function):
                 saved.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel() * 4)
         ensure_tuned(("stack_fwd", B, S, D, heads, hidden, depth), lambda: lib.act_block_stack_fwd_f32(*args, _C.stream()), dev)
         check(lib.act_block_stack_fwd_f32(*args, _C.stream()), "act_block_stack_fwd_f32")
+        ctx.set_materialize_grads(False)                     # an unused pos alias has no gradient: None, not a zero tensor
         if need_grad:
             ctx.save_for_backward(saved, *[t for t in params if t is not None], *[t for t in gts if t is not None])
-            ctx.keep = (parr, g1, g2, st, params, gts)      # pointer arrays of tensors that save_for_backward keeps alive (and version-checks)
+            ctx.layout = ([t is not None for t in params], [t is not None for t in gts])
             ctx.dims = (B, S, D, heads, hidden, eps, depth)
             ctx.has_pos = pos is not None
             ctx.train_w = int(train_w)
-        return out
+        return (out, pos) if emit_pos else out
 
     @staticmethod
-    def backward(ctx, dout):
-        saved = ctx.saved_tensors[0]                          # (also runs the in-place-modification check on every saved weight)
-        parr, g1, g2, st, params, gts = ctx.keep
+    def backward(ctx, dout, dpos_in=None):
+        sv = ctx.saved_tensors                                # (also runs the in-place-modification check on every saved weight)
+        saved = sv[0]
         B, S, D, heads, hidden, eps, depth = ctx.dims
-        dev = dout.device
+        dev = saved.device
+        # the pointer arrays are rebuilt from the SAVED tensors (round 6): a ``param.data = ...`` re-assignment between forward and backward changes an
+        # address without bumping a version counter; a pointer array captured in forward would then be stale (BlockFn has always re-derived them)
+        it = iter(sv[1:])
+        params = tuple(next(it) if has else None for has in ctx.layout[0])
+        gts = tuple(next(it) if has else None for has in ctx.layout[1])
+        parr = _ptr_array(params, dev.index)
+        g1 = g2 = None
+        if gts:
+            g1, g2 = _ptr_array(gts[0::2], dev.index), _ptr_array(gts[1::2], dev.index)
+        st = BlockStack(depth, ctypes.cast(parr, _vp), ctypes.cast(g1, _vp) if g1 is not None else None,
+                        ctypes.cast(g2, _vp) if g2 is not None else None)
         dims, _, _, n_scratch = _stack_dims(B, S, D, heads, hidden, eps, depth)
-        dout = K._f32c(dout).reshape(B * S, D)
         tw = ctx.train_w
         dx = torch.empty(B, S, D, dtype=torch.float32, device=dev)
-        dpos = torch.empty(B, S, D, dtype=torch.float32, device=dev) if (ctx.has_pos and depth > 1) else None
+        if dout is None:                                     # only the pos alias of this chunk was used downstream (never the case in the models)
+            dout = torch.zeros(B * S, D, dtype=torch.float32, device=dev)
+        dout = K._f32c(dout).reshape(B * S, D)
+        if dpos_in is not None:
+            dpos_in = K._f32c(dpos_in).reshape(B * S, D)
+        dpos = torch.empty(B, S, D, dtype=torch.float32, device=dev) if (ctx.has_pos and (depth > 1 or dpos_in is not None)) else None
         scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
         grads, garr = (None,) * len(params), None
         if tw:
@@ -380,11 +400,12 @@ class BlockStackFn(torch.autograd.Function):
             side = K.side_stream(dev, 1).cuda_stream
             sws = _ws_of(dev, side)
         args = (ctypes.byref(dims), ctypes.byref(st), saved.data_ptr(), dout.data_ptr(), dx.data_ptr(), dpos.data_ptr() if dpos is not None else None,
+                dpos_in.data_ptr() if (dpos_in is not None and dpos is not None) else None,
                 ctypes.cast(garr, _vp) if garr is not None else None, scratch.data_ptr(), ws.data_ptr(), ws.numel() * 4,
                 sws.data_ptr() if sws is not None else None, (sws.numel() * 4 if sws is not None else 0))
         ensure_tuned(("stack_bwd", B, S, D, heads, hidden, depth, bool(tw)), lambda: lib.act_block_stack_bwd_f32(*args, _C.stream(), side), dev)
         check(lib.act_block_stack_bwd_f32(*args, _C.stream(), side), "act_block_stack_bwd_f32")
-        return (dx, (dpos if dpos is not None else dx) if ctx.has_pos else None, None, None, None, None) + grads
+        return (dx, (dpos if dpos is not None else dx) if ctx.has_pos else None, None, None, None, None, None) + grads
 
 
 # host-side caches keyed by module, kept OUTSIDE the modules (weak keys): nothing un-picklable (ctypes structs) or stale is ever attached to a model that
@@ -410,11 +431,22 @@ def _stack_leaves(blocks):
     return cache
 
 
-def block_stack(blocks, x, pos, gates, draws=None, tag="enc"):
+def _stock_blocks(blocks):
+    """every block runs the stock Block.forward of act_amd.models.act (a subclass that overrides forward, or a block carrying forward hooks, must be
+    CALLED -- the stack path bypasses Module.__call__) -- cached per ModuleList by _stack_leaves' key"""
+    from act_amd.models.act import Block
+    for b in blocks:
+        if type(b).forward is not Block.forward or b._forward_hooks or b._forward_pre_hooks or b._backward_hooks or b._backward_pre_hooks:
+            return False
+    return True
+
+
+def block_stack(blocks, x, pos, gates, draws=None, tag="enc", chunk=None):
     """the loop ``for blk in blocks: x = blk(x + pos)`` -- one BlockStackFn per chunk of blocks when the composite path is on, else one
-    Block.forward per block (ACT_COMPOSITE=0 / ACT_BLOCK_STACK=0)."""
+    Block.forward per block (ACT_COMPOSITE=0 / ACT_BLOCK_STACK=0).  ``chunk``: blocks per host call (None: the ACT_BLOCK_STACK_CHUNK default,
+    0: the whole stack); the owning TransformerEncoder / Decoder passes its ``stack_chunk`` (set by runner_pretrain.wrap_ddp under multi-rank DDP)."""
     n = len(blocks)
-    if not (ENABLED and STACK) or n == 0 or any(type(b).forward is not type(blocks[0]).forward for b in blocks):
+    if not (ENABLED and STACK) or n == 0 or not _stock_blocks(blocks):
         for i, blk in enumerate(blocks):
             x = blk(x, pos, draws, f"{tag}.{i}", gates[i] if gates is not None else None)
         return x
@@ -428,14 +460,19 @@ def block_stack(blocks, x, pos, gates, draws=None, tag="enc"):
         for i, blk in enumerate(blocks):                     # blocks that differ in more than their weights: one call each
             x = blk(x, pos, None, f"{tag}.{i}", gates[i] if gates is not None else None)
         return x
-    chunk = STACK_CHUNK if STACK_CHUNK > 0 else n
+    if chunk is None:
+        chunk = STACK_CHUNK
+    chunk = chunk if chunk > 0 else n
+    carry = pos is not None and chunk < n and torch.is_grad_enabled() and pos.requires_grad
     for c0 in range(0, n, chunk):
         params = []
         for n1, qkv, proj, n2, fc1, fc2, _ in leaves[c0:c0 + chunk]:
             p1, pq, pp, p2, pf1, pf2 = n1._parameters, qkv._parameters, proj._parameters, n2._parameters, fc1._parameters, fc2._parameters
             params += [p1["weight"], p1["bias"], pq["weight"], pq["bias"], pp["weight"], pp["bias"], p2["weight"], p2["bias"],
                        pf1["weight"], pf1["bias"], pf2["weight"], pf2["bias"]]
-        x = BlockStackFn.apply(x, pos, gates[c0:c0 + chunk] if gates is not None else None, heads, eps, tw, *params)
+        emit = carry and c0 + chunk < n                      # every chunk but the deepest hands pos on (see BlockStackFn)
+        r = BlockStackFn.apply(x, pos, gates[c0:c0 + chunk] if gates is not None else None, heads, eps, tw, emit, *params)
+        x, pos = r if emit else (r, pos)
     return x
 
 

@@ -190,7 +190,9 @@ int prefix_block_core(const act_block_dims_t& d, int P, const act_block_params_t
     e = epi0(); e.bias = w.fc1_b; e.act = ACT_EPI_GELU; e.aux = keep ? sv.hpre : nullptr; e.ldaux = Hd;
     CK(linear(TG, Hd, D, sv.n2, w.fc1_w, x3 ? x3->fc1 : nullptr, (size_t)Hd * D, sv.a, e, ln2_planes ? tmp_planes : nullptr, mlp_planes ? hid_planes : nullptr));
     e = epi0(); e.bias = w.fc2_b; e.res = sv.x1; e.ldr = D;
-    CK(linear(TG, D, Hd, sv.a, w.fc2_w, x3 ? x3->fc2 : nullptr, (size_t)D * Hd, out, e, mlp_planes ? hid_planes : nullptr));
+    // fc2 on the split-bf16 kernel ONLY with its operand already in hid_planes: a lone fc2 would split sv.a [TG, Hd] into tmp_planes, which holds
+    // 2 * max(TG, TP) * D elements -- too small whenever Hd > D (reachable with a non-4x mlp_ratio, D % 128 == 0, Hd % 64 == 0, Hd % 128 != 0)
+    CK(linear(TG, D, Hd, sv.a, w.fc2_w, (x3 && mlp_planes) ? x3->fc2 : nullptr, (size_t)D * Hd, out, e, mlp_planes ? hid_planes : nullptr));
     return 0;
 }
 
@@ -365,21 +367,28 @@ int act_block_stack_fwd_f32(const act_block_dims_t* d, const act_block_stack_t* 
     return 0;
 }
 int act_block_stack_bwd_f32(const act_block_dims_t* d, const act_block_stack_t* st, const float* saved, const float* dout, float* dx, float* dpos,
-                            const act_block_grads_t* grads, float* scratch, float* ws, size_t wsb, float* sws, size_t swsb, act_stream_t stream,
-                            act_stream_t side_stream) {
+                            const float* dpos_in, const act_block_grads_t* grads, float* scratch, float* ws, size_t wsb, float* sws, size_t swsb,
+                            act_stream_t stream, act_stream_t side_stream) {
     if (!saved || !dout || !dx || !scratch) return ACT_E_NULLPTR;
     if (bad_stack(d, st)) return ACT_E_BADARG;
+    if (dpos_in && !dpos) return ACT_E_NULLPTR;
     const size_t per = act_block_saved_floats(d), TD = (size_t)d->B * d->S * d->D;
     const int L = st->depth;
     float* blk_scratch = scratch;
     float* hid[2] = {scratch + act_block_bwd_scratch_floats(d), scratch + act_block_bwd_scratch_floats(d) + TD};
     const float* cur = dout;
+    // gradient of the shared pos: ((dx_{L-1} + dx_{L-2}) + dx_{L-3}) + ... in the order the blocks finish (what an autograd engine's input buffer does).
+    // dpos_in (round 6) = the sum the DEEPER chunks of the same stack already folded (blocks L, L+1, ... of the whole stack): the chain continues through
+    // it, ((dpos_in + dx_{L-1}) + dx_{L-2}) + ..., so a stack differentiated in chunks associates exactly like the unchunked one.
+    const float* acc = dpos_in;
     for (int l = L - 1; l >= 0; --l) {
         float* o = (l == 0) ? dx : hid[l & 1];
         CK(act_block_bwd_f32(d, &st->blocks[l], st->gate1 ? st->gate1[l] : nullptr, st->gate2 ? st->gate2[l] : nullptr, saved + per * (size_t)l, cur, o,
                              grads ? &grads[l] : nullptr, blk_scratch, ws, wsb, sws, swsb, stream, side_stream));
-        // gradient of the shared pos: ((dx_{L-1} + dx_{L-2}) + dx_{L-3}) + ... in the order the blocks finish (what an autograd engine's input buffer does)
-        if (dpos && L > 1 && l < L - 1) RUN(act_add_f32(l == L - 2 ? cur : dpos, o, dpos, (long long)TD, stream));
+        if (dpos) {
+            if (acc) { RUN(act_add_f32(acc, o, dpos, (long long)TD, stream)); acc = dpos; }
+            else acc = o;                                        // first term: nothing to add yet (depth 1 without dpos_in: the caller uses dx as dpos)
+        }
         cur = o;
     }
     return 0;

@@ -689,7 +689,8 @@ extern "C" int act_scale_rows_f32(const float* x, const float* gate, int T, int 
 }
 
 // out = a + b (float4 stream): the accumulation of a gradient that several consumers of one tensor produce (act_block_stack_bwd_f32)
-__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long long total4, float* __restrict__ out) {
+// (no __restrict__: the C ABI allows out to alias a or b -- the stack backward accumulates in place)
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, long long total4, float* out) {
     const float4* a4 = reinterpret_cast<const float4*>(a);
     const float4* b4 = reinterpret_cast<const float4*>(b);
     float4* o4 = reinterpret_cast<float4*>(out);

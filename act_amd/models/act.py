@@ -109,10 +109,12 @@ class TransformerEncoder(nn.Module):
                   drop=drop_rate, attn_drop=attn_drop_rate,
                   drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
             for i in range(depth)])
+        self.stack_chunk = None             # blocks per host call (None: ACT_BLOCK_STACK_CHUNK, 0: all); runner_pretrain.wrap_ddp sets 4 under multi-rank DDP
 
     def forward(self, x, pos, draws=None, tag="enc"):
         gates = stack_gates(self.blocks, x.shape[0], x.device, draws, self.__dict__.setdefault("_keep_cache", {}))
-        return K.block_stack(self.blocks, x, pos, gates, draws, tag)           # every block in one host call per direction (composite.BlockStackFn)
+        # every block in one host call per direction (composite.BlockStackFn)
+        return K.block_stack(self.blocks, x, pos, gates, draws, tag, self.__dict__.get("stack_chunk"))
 
 
 class TransformerDecoder(nn.Module):
@@ -126,6 +128,7 @@ class TransformerDecoder(nn.Module):
             for i in range(depth)])
         self.norm = norm_layer(embed_dim)
         self.head = nn.Identity()
+        self.stack_chunk = None             # see TransformerEncoder
         self.apply(self._init_weights)
 
     def _init_weights(self, m):
@@ -139,7 +142,7 @@ class TransformerDecoder(nn.Module):
 
     def forward(self, x, pos, return_token_num, draws=None, tag="dec"):
         gates = stack_gates(self.blocks, x.shape[0], x.device, draws, self.__dict__.setdefault("_keep_cache", {}))
-        x = K.block_stack(self.blocks, x, pos, gates, draws, tag)
+        x = K.block_stack(self.blocks, x, pos, gates, draws, tag, self.__dict__.get("stack_chunk"))
         x = x[:, -return_token_num:].contiguous()          # only the mask tokens are predicted
         return K.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
 
@@ -493,18 +496,20 @@ class ACT_PointDistillation(nn.Module):
             return K.linear(x_rec, c.weight.view(c.weight.shape[0], -1), c.bias)
         return x_rec
 
-    def prefetch_teacher(self, next_pts):
+    def prefetch_teacher(self, next_pts, draws=None):
         """Software pipelining across steps (exact: the teacher is frozen, so its features for batch i+1 do not depend on the
         optimizer step of batch i).  Enqueues grouping + teacher forward of the NEXT batch on the auxiliary stream; called by the
         runner between forward and backward of the current batch, so the teacher's large GEMMs share the chip with the student's
-        small backward kernels.  ``forward(next_pts)`` picks the result up (same tensor object, unmodified since)."""
+        small backward kernels.  ``forward(next_pts)`` picks the result up (same tensor object, unmodified since).
+        ``draws`` (parity tests): the injected draws of the NEXT step's teacher (gumbel, prompt dropout); ``forward(next_pts, draws=...)`` then accepts the
+        prefetched features instead of recomputing them, so a replayed trajectory runs the same schedule as production."""
         if not (_OVERLAP_TEACHER and _PREFETCH_TEACHER and next_pts.is_cuda and self.training):
             return
         main, side = torch.cuda.current_stream(next_pts.device), K.side_stream(next_pts.device)
         side.wait_stream(main)
         tg = self._teacher_graph
         with torch.cuda.stream(side), torch.no_grad():
-            if _TEACHER_GRAPH and tg is not None and tg["shape"] == tuple(next_pts.shape) and tg["graph"] is not None:
+            if _TEACHER_GRAPH and draws is None and tg is not None and tg["shape"] == tuple(next_pts.shape) and tg["graph"] is not None:
                 # replay the captured grouping + teacher forward (about 180 launches) as one hipGraph launch
                 tg["pts"].copy_(next_pts)
                 tg["graph"].replay()
@@ -513,7 +518,7 @@ class ACT_PointDistillation(nn.Module):
                 grouped.record(side)
                 feat = tg["feat"]             # static buffer: consumed (take_rows) before the next replay is enqueued
             else:
-                if _TEACHER_GRAPH and tg is not None and tg["shape"] == tuple(next_pts.shape) and tg["graph"] is None:
+                if _TEACHER_GRAPH and draws is None and tg is not None and tg["shape"] == tuple(next_pts.shape) and tg["graph"] is None:
                     # second call with this shape (the first one ran eagerly: workspaces, caches and the RNG counter exist): capture
                     tg["pts"] = next_pts.clone()
                     g = torch.cuda.CUDAGraph()
@@ -531,8 +536,8 @@ class ACT_PointDistillation(nn.Module):
                     neighborhood, center = self.group_divider(next_pts)
                     grouped = torch.cuda.Event()
                     grouped.record(side)
-                    feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=None)
-        self._prefetched = (next_pts, next_pts._version, neighborhood, center, feat, grouped)
+                    feat = self.dvae_tokenizer.forward_tokenizer_features(neighborhood, center, return_global=True, draws=draws)
+        self._prefetched = (next_pts, next_pts._version, neighborhood, center, feat, grouped, draws is not None)
 
     def forward(self, pts, noaug=False, draws=None, **kwargs):
         if noaug:
@@ -543,8 +548,8 @@ class ACT_PointDistillation(nn.Module):
         overlap = _OVERLAP_TEACHER and pts.is_cuda
         pre = self._prefetched
         self._prefetched = None
-        if pre is not None and pre[0] is pts and pre[1] == pts._version and draws is None:
-            _, _, neighborhood, center, teacher_feat, grouped = pre
+        if pre is not None and pre[0] is pts and pre[1] == pts._version and (draws is None) == (not pre[6]):
+            _, _, neighborhood, center, teacher_feat, grouped, _ = pre
             main, side = torch.cuda.current_stream(pts.device), K.side_stream(pts.device)
             main.wait_event(grouped)                     # the student needs the grouping now, the teacher features only at the loss
             for t in (neighborhood, center):

@@ -103,7 +103,13 @@ class FusedAdamW(optim.AdamW):
         c = self._fast.get(gi)
         params = group['params']
         if c is not None and c[0] == len(params):
-            return c
+            # re-validate by identity: ``optimizer.state[p][...] = t`` or ``optimizer.state.clear()`` replaces moments without going
+            # through load_state_dict / add_param_group; the first and the last parameter's entries are the cheap witness, a mismatch rebuilds the lists
+            s0, s1 = self.state.get(params[0]), self.state.get(params[-1])
+            if (s0 and s1 and params[0] is c[1][0] and params[-1] is c[1][-1] and s0.get('exp_avg') is c[2][0] and s1.get('exp_avg') is c[2][-1]
+                    and s0.get('exp_avg_sq') is c[3][0] and s1.get('exp_avg_sq') is c[3][-1] and s0.get('step') is c[4][0] and s1.get('step') is c[4][-1]):
+                return c
+            self._fast.pop(gi, None)
         if not (group.get('fused') and not group['amsgrad'] and not group['maximize'] and not group['capturable'] and not group['differentiable']
                 and group.get('decoupled_weight_decay', True)):
             return None

@@ -45,13 +45,21 @@ def freeze_unused_heads(model):
                 p.requires_grad = False
 
 
+def set_stack_chunk(model, chunk):
+    """blocks per composite host call for every TransformerEncoder / TransformerDecoder of ``model`` (None: process default, 0: whole stack)"""
+    from act_amd.models.act import TransformerEncoder, TransformerDecoder
+    for m in model.modules():
+        if isinstance(m, (TransformerEncoder, TransformerDecoder)):
+            m.stack_chunk = chunk
+
+
 def wrap_ddp(base_model, args):
     device_ids = [args.local_rank % torch.cuda.device_count()] if torch.cuda.is_available() and args.use_gpu else None
     if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1 and "ACT_BLOCK_STACK_CHUNK" not in os.environ:
         # a block stack hands its parameter gradients to DDP when its backward call returns: in chunks of 4 blocks the bucket all-reduces of the
-        # deeper blocks start while the shallower ones are still being differentiated (bit-identical to any other chunking, tests/test_gpu_composite.py)
-        from act_amd import composite
-        composite.STACK_CHUNK = 4
+        # deeper blocks start while the shallower ones are still being differentiated.  Set on THIS model's encoder / decoder modules (no process-wide
+        # state); bit-identical to any other chunking, the folded gradient of the shared pos included (tests/test_gpu_composite.py)
+        set_stack_chunk(base_model, 4)
     return nn.parallel.DistributedDataParallel(base_model, device_ids=device_ids, broadcast_buffers=False,
                                                gradient_as_bucket_view=True, bucket_cap_mb=25)
 
@@ -84,12 +92,12 @@ class _Announced:
         return ref is not None and ref() is t and version == t._version
 
 
-def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, draws=None, next_points=None):
+def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, draws=None, next_points=None, next_draws=None):
     """one optimisation step on a device batch [B,N,3]; returns the detached loss tensor (no host sync).
 
     ``next_points`` (optional): the NEXT batch.  It is augmented here and announced to the model, which starts its grouping and
     frozen-teacher forward on the auxiliary stream while this batch's backward runs; pass that same tensor as ``points`` of the
-    next call (it is not augmented twice)."""
+    next call (it is not augmented twice).  ``draws`` / ``next_draws`` (parity tests): injected random draws of this step / of the next step's teacher."""
     inner = base_model.module if hasattr(base_model, "module") else base_model
     if augment and not _Announced.is_marked(inner, points):
         points = train_transforms(points)
@@ -101,7 +109,7 @@ def train_step(base_model, optimizer, points, config, num_iter=1, augment=True, 
             next_points = train_transforms(next_points)
             _Announced.mark(inner, next_points)
         if hasattr(inner, "prefetch_teacher"):
-            inner.prefetch_teacher(next_points)
+            inner.prefetch_teacher(next_points, next_draws) if next_draws is not None else inner.prefetch_teacher(next_points)
     loss.backward()
     if num_iter == config.step_per_update:
         optimizer.step()
@@ -119,6 +127,10 @@ def run_net(args, config, train_writer=None, val_writer=None, max_steps=None, lo
     if args.use_gpu:
         torch.cuda.set_device(device)          # every launch goes to the current device's current stream
         base_model.to(device)
+    if args.distributed:                       # one enqueue loop per rank on one host: own cores, on the GPU's NUMA node where sysfs tells (ACT_PIN_CORES=0 disables)
+        from act_amd.utils.dist_utils import pin_rank
+        pin = pin_rank(args.local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", getattr(args, "world_size", 1))), device.index if args.use_gpu else None)
+        print_log(f'[rank {args.local_rank}] host affinity: {pin}', logger=logger)
     start_epoch, best_metrics, metrics = 0, Acc_Metric(0.), Acc_Metric(0.)
     if args.resume:
         start_epoch, best_metric = builder.resume_model(base_model, args, logger=logger)

@@ -38,3 +38,74 @@ def gather_tensor(tensor, args):
     output_tensors = [tensor.clone() for _ in range(args.world_size)]
     dist.all_gather(output_tensors, tensor)
     return torch.cat(output_tensors, dim=0)
+
+
+# ---- host-side placement of the ranks of one node ---------------------------------------------------------------------------------------
+# Every rank runs its own enqueue loop (~5 ms of Python + ~500 launches per Stage-II step against a ~26 ms GPU step): eight of them on one host must not
+# migrate between sockets or share cores.  Reference: main.py:44-67 starts one process per GPU and leaves placement to the OS.
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(device_index):
+    """CPUs of the NUMA node the GPU's PCIe function hangs off (sysfs), or None when the platform does not say (VM, container without sysfs, node -1)"""
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        return _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+    except Exception:
+        return None
+
+
+def plan_affinity(allowed, local_rank, local_world, node_cpus=None, ranks_on_node=None, max_cores=None):
+    """the CPU set of one rank: an equal, disjoint, contiguous slice of ``allowed`` (the CPUs this process may use); with ``node_cpus`` (the GPU's NUMA
+    node) the slice is cut from allowed ∩ node_cpus among the ``ranks_on_node`` = (index of this rank among the ranks of that node, their count).
+    Never returns an empty set: with fewer CPUs than ranks the ranks share round-robin."""
+    allowed = sorted(allowed)
+    pool, idx, cnt = allowed, local_rank, max(1, local_world)
+    if node_cpus:
+        inter = [c for c in allowed if c in set(node_cpus)]
+        if inter and ranks_on_node:
+            pool, (idx, cnt) = inter, ranks_on_node
+    per = len(pool) // cnt
+    if per == 0:
+        return [pool[idx % len(pool)]]
+    cores = pool[idx * per:(idx + 1) * per]
+    return cores[:max_cores] if max_cores else cores
+
+
+def pin_rank(local_rank, local_world, device_index=None, max_cores=None):
+    """os.sched_setaffinity of THIS process to its slice (ACT_PIN_CORES=0 disables); returns a description for logs / the bench line.  With one rank per
+    node nothing is pinned (the whole host is that rank's)."""
+    info = {"pinned": False, "local_rank": local_rank, "local_world": local_world}
+    if os.environ.get("ACT_PIN_CORES", "1") == "0" or local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        info["reason"] = "ACT_PIN_CORES=0" if os.environ.get("ACT_PIN_CORES", "1") == "0" else ("single rank" if local_world <= 1 else "no sched_setaffinity")
+        return info
+    allowed = sorted(os.sched_getaffinity(0))
+    node = gpu_numa_cpus(device_index) if device_index is not None and torch.cuda.is_available() else None
+    ron = None
+    if node:
+        # ranks whose GPU sits on the same node: device i -> node, by the same sysfs walk (all ranks see all devices of the node)
+        same = [r for r in range(local_world) if (gpu_numa_cpus(r % max(1, torch.cuda.device_count())) or []) == node]
+        if local_rank in same:
+            ron = (same.index(local_rank), len(same))
+    cores = plan_affinity(allowed, local_rank, local_world, node, ron, max_cores)
+    try:
+        os.sched_setaffinity(0, cores)
+    except OSError as e:
+        info["reason"] = f"sched_setaffinity failed: {e}"
+        return info
+    # the intra-op pool of torch (CPU-side tensor bookkeeping only: every kernel runs on the GPU) must not oversubscribe the slice
+    torch.set_num_threads(max(1, min(len(cores), 8)))
+    info.update(pinned=True, cores=f"{cores[0]}-{cores[-1]}" if cores == list(range(cores[0], cores[-1] + 1)) else ",".join(map(str, cores)),
+                n_cores=len(cores), numa_aware=bool(node and ron))
+    return info

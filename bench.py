@@ -254,6 +254,10 @@ def main():
                          "(N=8192 pts, 512 groups x 64 nbrs, 24-layer d=768 student, B=32/GPU) -- stage 2 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-instrument", action="store_true")
+    ap.add_argument("--preflight", action="store_true",
+                    help="<= 30 s readiness check of the multi-GPU path before a SCALE run: process-group (RCCL) init on every rank, the all-reduce probe of the "
+                         "gradient payload, ONE warm-up + TWO timed DDP steps, per-rank core pinning; one JSON line with preflight.world_size_seen_by_rccl. "
+                         "At --gpus 1 a world-1 RCCL group is initialised so the same code path runs")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short configs[2] (Stage I) and configs[4] (C5 stress) timings that the default single-GPU run appends as other_workloads")
     args = ap.parse_args()
@@ -265,16 +269,25 @@ def main():
             raise SystemExit(f"bench.py: --gpus {args.gpus} but {ndev} GPU(s) visible (ACT_BENCH_SHARE_GPU=1 ACT_BENCH_BACKEND=gloo puts every "
                              "rank on the visible devices round-robin: a test mode, not a measurement)")
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    t_proc0 = time.perf_counter()
+    if args.preflight:
+        args.steps, args.warmup = 2, 1
+        args.no_instrument = args.no_cpu_baseline = args.no_other_workloads = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP kernels are the product path; there is no CPU fallback)")
     if os.environ.get("ACT_BENCH_SHARE_GPU") == "1":                # testing on a one-GPU box: every rank on cuda:0 (use with ACT_BENCH_BACKEND=gloo)
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    force_ddp = os.environ.get("ACT_BENCH_FORCE_DDP") == "1"       # exercise the DDP/RCCL path on a single GPU (testing)
+    # one enqueue loop per rank on ONE host: give every rank its own cores, on its GPU's NUMA node where sysfs says which (ACT_PIN_CORES=0: leave it to the OS)
+    from act_amd.utils.dist_utils import pin_rank
+    affinity = pin_rank(int(os.environ.get("LOCAL_RANK", "0")), local_world, device_index=local_rank)
+    force_ddp = os.environ.get("ACT_BENCH_FORCE_DDP") == "1" or args.preflight     # exercise the DDP/RCCL path on a single GPU (testing / preflight)
+    t_pg0 = time.perf_counter()
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -283,6 +296,7 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    pg_init_s = time.perf_counter() - t_pg0
     gpus_flag = args.gpus
     if world != args.gpus:                              # the launcher's environment is the truth (main.py:44-58); never die on the flag
         if rank == 0:
@@ -402,6 +416,10 @@ def main():
         hb = [torch.zeros(2, device=device, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(hb, torch.tensor([host_idle_ms, 1e3 * host_issue / args.steps], device=device, dtype=torch.float64))
         host_by_rank = [[round(v, 3) for v in t.tolist()] for t in hb]
+    affinity_by_rank = [affinity]
+    if world > 1:
+        affinity_by_rank = [None] * world
+        dist.all_gather_object(affinity_by_rank, affinity)
     ms_by_rank = None
     if world > 1:
         el = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
@@ -477,6 +495,14 @@ def main():
     out["config"]["parity_bar"] = ("loss and features within 1e-4 of the fp32 CPU oracle at this geometry and batch; FPS / kNN indices bit-exact; gradients "
                                    "flip-tolerant: <= 1e-3 of a gradient's elements may exceed 1e-4 (the reference's own fp32 summation-order noise through the "
                                    "hard arg-max / max-pool choices), L2 error <= 5e-3 (tests/test_gpu_model.py)")
+    out["config"]["host_affinity_by_rank"] = affinity_by_rank
+    if args.preflight:
+        out["preflight"] = {"ok": True, "world_size_seen_by_rccl": comm["world_size_seen_by_rccl"], "backend": comm["backend"],
+                            "process_group_init_s": round(pg_init_s, 3), "allreduce_ms": comm["allreduce_ms"], "allreduce_payload_MB": comm["allreduce_payload_MB"],
+                            "ddp_steps_run": args.warmup + args.steps + 3, "final_loss": loss_val,
+                            "stack_chunk": next((m.stack_chunk for m in model.modules() if getattr(m, "stack_chunk", None)), 0),
+                            "ranks_pinned": sum(1 for a in affinity_by_rank if a and a.get("pinned")), "wall_s": round(time.perf_counter() - t_proc0, 2),
+                            "note": "readiness check only: 2 timed steps are not a measurement (value / ms_per_step on this line are NOT a benchmark result)"}
     if ms_by_rank:
         out["ms_per_step_by_rank"] = ms_by_rank
     if comm:

@@ -432,8 +432,11 @@ size_t act_block_stack_saved_floats(const act_block_dims_t* d, int depth, int ke
 size_t act_block_stack_bwd_scratch_floats(const act_block_dims_t* d, int depth);
 int act_block_stack_fwd_f32(const act_block_dims_t* d, const act_block_stack_t* st, const float* x, const float* pos, int keep_for_backward,
                             float* saved, float* out, float* workspace, size_t workspace_bytes, act_stream_t stream);
+/* dpos (nullable): gradient of the shared pos, folded in the order the blocks finish; with depth 1 and no dpos_in nothing is written (it IS dx).
+   dpos_in (nullable, needs dpos): the fold of the deeper chunks of the same stack -- the chain continues through it, so a stack differentiated in
+   chunks associates exactly like the unchunked call */
 int act_block_stack_bwd_f32(const act_block_dims_t* d, const act_block_stack_t* st, const float* saved, const float* dout, float* dx, float* dpos,
-                            const act_block_grads_t* grads, float* scratch, float* workspace, size_t workspace_bytes, float* side_workspace,
+                            const float* dpos_in, const act_block_grads_t* grads, float* scratch, float* workspace, size_t workspace_bytes, float* side_workspace,
                             size_t side_workspace_bytes, act_stream_t stream, act_stream_t side_stream);
 /* out[i] = a[i] + b[i] (one rounding; out may alias a or b), n % 4 == 0, 16-byte aligned */
 int act_add_f32(const float* a, const float* b, float* out, long long n, act_stream_t stream);

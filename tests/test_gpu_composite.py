@@ -75,7 +75,7 @@ def test_block_stack_is_bit_identical_to_a_chain_of_block_calls(dev, B, S, D, H,
         x = x0.clone().requires_grad_(True)
         pos = pos0.clone().requires_grad_(True) if with_pos else None
         if stacked:
-            y = CP.BlockStackFn.apply(x, pos, gates, H, 1e-5, train_w, *[p for blk in ps for p in blk])
+            y = CP.BlockStackFn.apply(x, pos, gates, H, 1e-5, train_w, False, *[p for blk in ps for p in blk])
         else:
             y = x
             for l in range(depth):
@@ -93,17 +93,112 @@ def test_block_stack_is_bit_identical_to_a_chain_of_block_calls(dev, B, S, D, H,
     # inference form (no_grad: one saved slab re-used by every block)
     with torch.no_grad():
         ps = [[p.detach() if p is not None else None for p in _params(dev, D, 4 * D, qkv_bias, 10 + l)] for l in range(depth)]
-        yi = CP.BlockStackFn.apply(x0, pos0 if with_pos else None, gates, H, 1e-5, train_w, *[p for blk in ps for p in blk])
+        yi = CP.BlockStackFn.apply(x0, pos0 if with_pos else None, gates, H, 1e-5, train_w, False, *[p for blk in ps for p in blk])
     assert torch.equal(yi, res[0][0])
+
+
+@pytest.mark.parametrize("depth,split", [(5, (2, 2, 1)), (5, (3, 2)), (5, (1, 1, 1, 1, 1)), (12, (4, 4, 4)), (6, (1, 5))])
+def test_block_stack_in_chunks_is_bit_identical_pos_gradient_included(dev, depth, split):
+    """a stack differentiated in CHUNKS (what runner_pretrain.wrap_ddp selects under multi-rank DDP: 4 blocks per host call) against the one-call
+    stack and against the per-block chain, DropPath gates on, ``pos.requires_grad``: output, dx, every parameter gradient AND the folded gradient of
+    the shared pos are torch.equal -- each chunk hands ``pos`` on as a second output, so the deeper chunks' sum re-enters the fold as ``dpos_in``
+    and the association stays ((dx_{L-1} + dx_{L-2}) + ...) instead of (s_2 + s_1) + s_0."""
+    import act_amd.composite as CP
+    B, S, D, H = 3, 14, 128, 2
+    torch.manual_seed(1)
+    x0 = torch.randn(B, S, D, device=dev); pos0 = 0.1 * torch.randn(B, S, D, device=dev)
+    gates = [(torch.floor(0.7 + torch.rand(B, device=dev)) / 0.7, torch.floor(0.7 + torch.rand(B, device=dev)) / 0.7) if l % 3 != 0 else None
+             for l in range(depth)]
+    dout = torch.randn(B, S, D, device=dev)
+    res = []
+    for mode in ("chain", "one", "chunks"):
+        ps = [_params(dev, D, 4 * D, False, 10 + l) for l in range(depth)]
+        x = x0.clone().requires_grad_(True)
+        pos = pos0.clone().requires_grad_(True)
+        if mode == "chain":
+            y = x
+            for l in range(depth):
+                g1, g2 = gates[l] if gates[l] is not None else (None, None)
+                y = CP.BlockFn.apply(y, pos, g1, g2, *ps[l], H, 1e-5, 1)
+        else:
+            y, pc, c0 = x, pos, 0
+            for n in ((depth,) if mode == "one" else split):
+                emit = c0 + n < depth
+                r = CP.BlockStackFn.apply(y, pc, gates[c0:c0 + n], H, 1e-5, 1, emit, *[p for blk in ps[c0:c0 + n] for p in blk])
+                y, pc = r if emit else (r, pc)
+                c0 += n
+        y.backward(dout)
+        torch.cuda.synchronize()
+        res.append([y.detach(), x.grad, pos.grad] + [p.grad for blk in ps for p in blk if p is not None])
+    for other in res[1:]:
+        for i, (a, b) in enumerate(zip(res[0], other)):
+            assert torch.equal(a, b), i
+    assert res[0][2].abs().max() > 0
+
+
+def test_block_stack_falls_back_for_hooked_or_overridden_blocks(dev):
+    """block_stack bypasses Module.__call__: a block with a forward hook, or a Block subclass that overrides forward, must be CALLED."""
+    import act_amd.composite as CP
+    from act_amd.models.act import TransformerEncoder, Block
+    torch.manual_seed(0)
+    enc = TransformerEncoder(embed_dim=64, depth=3, num_heads=2).to(dev)
+    x = torch.randn(2, 8, 64, device=dev); pos = torch.randn(2, 8, 64, device=dev)
+    y0 = enc(x, pos)
+    seen = []
+    h = enc.blocks[1].register_forward_hook(lambda m, i, o: seen.append(1))
+    y1 = enc(x, pos)
+    h.remove()
+    assert seen == [1] and torch.equal(y0, y1)
+
+    class Doubling(Block):
+        def forward(self, x, pos=None, draws=None, tag="blk", gates=None):
+            return 2.0 * super().forward(x, pos, draws, tag, gates)
+    for b in enc.blocks:
+        b.__class__ = Doubling
+    y2 = enc(x, pos)
+    assert not torch.equal(y0, y2)                          # the override ran
+    for b in enc.blocks:
+        b.__class__ = Block
+    assert torch.equal(enc(x, pos), y0)
+
+
+def test_block_stack_backward_follows_a_data_reassignment(dev):
+    """``param.data = other`` between forward and backward moves an address without bumping a version: the backward re-derives its pointer array
+    from the saved tensors (as BlockFn does), so stack and per-block chain still agree bit for bit."""
+    import act_amd.composite as CP
+    B, S, D, H, depth = 2, 16, 64, 2, 3
+    torch.manual_seed(0)
+    x0 = torch.randn(B, S, D, device=dev); dout = torch.randn(B, S, D, device=dev)
+    res = []
+    for stacked in (False, True):
+        ps = [_params(dev, D, 4 * D, False, 10 + l) for l in range(depth)]
+        x = x0.clone().requires_grad_(True)
+        if stacked:
+            y = CP.BlockStackFn.apply(x, None, None, H, 1e-5, 1, False, *[p for blk in ps for p in blk])
+        else:
+            y = x
+            for l in range(depth):
+                y = CP.BlockFn.apply(y, None, None, None, *ps[l], H, 1e-5, 1)
+        w = ps[1][8]                                         # fc1 weight of the middle block: same values at a NEW address, old storage poisoned
+        old = w.data
+        w.data = old.clone()
+        old.fill_(float("nan"))
+        y.backward(dout)
+        torch.cuda.synchronize()
+        res.append([x.grad] + [p.grad for blk in ps for p in blk if p is not None])
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), i
 
 
 def test_block_stack_training_trajectory_is_bit_identical(dev):
     """the tiny Stage-II model trained for 3 AdamW steps with the stack-level host calls (default) and with one BlockFn per block (ACT_BLOCK_STACK=0
-    semantics), DropPath active, cross-step teacher prefetch on: losses and every parameter torch.equal; also in chunks of 2 blocks per call."""
+    semantics), DropPath ACTIVE (rate 0.25 set on every block: the tiny YAML has 0), cross-step teacher prefetch on: losses and every parameter
+    torch.equal; also in chunks of ONE block per call (depth 2: two chunks, so the pos carry between chunks is on the path), selected per model the way
+    wrap_ddp does it (runner_pretrain.set_stack_chunk)."""
     import act_amd.composite as CP
     from act_amd.models import build_model_from_cfg
     from act_amd.tools import builder
-    from act_amd.tools.runner_pretrain import train_step, _Single, freeze_unused_heads
+    from act_amd.tools.runner_pretrain import train_step, _Single, freeze_unused_heads, set_stack_chunk
     from act_amd.utils.config import EasyDict
     from tests.golden.fill import fill_module, clouds, TINY_STAGE2, TINY_B, TINY_N
     cfg = EasyDict(optimizer=dict(type="AdamW", kwargs=dict(lr=1e-3, weight_decay=0.05)),
@@ -112,11 +207,14 @@ def test_block_stack_training_trajectory_is_bit_identical(dev):
     saved = (CP.STACK, CP.STACK_CHUNK)
     results = []
     try:
-        for stack, chunk in ((False, 0), (True, 0), (True, 2), (False, 0)):
-            CP.STACK, CP.STACK_CHUNK = stack, chunk
+        for stack, chunk in ((False, 0), (True, 0), (True, 1), (False, 0)):
+            CP.STACK = stack
             torch.manual_seed(0)
             model = fill_module(build_model_from_cfg(EasyDict(copy.deepcopy(TINY_STAGE2))), "g4.").to(dev).train()
             model.dvae_tokenizer.prompt_dropout.p = 0.0
+            for blk in list(model.ACT_encoder.blocks.blocks) + list(model.ACT_decoder.blocks):
+                blk.drop_prob = 0.25
+            set_stack_chunk(model, chunk)
             freeze_unused_heads(model)
             wrapped = _Single(model)
             opt, _ = builder.build_opti_sche(wrapped, cfg)

@@ -329,6 +329,40 @@ def test_fused_adamw_fast_path_equals_torch_adamw():
         assert all(torch.equal(sa[k][n], sb[k][n]) for n in ('step', 'exp_avg', 'exp_avg_sq'))
 
 
+def test_fused_adamw_cache_follows_direct_state_replacement():
+    """moments replaced WITHOUT load_state_dict (``optimizer.state[p]['exp_avg'] = t`` on the first / last parameter of a group, or
+    ``optimizer.state.clear()``) must not leave the fast path updating orphaned tensors: trajectories stay torch.equal to torch.optim.AdamW under
+    the same surgery, and state_dict() reports the tensors that are being updated."""
+    import copy
+    from act_amd.tools.builder import FusedAdamW
+    torch.manual_seed(0)
+    net_a = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Linear(8, 3))
+    net_b = copy.deepcopy(net_a)
+    oa = FusedAdamW(net_a.parameters(), lr=1e-2, weight_decay=0.05, fused=True)
+    ob = torch.optim.AdamW(net_b.parameters(), lr=1e-2, weight_decay=0.05, fused=True)
+    for i in range(8):
+        x = torch.randn(5, 6)
+        for net, o in ((net_a, oa), (net_b, ob)):
+            net(x).pow(2).sum().backward()
+            o.step(); o.zero_grad()
+            ps = list(net.parameters())
+            if i == 2:
+                o.state[ps[0]]['exp_avg'] = torch.full_like(ps[0], 0.5)          # first parameter's first moment replaced
+            if i == 4:
+                o.state[ps[-1]]['exp_avg_sq'] = torch.full_like(ps[-1], 0.25)    # last parameter's second moment replaced
+            if i == 6:
+                o.state.clear()                                                  # optimizer state dropped: lazily re-created by the stock step
+        if i == 1:
+            assert 0 in oa._fast
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert torch.equal(pa, pb)
+    sa, sb = oa.state_dict()['state'], ob.state_dict()['state']
+    for k in sb:
+        assert all(torch.equal(sa[k][n], sb[k][n]) for n in ('step', 'exp_avg', 'exp_avg_sq'))
+    c = oa._lists(0, oa.param_groups[0])
+    assert c is not None and all(oa.state[p]['exp_avg'] is m for p, m in zip(c[1], c[2]))
+
+
 def test_announced_batch_marker_does_not_break_pickling():
     """runner_pretrain._Announced keeps its weak reference OUTSIDE the module: a model that went through train_step bookkeeping pickles"""
     import io
@@ -351,3 +385,32 @@ def test_split_bf16_teacher_is_off_unless_asked_for():
     assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300).stdout.strip() == "0"
     assert subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, ACT_TEACHER_BF16X3="1"), capture_output=True, text=True,
                           timeout=300).stdout.strip() == "1"
+
+
+def test_rank_affinity_plan_is_disjoint_and_numa_aware():
+    """dist_utils.plan_affinity / pin_rank (eight enqueue loops share one host): equal disjoint slices of the allowed CPUs, cut from
+    the GPU's NUMA node when known, never empty; pin_rank really narrows the affinity of a process (checked in a child so this process keeps its own)."""
+    import subprocess
+    import sys
+    from act_amd.utils.dist_utils import plan_affinity, _parse_cpulist
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    allowed = list(range(256))
+    slices = [plan_affinity(allowed, r, 8) for r in range(8)]
+    assert all(len(s) == 32 for s in slices) and sorted(c for s in slices for c in s) == allowed
+    # two sockets: GPUs 0-3 on node 0 (cpus 0-63 + 128-191), GPUs 4-7 on node 1
+    node0 = list(range(0, 64)) + list(range(128, 192)); node1 = [c for c in allowed if c not in set(node0)]
+    sl = [plan_affinity(allowed, r, 8, node0 if r < 4 else node1, (r % 4, 4)) for r in range(8)]
+    assert all(len(s) == 32 for s in sl) and sorted(c for s in sl for c in s) == allowed
+    assert all(set(sl[r]) <= set(node0) for r in range(4)) and all(set(sl[r]) <= set(node1) for r in range(4, 8))
+    assert plan_affinity([3, 5], 5, 8) == [5] and plan_affinity(allowed, 0, 8, max_cores=4) == [0, 1, 2, 3]
+    assert plan_affinity(allowed, 1, 2, node_cpus=[999], ranks_on_node=(0, 1)) == list(range(128, 256))       # a node outside the cpuset: plain slices
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); from act_amd.utils.dist_utils import pin_rank; a = sorted(os.sched_getaffinity(0)); "
+            "i = pin_rank(1, 2); b = sorted(os.sched_getaffinity(0)); "
+            "print(len(a), len(b), i['pinned'], b == a[len(a) // 2: 2 * (len(a) // 2)] if len(a) > 1 else True); "
+            "os.environ['ACT_PIN_CORES'] = '0'; print(pin_rank(0, 2)['pinned'], pin_rank(0, 1)['pinned'])" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    l1, l2 = r.stdout.strip().splitlines()[-2:]
+    na, nb, pinned, ok = l1.split()
+    assert ok == "True" and (pinned == "True") == (int(na) > 1) and l2 == "False False"
