@@ -1182,6 +1182,199 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_reg_kernel(const AttnRegArgs 
     }
 }
 
+// =================================================================================== single-pass backward (round 6)
+// The two-role kernel above executes 7 matmul units per 5 algorithmic ones (S and dP are recomputed in both roles) and fetches every fragment of
+// every tile pair from global memory.  This kernel computes S and dP ONCE per 32x32 tile pair: 160 MFMAs instead of 224.
+//   * a workgroup = 4 waves owns PAIRS = 4 / KW (cloud, head) pairs; wave kw of a pair owns 32 keys of the current block of KW key tiles: K, V rows stay in
+//     registers (row form) and dK^t, dV^t accumulate in registers over all query tiles, exactly like the dK / dV role above;
+//   * the 32-query tile of Q and dO is staged ONCE per pair in LDS ([32][HD + 4]; both fragment forms are conflict-free reads of it: row form = b128,
+//     col form = b64) together with lse and D = rowsum(dO * O) of its queries, instead of 40 global loads per wave and tile pair;
+//   * dS goes through a wave-private [32][36] LDS tile to come back transposed (4 x ds_write_b128 + 16 x ds_read_b32, no barrier: the wave's own LDS
+//     queue is in order), which makes dS^t the B operand of the wave's partial dQ^t = K^t dS^t over ITS 32 keys (K in col form: the only global fragment);
+//   * the KW partial dQ tiles of a pair meet in LDS and are summed in wave order by the pair's threads (deterministic, no atomics); with more than one
+//     key block the sum continues through global memory (the workgroup owns its rows).
+// Two workgroup barriers per query tile (stage -> compute -> reduce); two workgroups per CU cover each other's staging.  Tails as above: the last
+// tile of a side is shifted back to end at the last row, the rows it shares with its neighbour are masked out of P / not stored.
+template <int HD, int KW>
+__global__ __launch_bounds__(256, 2) void attn_bwd_one_kernel(const AttnRegArgs a) {
+    constexpr int PAIRS = 4 / KW, NDT = HD / 32, LDQ = HD + 4, LDT = 36, C4 = HD / 4;
+    constexpr int PSZ = 2 * 32 * LDQ + 64;                             // floats per pair: Q tile | dO tile | lse[32] | D[32]
+    constexpr int XSZ = 32 * LDQ;                                      // floats per wave: dS^t [32][LDT] first, then the partial dQ [32][LDQ]
+    constexpr int NT = 64 * KW;                                        // threads of a pair group
+    constexpr int ITS = 32 * C4 / NT;                                  // float4 per thread and staged operand
+    static_assert(32 * LDT <= XSZ && (32 * C4) % NT == 0, "layout");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int pl = wave / KW, kw = wave % KW, tp = tid - pl * NT;      // pair slot, key tile inside the block, thread inside the pair group
+    const int Sk = a.S0 + a.S1, D = a.H * HD;
+    const int nqt = (a.Sq + 31) >> 5, nkt = (Sk + 31) >> 5, nkb = (nkt + KW - 1) / KW;
+    const float scale = a.scale;
+    const unsigned pr = blockIdx.x * (unsigned)PAIRS + (unsigned)pl;
+    const bool pair_ok = pr < (unsigned)(a.B * a.H);
+    const int b = __builtin_amdgcn_readfirstlane(pair_ok ? (int)(pr / (unsigned)a.H) : 0);
+    const int h = __builtin_amdgcn_readfirstlane(pair_ok ? (int)(pr % (unsigned)a.H) : 0);
+    float* Qs = smem + (size_t)pl * PSZ; float* Gs = Qs + 32 * LDQ; float* Ls = Gs + 32 * LDQ; float* Ds = Ls + 32;
+    float* Xp = smem + (size_t)PAIRS * PSZ + (size_t)pl * KW * XSZ;    // the KW partial tiles of this pair
+    float* X = Xp + (size_t)kw * XSZ;                                  // this wave's
+    const float* qb = a.q + (size_t)b * a.q_bs + h * HD;
+    const float* ob = a.out + (size_t)b * a.Sq * D + h * HD;
+    const float* gb = a.dout + (size_t)b * a.Sq * D + h * HD;
+    const float* lb = a.lse + ((size_t)b * a.H + h) * a.Sq;
+    float* dqb = a.dq + (size_t)b * a.q_bs + h * HD;
+    const float* k0 = a.k0 + (size_t)b * a.kv0_bs + h * HD; const float* v0 = a.v0 + (size_t)b * a.kv0_bs + h * HD;
+    const float* k1 = a.k1 + (size_t)b * a.kv1_bs + h * HD; const float* v1 = a.v1 + (size_t)b * a.kv1_bs + h * HD;
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int kt = kb * KW + kw;
+        const bool work = pair_ok && kt < nkt;                         // wave-uniform
+        const int nact = min(KW, nkt - kb * KW);                       // partial tiles to sum
+        const int k0n = kt * 32, k0s = min(k0n, Sk - 32);
+        const AttSeg kg = att_seg_tile(k0, a.ld0, k1, a.ld1, a.S0, work ? k0s : 0);
+        float kreg[HD / 2], vreg[HD / 2];
+        f32x16 dk[NDT], dv[NDT];
+        if (work) {
+            att_load_row_form<HD>(kg, ql, half, kreg);
+            att_load_row_form<HD>(att_seg_tile(v0, a.ld0, v1, a.ld1, a.S0, k0s), ql, half, vreg);
+        }
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+        const bool keyok = k0s + ql >= k0n;                            // keys shared with the previous tile belong to that tile
+        for (int u = 0; u < nqt; ++u) {
+            const int u0n = u * 32, u0 = min(u0n, a.Sq - 32);
+            // ---- stage Q, dO (LDS) and lse, D = rowsum(dO * O) of the 32 queries: C4 consecutive lanes own one row
+            if (pair_ok) {
+#pragma unroll
+                for (int it = 0; it < ITS; ++it) {
+                    if (it > 0 && (it & 1) == 0) __builtin_amdgcn_sched_barrier(0);       // at most two rows' worth of staging registers in flight
+                    const int idx = tp + NT * it, row = idx / C4, c4 = idx % C4;
+                    const float4 qv = *reinterpret_cast<const float4*>(qb + (size_t)(u0 + row) * a.ldq + 4 * c4);
+                    const float4 gv = *reinterpret_cast<const float4*>(gb + (size_t)(u0 + row) * D + 4 * c4);
+                    const float4 ov = *reinterpret_cast<const float4*>(ob + (size_t)(u0 + row) * D + 4 * c4);
+                    *reinterpret_cast<float4*>(Qs + row * LDQ + 4 * c4) = qv;
+                    *reinterpret_cast<float4*>(Gs + row * LDQ + 4 * c4) = gv;
+                    float part = (gv.x * ov.x + gv.y * ov.y) + (gv.z * ov.z + gv.w * ov.w);
+#pragma unroll
+                    for (int m = C4 / 2; m >= 1; m >>= 1) part += __shfl_xor(part, m);
+                    if (c4 == 0) { Ds[row] = part; Ls[row] = lb[u0 + row]; }
+                }
+            }
+            __syncthreads();
+            if (work) {
+                f32x16 sa, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+                {
+                    float fr[HD / 2];
+                    const float* gp = Gs + ql * LDQ + half * (HD / 2);
+#pragma unroll
+                    for (int i = 0; i < HD / 8; ++i) { const float4 t = *reinterpret_cast<const float4*>(gp + 4 * i); fr[4 * i] = t.x; fr[4 * i + 1] = t.y; fr[4 * i + 2] = t.z; fr[4 * i + 3] = t.w; }
+#pragma unroll
+                    for (int s2 = 0; s2 < HD / 2; ++s2) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s2], vreg[s2], dp, 0, 0, 0);
+                    const float* qp = Qs + ql * LDQ + half * (HD / 2);
+#pragma unroll
+                    for (int i = 0; i < HD / 8; ++i) { const float4 t = *reinterpret_cast<const float4*>(qp + 4 * i); fr[4 * i] = t.x; fr[4 * i + 1] = t.y; fr[4 * i + 2] = t.z; fr[4 * i + 3] = t.w; }
+#pragma unroll
+                    for (int s2 = 0; s2 < HD / 2; ++s2) sa = __builtin_amdgcn_mfma_f32_32x32x2f32(fr[s2], kreg[s2], sa, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // P and dS: register r <-> query u0 + f(r, half), lane <-> key k0s + ql
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(Ls + 8 * g + 4 * half);
+                    const float4 d4 = *reinterpret_cast<const float4*>(Ds + 8 * g + 4 * half);
+                    const float lr[4] = {l4.x, l4.y, l4.z, l4.w}, dr[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g + j;
+                        const float pv = (keyok && u0 + 8 * g + 4 * half + j >= u0n) ? __expf(scale * sa[r] - lr[j]) : 0.f;
+                        sa[r] = pv;
+                        dp[r] = pv * (dp[r] - dr[j]) * scale;
+                    }
+                    // dS^t: T[key = ql][query = 8g + 4 half + 0..3]
+                    *reinterpret_cast<float4*>(X + ql * LDT + 8 * g + 4 * half) = make_float4(dp[4 * g], dp[4 * g + 1], dp[4 * g + 2], dp[4 * g + 3]);
+                }
+                {   // dV^t += dO^t P
+                    float fc[16][NDT];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float* rp = Gs + ATT_F(r, half) * LDQ + NDT * ql;
+                        if constexpr (NDT == 2) { const float2 t = *reinterpret_cast<const float2*>(rp); fc[r][0] = t.x; fc[r][1] = t.y; } else fc[r][0] = rp[0];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int dt = 0; dt < NDT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc[r][dt], sa[r], dv[dt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // dK^t += Q^t dS
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float* rp = Qs + ATT_F(r, half) * LDQ + NDT * ql;
+                        if constexpr (NDT == 2) { const float2 t = *reinterpret_cast<const float2*>(rp); fc[r][0] = t.x; fc[r][1] = t.y; } else fc[r][0] = rp[0];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int dt = 0; dt < NDT; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc[r][dt], dp[r], dk[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // K of this wave's keys in col form (the A operand of the partial dQ; the only fragment that still comes from global memory: L2 hits, the
+                // other wave of the SIMD owns the matrix pipe meanwhile)
+                float kc[16][NDT];
+                att_load_col_form<HD>(kg, ql, half, kc);
+                // partial dQ^t = K^t dS^t over this wave's keys: dS^t[key = f(r, half)][query = ql] back from the wave's own tile
+                float dst[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[r] = X[ATT_F(r, half) * LDT + ql];
+                f32x16 dq[NDT];
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int dt = 0; dt < NDT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[r][dt], dst[r], dq[dt], 0, 0, 0);
+                att_store_o<HD>(X + ql * LDQ, half, dq, 1.0f);         // (every dS^t value of this wave is in registers by now: same region)
+            }
+            __syncthreads();
+            // ---- dQ rows of this query tile: sum of the pair's partial tiles in wave order (+ what earlier key blocks left in global memory)
+            if (pair_ok) {
+#pragma unroll
+                for (int it = 0; it < ITS; ++it) {
+                    const int idx = tp + NT * it, row = idx / C4, c4 = idx % C4;
+                    float4 acc = *reinterpret_cast<const float4*>(Xp + row * LDQ + 4 * c4);
+                    for (int w = 1; w < nact; ++w) {
+                        const float4 t = *reinterpret_cast<const float4*>(Xp + (size_t)w * XSZ + row * LDQ + 4 * c4);
+                        acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+                    }
+                    if (u0 + row >= u0n) {
+                        float* dst4 = dqb + (size_t)(u0 + row) * a.ldq + 4 * c4;
+                        if (kb > 0) {
+                            const float4 t = *reinterpret_cast<const float4*>(dst4);
+                            acc.x = t.x + acc.x; acc.y = t.y + acc.y; acc.z = t.z + acc.z; acc.w = t.w + acc.w;
+                        }
+                        *reinterpret_cast<float4*>(dst4) = acc;
+                    }
+                }
+            }
+            // (no barrier here: the next tile's staging writes the Q / dO region, which every wave finished reading before the barrier above; the
+            //  partial region is written again only after the next staging barrier, by when every thread has left this reduction)
+        }
+        if (work) {
+            const int key = k0s + ql;
+            if (key >= k0n) {
+                float* dkp = key < a.S0 ? a.dk0 + (size_t)b * a.kv0_bs + (size_t)key * a.ld0 + h * HD : a.dk1 + (size_t)b * a.kv1_bs + (size_t)(key - a.S0) * a.ld1 + h * HD;
+                float* dvp = key < a.S0 ? a.dv0 + (size_t)b * a.kv0_bs + (size_t)key * a.ld0 + h * HD : a.dv1 + (size_t)b * a.kv1_bs + (size_t)(key - a.S0) * a.ld1 + h * HD;
+                att_store_o<HD>(dkp, half, dk, 1.0f);
+                att_store_o<HD>(dvp, half, dv, 1.0f);
+            }
+        }
+    }
+}
+
 static const bool g_attn_small = [] { const char* e = getenv("ACT_ATTN_SMALL"); return !(e && e[0] == '0'); }();      // dev A/B knob
 
 static const bool g_attn_reg = [] { const char* e = getenv("ACT_ATTN_REG"); return !(e && e[0] == '0'); }();          // dev A/B knob: 0 = LDS-staged kernels
@@ -1199,7 +1392,29 @@ static int launch_attn_fwd_reg(const AttnRegArgs& a, int head_dim, hipStream_t s
     ACT_LAUNCH_CHECK();
     return 0;
 }
+// ACT_ATTN_BWD_ONE: 1 (default) = the single-pass kernel wherever the register kernels' tile conditions hold, 0 = the two-role kernel (A/B)
+static const bool g_attn_bwd_one = [] { const char* e = getenv("ACT_ATTN_BWD_ONE"); return !(e && e[0] == '0'); }();
+template <int HD, int KW>
+static int launch_attn_bwd_one_t(const AttnRegArgs& a, hipStream_t s) {
+    constexpr int PAIRS = 4 / KW;
+    const size_t smem = ((size_t)PAIRS * (2 * 32 * (HD + 4) + 64) + (size_t)4 * 32 * (HD + 4)) * sizeof(float);
+    auto k = attn_bwd_one_kernel<HD, KW>;
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long long pairs = (long long)a.B * a.H;
+    hipLaunchKernelGGL(k, dim3((unsigned)((pairs + PAIRS - 1) / PAIRS)), dim3(256), smem, s, a);
+    ACT_LAUNCH_CHECK();
+    return 0;
+}
+static int launch_attn_bwd_one(const AttnRegArgs& a, int head_dim, hipStream_t s) {
+    const int nkt = (a.S0 + a.S1 + 31) / 32;
+    if (head_dim == 64) return nkt <= 2 ? launch_attn_bwd_one_t<64, 2>(a, s) : launch_attn_bwd_one_t<64, 4>(a, s);
+    return nkt <= 2 ? launch_attn_bwd_one_t<32, 2>(a, s) : launch_attn_bwd_one_t<32, 4>(a, s);
+}
 static int launch_attn_bwd_reg(const AttnRegArgs& a, int head_dim, hipStream_t s) {
+    if (g_attn_bwd_one) return launch_attn_bwd_one(a, head_dim, s);
     const long long pairs = (long long)a.B * a.H;
     const unsigned ndq = (unsigned)((pairs * ((a.Sq + 31) / 32) + 3) / 4), ndkv = (unsigned)((pairs * ((a.S0 + a.S1 + 31) / 32) + 3) / 4);
     // the heavier dK / dV items (128 MFMAs per tile pair) are dispatched first? no: dQ blocks first -- their stores are the ones a following

@@ -474,7 +474,9 @@ def test_attention_prefix_and_teacher_block_prefix(K):
 @pytest.mark.parametrize("B,S0,Sq,H,hd", [(2, 20, 33, 3, 64), (2, 64, 64, 12, 64), (3, 8, 16, 2, 32), (1, 100, 70, 2, 64),
                                            (2, 0, 40, 2, 64), (1, 130, 129, 1, 32),
                                            # the register-resident kernels (S0 % 32 == 0, Sq >= 32): shifted tail tiles on either side, both head dims
-                                           (2, 64, 40, 2, 64), (2, 32, 33, 2, 64), (1, 64, 104, 3, 32), (1, 64, 512, 2, 64), (3, 96, 32, 1, 64), (5, 0, 63, 2, 32)])
+                                           (2, 64, 40, 2, 64), (2, 32, 33, 2, 64), (1, 64, 104, 3, 32), (1, 64, 512, 2, 64), (3, 96, 32, 1, 64), (5, 0, 63, 2, 32),
+                                           # single-pass backward (round 6): two pairs per workgroup with an odd pair count, one key tile, several key blocks with a ragged last one
+                                           (3, 0, 64, 1, 64), (1, 32, 32, 3, 64), (3, 0, 32, 1, 32), (1, 128, 200, 1, 64), (2, 64, 64, 6, 32)])
 def test_attention_prefix_backward(K, B, S0, Sq, H, hd):
     """dQ / dK / dV of the own rows and dK / dV of the prefix rows against a float64 reference."""
     kv0 = _rnd(f"pb.kv{S0}{Sq}", B * max(S0, 1), 2 * H * hd)[:B * S0]; qkv = _rnd(f"pb.qkv{S0}{Sq}", B * Sq, 3 * H * hd)

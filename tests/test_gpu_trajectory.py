@@ -60,9 +60,17 @@ def test_twenty_step_trajectory_vs_oracle(dev, prefetch):
     for g in opt_g.param_groups:                             # (the scheduler's epoch-0 warm-up value is the runner's business: same constant lr on both sides)
         g["lr"] = 1e-3
 
+    # A Conv1d bias in front of a BatchNorm has a mathematically ZERO gradient (the normalisation removes it); what AdamW sees there is fp32 rounding noise,
+    # which it normalises to steps of up to lr -- in the reference as much as here.  Those biases random-walk differently on the two sides and shift the BN
+    # input mean with them, so for the two student BatchNorms the running MEAN is compared after removing exactly that (recorded) contribution.
+    BIASED = {"ACT_encoder.encoder.first_conv.1.running_mean": "ACT_encoder.encoder.first_conv.0.bias",
+              "ACT_encoder.encoder.second_conv.1.running_mean": "ACT_encoder.encoder.second_conv.0.bias"}
+    hist_o = {b: [] for b in BIASED.values()}; hist_g = {b: [] for b in BIASED.values()}
     batches = [_augmented(300 + k, B) for k in range(STEPS)]
     lo, tables = [], []
     for k in range(STEPS):
+        for bn in hist_o:
+            hist_o[bn].append(dict(oracle.named_parameters())[bn].detach().clone())
         rec = OL.Draws(record=True)
         loss = oracle(batches[k], rec)
         loss.backward()
@@ -72,7 +80,10 @@ def test_twenty_step_trajectory_vs_oracle(dev, prefetch):
 
     dbat = [b.to(dev) for b in batches]
     lg = []
+    pgm = dict(model.named_parameters())
     for k in range(STEPS):
+        for bn in hist_g:
+            hist_g[bn].append(pgm[bn].detach().cpu().clone())
         nxt = dbat[k + 1] if (prefetch and k + 1 < STEPS) else None
         # (the look-ahead teacher forward of batch k+1 consumes the NEXT step's teacher draws: gumbel, prompt dropout)
         lg.append(train_step(wrapped, opt_g, dbat[k], rcfg, next_points=nxt, augment=False, draws=Draws(tables[k], device=dev),
@@ -96,7 +107,14 @@ def test_twenty_step_trajectory_vs_oracle(dev, prefetch):
         if n.endswith("num_batches_tracked"):
             assert int(bg[n].item()) == int(t.item()), n
         elif n.endswith("running_mean") or n.endswith("running_var"):
-            d = (bg[n].detach().cpu().double() - t.double()).abs().max().item()
+            diff = bg[n].detach().cpu().double() - t.double()
+            if n in BIASED:                                  # EMA (momentum 0.1) of the bias difference the statistic saw at each step
+                exp = torch.zeros_like(diff)
+                for k in range(STEPS):
+                    exp = 0.9 * exp + 0.1 * (hist_g[BIASED[n]][k].double() - hist_o[BIASED[n]][k].double())
+                print(f"[trajectory] {n}: raw difference {diff.abs().max().item():.2e}, of which the zero-gradient conv bias explains {exp.abs().max().item():.2e}")
+                diff = diff - exp
+            d = diff.abs().max().item()
             assert d <= 5 * TOL * max(1.0, t.abs().max().item()), (n, d)
             n_stats += 1
     assert n_stats >= 4                                      # student mini-PointNet (2 BN) + the train-mode teacher's
