@@ -37,6 +37,7 @@ SIGNATURES = {
     "act_prof_read": [_i, _vp, _vp, _vp, _vp],
     "act_fps_scratch_floats": [_i, _i],
     "act_fps_f32": [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
+    "act_fps_chain_probe": [_i, _i, _vp, _vp, _vp, _vp],
     "act_knn_group_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp],
     "act_gather_points_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "act_gather_points_bwd_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],

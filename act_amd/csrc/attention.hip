@@ -38,14 +38,18 @@ struct AttnFwdArgs {
 // per chunk: an exposed LDS round trip per 128 MFMA cycles.  The transpose costs nothing: a lane = one head-dimension column loads the four keys of a
 // quad with four coalesced dword loads (a wave reads a 256-byte row segment per instruction) and writes them with one conflict-free ds_write_b128.
 // Same products in the same order: bit-identical to VT = false (tests/test_gpu_dense.py).
-template <int HD, int JT, int QT, bool VT>
-__global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const AttnFwdArgs a) {
+// NW (round 6) = waves per workgroup: 4, or 2 = ONE pair per workgroup at QT = 2 (Sq = 64: only the two query tiles of a pair share K / V, so a barrier need not couple two
+// pairs; 6 independent workgroups per CU instead of 3).  PRIO: s_setprio 1 around the MFMA bursts (waves in their softmax / staging phase yield the issue port).
+template <int HD, int JT, int QT, bool VT, int NW = 4, bool PRIO = false>
+__global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const AttnFwdArgs a) {
+    constexpr int NTHR = NW * 64;
     constexpr int LDK = HD + 4;
-    constexpr int PAIRS = (QT == 1) ? 4 : (QT == 2 ? 2 : 1);       // (cloud, head) pairs per workgroup
+    constexpr int PAIRS = NW / QT;                                  // (cloud, head) pairs per workgroup (NW = 4: 4 / 2 / 1 / 1 for QT = 1 .. 4)
+    static_assert(PAIRS >= 1, "a workgroup holds at least the query tiles of one pair");
     constexpr int ROWS = JT * 32;
     constexpr int LDT = ROWS + 4;                                   // Vt row pitch: 4 (mod 32) dwords -> conflict-free b128 reads / writes
     constexpr int KSZ = ROWS * LDK, VSZ = VT ? HD * LDT : ROWS * LDK, PSZ = KSZ + VSZ;     // floats per pair: K image, V image
-    static_assert((ROWS * (HD / 4)) % 256 == 0, "staging: whole iterations per pair");
+    static_assert((ROWS * (HD / 4)) % NTHR == 0, "staging: whole iterations per pair");
     extern __shared__ __attribute__((aligned(16))) float smem[];    // [PAIRS][K image | V image]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, Sk = a.S0 + a.S1;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
     // load-latency bound: every chunk paid a full L2 / fabric round trip between its two barriers (MfmaUtil 36 %).  ROWS * HD / 4 is a multiple of 256, so all
     // threads of an iteration work on the same pair: the (cloud, head) split is wave-uniform 32-bit arithmetic done once per pair, not a 64-bit division per float4.
     // Only for JT = 1 (8 float4 per thread at QT >= 2; the larger resident chunks would need 64-128 staging registers and lose a wave per SIMD or spill).
-    constexpr int ITS = ROWS * (HD / 4) / 256;
+    constexpr int ITS = ROWS * (HD / 4) / NTHR;
     constexpr bool PF = (JT <= 2 && QT >= 2);
     float4 kreg[PAIRS][ITS], vreg[PAIRS][ITS];
     // VT: staging item idx = (key quad idx / HD, column idx % HD): the four keys kc + 4*quad + 0..3 of one column, zero beyond Sk.  The launcher takes
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
             const float* k1p = a.k1 + (size_t)b2 * a.kv1_bs + h2 * HD; const float* v1p = a.v1 + (size_t)b2 * a.kv1_bs + h2 * HD;
 #pragma unroll
             for (int it = 0; it < ITS; ++it) {
-                const int idx = tid + 256 * it;
+                const int idx = tid + NTHR * it;
                 const int c4 = idx % (HD / 4), rl = idx / (HD / 4), row = kc + rl;
                 float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
                 if (live && row < Sk) {
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
                 float* kd = smem + (size_t)p2 * PSZ; float* vd = kd + KSZ;
 #pragma unroll
                 for (int it = 0; it < ITS; ++it) {
-                    const int idx = tid + 256 * it;
+                    const int idx = tid + NTHR * it;
                     const int c4 = idx % (HD / 4), rl = idx / (HD / 4);
                     *reinterpret_cast<float4*>(kd + rl * LDK + c4 * 4) = kreg[p2][it];
                     *reinterpret_cast<float4*>(vd + v_lds_offset(idx)) = VT ? mask_vt(vreg[p2][it], kc, idx) : vreg[p2][it];
@@ -173,8 +177,8 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
                 const float* k1p = a.k1 + (size_t)b2 * a.kv1_bs + h2 * HD; const float* v1p = a.v1 + (size_t)b2 * a.kv1_bs + h2 * HD;
                 float* kd = smem + (size_t)p2 * PSZ; float* vd = kd + KSZ;
     #pragma unroll
-                for (int it = 0; it < ROWS * (HD / 4) / 256; ++it) {
-                    const int idx = tid + 256 * it;
+                for (int it = 0; it < ROWS * (HD / 4) / NTHR; ++it) {
+                    const int idx = tid + NTHR * it;
                     const int c4 = idx % (HD / 4), rl = idx / (HD / 4), row = kc + rl;
                     float4 kx = make_float4(0.f, 0.f, 0.f, 0.f), vx = kx;
                     if (live && row < Sk) {
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
         if (!active) continue;                                       // idle waves only help staging
         // ---- S^T tiles: acc[jt][r] = score(key = kc + jt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
         f32x16 acc[JT];
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
@@ -210,6 +215,7 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
                 acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[s4 * 4 + 3], acc[jt], 0, 0, 0);
             }
         }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- online softmax over keys (registers + one lane^32 exchange)
         float mc = -3.0e38f;
 #pragma unroll
@@ -243,6 +249,7 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
         }
         // ---- O^T += V^T P^T : o[dt][r] = out(d = dt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
         if constexpr (VT) {
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(256, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const 
                         o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], acc[jt][r], o[dt], 0, 0, 0);
                 }
         }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     if (active && q < a.Sq) {
         const float inv_l = 1.0f / l;
@@ -1195,7 +1203,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_reg_kernel(const AttnRegArgs 
 //     key block the sum continues through global memory (the workgroup owns its rows).
 // Two workgroup barriers per query tile (stage -> compute -> reduce); two workgroups per CU cover each other's staging.  Tails as above: the last
 // tile of a side is shifted back to end at the last row, the rows it shares with its neighbour are masked out of P / not stored.
-template <int HD, int KW>
+template <int HD, int KW, bool PRIO = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_one_kernel(const AttnRegArgs a) {
     constexpr int PAIRS = 4 / KW, NDT = HD / 32, LDQ = HD + 4, LDT = 36, C4 = HD / 4;
     constexpr int PSZ = 2 * 32 * LDQ + 64;                             // floats per pair: Q tile | dO tile | lse[32] | D[32]
@@ -1264,6 +1272,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_kernel(const AttnRegArgs 
             __syncthreads();
             if (work) {
                 f32x16 sa, dp;
+                if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
                 {
@@ -1338,6 +1347,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_kernel(const AttnRegArgs 
 #pragma unroll
                     for (int dt = 0; dt < NDT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[r][dt], dst[r], dq[dt], 0, 0, 0);
                 att_store_o<HD>(X + ql * LDQ, half, dq, 1.0f);         // (every dS^t value of this wave is in registers by now: same region)
+                if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
             // ---- dQ rows of this query tile: sum of the pair's partial tiles in wave order (+ what earlier key blocks left in global memory)
@@ -1398,7 +1408,8 @@ template <int HD, int KW>
 static int launch_attn_bwd_one_t(const AttnRegArgs& a, hipStream_t s) {
     constexpr int PAIRS = 4 / KW;
     const size_t smem = ((size_t)PAIRS * (2 * 32 * (HD + 4) + 64) + (size_t)4 * 32 * (HD + 4)) * sizeof(float);
-    auto k = attn_bwd_one_kernel<HD, KW>;
+    static const bool prio = [] { const char* e = getenv("ACT_ATTN_BWD_PRIO"); return e && e[0] == '1'; }();      // dev A/B knob
+    auto k = prio ? attn_bwd_one_kernel<HD, KW, true> : attn_bwd_one_kernel<HD, KW, false>;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -1446,21 +1457,32 @@ static int launch_attn_bwd_mfma(const AttnBwdArgs& a, int head_dim, hipStream_t 
 // S = 512 226 -> 238 us, profiles/r05_attn_vt_ab.txt): the four dword loads per quad cost more than the sixteen exposed ds_read_b32 round trips they remove --
 // three waves per SIMD already hide those.  Kept as a measured non-improvement; bit-identical either way.
 static const bool g_attn_vt = [] { const char* e = getenv("ACT_ATTN_VT"); return e && e[0] == '1'; }();
-template <int HD, int JT, int QT>
-static int launch_attn_fwd3(const AttnFwdArgs& a, hipStream_t s) {
-    constexpr int pairs = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
-    const bool vt = g_attn_vt && (a.S0 % (JT * 32)) == 0;              // a key chunk must not straddle the two key segments (kernel comment)
-    const size_t smem = (size_t)pairs * (JT * 32 * (HD + 4) + (vt ? HD * (JT * 32 + 4) : JT * 32 * (HD + 4))) * sizeof(float);
+// dev A/B knobs (round 6): ACT_ATTN_FWD_NW=2 -> one pair per 128-thread workgroup where QT == 2; ACT_ATTN_FWD_PRIO=1 -> s_setprio around the MFMA bursts
+static const int g_attn_fwd_nw = [] { const char* e = getenv("ACT_ATTN_FWD_NW"); return e ? atoi(e) : 4; }();
+static const bool g_attn_fwd_prio = [] { const char* e = getenv("ACT_ATTN_FWD_PRIO"); return e && e[0] == '1'; }();
+template <int HD, int JT, int QT, bool VT, int NW, bool PRIO>
+static int launch_attn_fwd4(const AttnFwdArgs& a, hipStream_t s) {
+    constexpr int pairs = NW / QT;
+    const size_t smem = (size_t)pairs * (JT * 32 * (HD + 4) + (VT ? HD * (JT * 32 + 4) : JT * 32 * (HD + 4))) * sizeof(float);
     const long long np = (long long)a.B * a.H;
     const unsigned gx = (unsigned)((np + pairs - 1) / pairs), gy = (unsigned)((a.Sq + QT * 32 - 1) / (QT * 32));
-    auto k = vt ? attn_fwd_kernel<HD, JT, QT, true> : attn_fwd_kernel<HD, JT, QT, false>;
+    auto k = attn_fwd_kernel<HD, JT, QT, VT, NW, PRIO>;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k, dim3(gx, gy), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(k, dim3(gx, gy), dim3(NW * 64), smem, s, a);
     ACT_LAUNCH_CHECK();
     return 0;
+}
+template <int HD, int JT, int QT>
+static int launch_attn_fwd3(const AttnFwdArgs& a, hipStream_t s) {
+    const bool vt = g_attn_vt && (a.S0 % (JT * 32)) == 0;              // a key chunk must not straddle the two key segments (kernel comment)
+    if constexpr (QT == 2 && JT <= 2) {
+        if (!vt && g_attn_fwd_nw == 2) return g_attn_fwd_prio ? launch_attn_fwd4<HD, JT, QT, false, 2, true>(a, s) : launch_attn_fwd4<HD, JT, QT, false, 2, false>(a, s);
+        if (!vt && g_attn_fwd_prio) return launch_attn_fwd4<HD, JT, QT, false, 4, true>(a, s);
+    }
+    return vt ? launch_attn_fwd4<HD, JT, QT, true, 4, false>(a, s) : launch_attn_fwd4<HD, JT, QT, false, 4, false>(a, s);
 }
 template <int HD>
 static int launch_attn_fwd(const AttnFwdArgs& a, hipStream_t s) {

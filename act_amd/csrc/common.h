@@ -18,6 +18,9 @@ enum ActKernelId {
 void act_prof_begin(int kid, hipStream_t s, double flops, double bytes);
 void act_prof_end(int kid, hipStream_t s);
 extern int g_act_prof_on;
+// fraction of non-zero int32 flags (group-liveness lists), read back SYNCHRONOUSLY: only while the instrumented pass of bench.py is on -- never on the hot
+// path -- so that the byte model of a kernel that skips dead rows counts the rows it touches; 1.0 when profiling is off or flags == null
+double act_prof_live_fraction(const int32_t* flags, int n, hipStream_t s);
 
 struct ActProfScope {
     int kid; hipStream_t s; bool on;

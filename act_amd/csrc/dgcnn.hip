@@ -231,7 +231,9 @@ extern "C" int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, con
     if (!yz || !gamma || !beta || !stats || !out) return ACT_E_NULLPTR;
     if (B <= 0 || G <= 0 || k <= 0 || C <= 0 || groups <= 0 || C % groups) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * k + (zoff >= 0 ? 2 : 0) + 1));
+    // compulsory bytes (round 6): y (and z) [B G, C] read once, out written once, the k-neighbour index list read once -- the k gathers of both passes hit
+    // rows that are already on the chip (the previous model counted them as 2k reads of HBM)
+    ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * ((zoff >= 0 ? 2 : 1) + 1) + 8.0 * B * G * (double)k);
     float* mean = stats; float* rstd = stats + (size_t)B * groups;
     float* part = stats + (size_t)2 * B * groups;
     {
@@ -394,7 +396,8 @@ extern "C" int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff,
     if (!yz || !gamma || !beta || !stats || !dout || !dyz || !part || !mstat) return ACT_E_NULLPTR;
     if (B <= 0 || G <= 0 || k <= 0 || C <= 0 || groups <= 0 || C % groups || (!idx && (k != 1 || zoff >= 0))) return ACT_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
-    ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * (k + (zoff >= 0 ? 1 : 0)) + 2.0 + (zoff >= 0 ? 2 : 1)));
+    // compulsory bytes: y (and z) and dout read once, dy (and dz) written once, index list read once
+    ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * (zoff >= 0 ? 2 : 1) + 1.0) + 8.0 * B * G * (double)k);
     const float* mean = stats; const float* rstd = stats + (size_t)B * groups;
     hipLaunchKernelGGL(edge_gn_bwd_partials_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, yz, ldy, zoff, idx, B, G, k, C, groups, mean,
                        rstd, gamma, beta, slope, dout, ldd, part);

@@ -217,6 +217,141 @@ extern "C" int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_o
     return 0;
 }
 
+// ---- latency probes of the FPS critical path (measurement infrastructure for bench.py `group_fps_knn.fps_chain`; not on any product path) -------------
+// One FPS iteration is a chain of four dependent phases; each phase is timed on its own as `iters` dependent repetitions inside ONE workgroup (the chip is
+// otherwise idle, so this is latency, not throughput), with s_memrealtime (100 MHz, constant) stamps taken by thread 0:
+//   0 eval    PPL x (sqdist3 + min + integer compare / select) on register-resident points     -- VALU issue of one wave (every wave does the same in parallel)
+//   1 argmax  6-step DPP integer max + ballot + readlane                                        -- the wave reduction
+//   2 xwave   LDS slot write, s_barrier, the cross-wave arg-max (scan for WAVES < 8, DPP row reduction from 8 waves on)
+//   3 centre  3 dependent LDS reads at a wave-uniform, data-dependent address                   -- the winner's coordinates
+//   4 all     the four phases chained as in fps_kernel (a workgroup alone on the chip)
+// The sum of 0..3 is the floor of a design that serialises the phases; `all` shows what the hardware overlaps between them.
+template <int WAVES, int PPL>
+__global__ __launch_bounds__(WAVES * 64) void fps_chain_probe_kernel(int iters, unsigned long long* __restrict__ ticks, int* __restrict__ sink) {
+    __shared__ int s_vali[2 * WAVES], s_idx[2 * WAVES];
+    __shared__ float s_xyz[WAVES * 64 * PPL * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, base = tid * PPL;
+    constexpr int N = WAVES * 64 * PPL;
+    float px[PPL], py[PPL], pz[PPL], td[PPL];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+        const int k = base + j;
+        px[j] = __sinf(0.37f * k); py[j] = __cosf(0.11f * k + 1.f); pz[j] = __sinf(0.05f * k + 2.f); td[j] = 1e10f;
+        s_xyz[k * 3 + 0] = px[j]; s_xyz[k * 3 + 1] = py[j]; s_xyz[k * 3 + 2] = pz[j];
+    }
+    __syncthreads();
+    float cx = px[0], cy = py[0], cz = pz[0];
+    int best = 0, bj = 0, old = 0, acc = 0;
+    unsigned long long t[6];
+    auto eval = [&]() {
+        best = (int)0x80000000; bj = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const float d = sqdist3(px[j], py[j], pz[j], cx, cy, cz);
+            const float tt = fminf(td[j], d);
+            td[j] = tt;
+            const int ti = __float_as_int(tt);
+            if (ti > best) { best = ti; bj = j; }
+        }
+    };
+    auto argmax = [&]() -> int {
+        const int wmax = wave_max_i32(best, (int)0x80000000);
+        const int wl = first_lane(__ballot(best == wmax));
+        const int widx = __builtin_amdgcn_readlane(base + bj, wl);
+        if (lane == 0) { s_vali[wave] = wmax; s_idx[wave] = widx; }      // (kept out of the timed dependency of phase 1 by the caller)
+        return widx;
+    };
+    auto xwave = [&](int par, int wmax, int widx) -> int {
+        if (WAVES == 1) return widx;
+        if (lane == 0) { s_vali[par * WAVES + wave] = wmax; s_idx[par * WAVES + wave] = widx; }
+        __syncthreads();
+        if constexpr (WAVES >= 8) {
+            const int v = lane < WAVES ? s_vali[par * WAVES + lane] : (int)0x80000000;
+            const int id = lane < WAVES ? s_idx[par * WAVES + lane] : 0;
+            int mx = v;
+            mx = max(mx, dpp_mov_i<0x111, 0xf>((int)0x80000000, mx));
+            mx = max(mx, dpp_mov_i<0x112, 0xf>((int)0x80000000, mx));
+            mx = max(mx, dpp_mov_i<0x114, 0xf>((int)0x80000000, mx));
+            mx = max(mx, dpp_mov_i<0x118, 0xf>((int)0x80000000, mx));
+            const int gmax = __builtin_amdgcn_readlane(mx, 15);
+            const int gl = first_lane(__ballot(v == gmax && lane < WAVES));
+            return __builtin_amdgcn_readlane(id, gl);
+        } else {
+            int gv = s_vali[par * WAVES]; int gi = s_idx[par * WAVES];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) {
+                const int v = s_vali[par * WAVES + w];
+                if (v > gv) { gv = v; gi = s_idx[par * WAVES + w]; }
+            }
+            return gi;
+        }
+    };
+    // ---- phase 0: distance evaluations (the chain runs through cx: the next iteration's centre depends on this one's result)
+    __syncthreads(); t[0] = wall_clock64();
+    for (int it = 0; it < iters; ++it) { eval(); cx = __int_as_float(__float_as_int(cx) ^ (best & 1)); }
+    acc += best + bj;
+    // ---- phase 1: wave arg-max
+    __syncthreads(); t[1] = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        const int wmax = wave_max_i32(best, (int)0x80000000);
+        const int wl = first_lane(__ballot(best == wmax));
+        const int widx = __builtin_amdgcn_readlane(base + bj, wl);
+        best = best ^ (widx & 1); bj = (bj + widx) & (PPL - 1);
+    }
+    acc += best;
+    // ---- phase 2: cross-wave arg-max through LDS + barrier
+    __syncthreads(); t[2] = wall_clock64();
+    { int w = best, id = base;
+      for (int it = 0; it < iters; ++it) { id = xwave(it & 1, w, id); w ^= id & 1; }
+      acc += id + w; }
+    // ---- phase 3: the winner's coordinates from LDS
+    __syncthreads(); t[3] = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        cx = s_xyz[old * 3 + 0]; cy = s_xyz[old * 3 + 1]; cz = s_xyz[old * 3 + 2];
+        old = (__float_as_int(cx) ^ __float_as_int(cy) ^ __float_as_int(cz)) & (N - 1);
+    }
+    acc += old;
+    // ---- phase 4: the whole iteration, as in fps_kernel
+    __syncthreads(); t[4] = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+        eval();
+        const int wmax = wave_max_i32(best, (int)0x80000000);
+        const int wl = first_lane(__ballot(best == wmax));
+        int widx = __builtin_amdgcn_readlane(base + bj, wl);
+        widx = xwave(it & 1, wmax, widx);
+        old = widx & (N - 1);
+        cx = s_xyz[old * 3 + 0]; cy = s_xyz[old * 3 + 1]; cz = s_xyz[old * 3 + 2];
+    }
+    acc += old + best;
+    __syncthreads(); t[5] = wall_clock64();
+    if (tid == 0) for (int i = 0; i < 5; ++i) ticks[i] = t[i + 1] - t[i];
+    if (acc == 0x7fffffff) sink[tid] = acc;                                 // keep every chain alive
+}
+
+// us_per_iteration[5] = {eval, argmax, xwave, centre, all} for the launch configuration act_fps_f32 uses at this N (N <= 8192); synchronises the stream
+extern "C" int act_fps_chain_probe(int N, int iters, double* us_per_iteration, int* waves_out, int* ppl_out, act_stream_t stream) {
+    if (!us_per_iteration) return ACT_E_NULLPTR;
+    if (N <= 0 || N > 8192 || iters <= 0) return ACT_E_BADARG;           // (larger clouds do not keep their coordinates in LDS)
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* ticks = nullptr; int* sink = nullptr;
+    if (hipMalloc(&ticks, 5 * sizeof(unsigned long long)) != hipSuccess) return ACT_E_BADARG;
+    if (hipMalloc(&sink, 1024 * sizeof(int)) != hipSuccess) { (void)hipFree(ticks); return ACT_E_BADARG; }
+    int W = 0, P = 0;
+#define PROBE(W_, P_) { W = W_; P = P_; hipLaunchKernelGGL((fps_chain_probe_kernel<W_, P_>), dim3(1), dim3(W_ * 64), 0, s, iters, ticks, sink); }
+    if (N <= 256) PROBE(1, 4) else if (N <= 1024) PROBE(4, 4) else if (N <= 2048) PROBE(4, 8) else if (N <= 4096) PROBE(8, 8) else PROBE(16, 8)
+#undef PROBE
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, ticks, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(ticks); (void)hipFree(sink);
+    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < 5; ++i) us_per_iteration[i] = (double)h[i] * 0.01 / (double)iters;      // s_memrealtime: 100 MHz
+    if (waves_out) *waves_out = W;
+    if (ppl_out) *ppl_out = P;
+    return 0;
+}
+
 // =========================================== kNN + group ==========================================
 // one wave per query; PPL reference points per lane (contiguous), N <= 64*PPL
 template <int PPL>

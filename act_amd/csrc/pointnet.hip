@@ -298,7 +298,9 @@ extern "C" int act_bn_bwd_groups_f32(const float* x, const float* dy, const floa
     int rpb = (R + parts - 1) / parts; rpb = (rpb + 3) / 4 * 4;
     const int nparts = (R + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
-    ActProfScope ps(KID_BN_BWD, s, 0.0, 20.0 * R * (double)C);
+    // compulsory bytes (round 6; the two-pass kernel re-reads x / dy, mostly from L2): x read once, dy of the LIVE rows read once, dx written once
+    const double live_frac = live ? act_prof_live_fraction(live, R / n, s) : 1.0;
+    ActProfScope ps(KID_BN_BWD, s, 0.0, 4.0 * R * (double)C * (2.0 + live_frac));
     // the kernel choice (and with it the fp32 summation order of dgamma / dbeta) depends on the SHAPE only: C % 4 == 0 takes the 16-byte
     // forms and requires 16-byte aligned operands (BADARG otherwise) instead of silently falling back to the scalar order
     const bool vec = (C % 4 == 0);

@@ -387,7 +387,9 @@ extern "C" int act_group_max_bwd_matmul_live_f32(const float* dout, const int32_
         return ACT_E_BADARG;
     if (G == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * (double)C * N, 4.0 * G * ((double)n * N + 2.0 * C));
+    // compulsory bytes: dx [G n, N] written, dout + arg [G, C] of the live groups read, w [C, N] read once (dead groups: their dx rows are zero-filled)
+    const double lf_dx = (live && pool_live_on()) ? act_prof_live_fraction(live, G, s) : 1.0;
+    ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * lf_dx * (double)C * N, 4.0 * (G * ((double)n * N + 2.0 * C * lf_dx) + (double)C * N));
     const size_t lds = (size_t)C * 8 + (size_t)(n + 1 + 4) * 4 + (size_t)C * 2;
     const int parts = 1024 / N, skip = pool_live_on() ? 1 : 0;
     if (n % parts == 0) {
@@ -434,7 +436,10 @@ extern "C" int act_group_max_bwd_wgrad_f32(const float* dout, const int32_t* arg
         hipLaunchKernelGGL(pool_bwd_flags_kernel, dim3((G + 3) / 4), dim3(256), 0, s, dout, G, C, flags);
         hipLaunchKernelGGL(pool_bwd_compact_kernel, dim3(1), dim3(1024), 0, s, flags, G, live, nlive);
     }
-    ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * (double)C * N, 4.0 * ((double)G * n * N * (C / (64 * nw)) + 2.0 * G * C * (N / 64) + (double)C * N));
+    // compulsory bytes (round 6): x rows of the LIVE groups read once, their dout + arg read once, dw [C, N] written once.  (The kernel re-reads x once per
+    // 64 nw-channel block and dout / arg once per 64-column slice -- L2 traffic, which the previous model counted and which made alg_GBs exceed the HBM peak.)
+    const double lf_dw = flags ? act_prof_live_fraction(flags, G, s) : 1.0;
+    ActProfScope ps(KID_MAXPOOL_BWD, s, 2.0 * G * lf_dw * (double)C * N, 4.0 * (G * lf_dw * ((double)n * N + 2.0 * C) + (double)C * N));
     float* part = splits > 1 ? workspace : dw;
     const int ldp = splits > 1 ? N : lddw;
     const size_t stride = (size_t)C * N;

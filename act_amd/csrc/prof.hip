@@ -41,6 +41,16 @@ void fold(State& s) {
 }
 }  // namespace
 
+double act_prof_live_fraction(const int32_t* flags, int n, hipStream_t stream) {
+    if (!g_act_prof_on || !flags || n <= 0) return 1.0;
+    std::vector<int32_t> h((size_t)n);
+    if (hipMemcpyAsync(h.data(), flags, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return 1.0;
+    if (hipStreamSynchronize(stream) != hipSuccess) return 1.0;
+    long long live = 0;
+    for (int32_t v : h) live += v != 0;
+    return (double)live / (double)n;
+}
+
 void act_prof_begin(int kid, hipStream_t stream, double flops, double bytes) {
     State& s = st();
     std::lock_guard<std::mutex> g(s.mu);

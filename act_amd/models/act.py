@@ -100,6 +100,9 @@ def stack_gates(blocks, B, device, draws, cache):
     return [(g[2 * i], g[2 * i + 1]) if b.drop_prob > 0 else None for i, b in enumerate(blocks)]
 
 
+_FT_OVERLAP_DW = os.environ.get("ACT_FT_OVERLAP_DW", "0") == "1"       # PointTransformer (finetune): measured per workload, see DESIGN
+
+
 class TransformerEncoder(nn.Module):
     def __init__(self, embed_dim=768, depth=4, num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None,
                  drop_rate=0., attn_drop_rate=0., drop_path_rate=0.):
@@ -292,6 +295,10 @@ class PointTransformer(nn.Module):
         self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.embed_dim))
         dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
         self.blocks = TransformerEncoder(embed_dim=self.embed_dim, depth=self.depth, drop_path_rate=dpr, num_heads=self.num_heads)
+        if _FT_OVERLAP_DW:                  # weight-gradient GEMMs of the blocks on auxiliary stream 1, as in Stage II (bit-identical schedule)
+            for m in self.blocks.modules():
+                if isinstance(m, Block):
+                    m.overlap_wgrad = True
         self.norm = nn.LayerNorm(self.embed_dim)
         if config.transfer_type == 'linear':
             self.cls_head_finetune = nn.Sequential(nn.Linear(self.embed_dim * 2, self.cls_dim))

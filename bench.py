@@ -189,6 +189,57 @@ def other_workloads(timeout_s=100):
     return res
 
 
+def point_op_latency_models(pts, G, M, C, reps=20, clock_ghz=2.4):
+    """What bounds FPS and kNN-group (their HBM fraction is small by construction and must be read next to a latency model).
+    fps_chain: FPS is G-1 dependent arg-max steps; per-step latency as launched (hipEvents over the kernel / (G-1)) against the floor = sum of the four
+    dependent phases of one step, each measured on its own by the s_memrealtime-stamped micro act_fps_chain_probe (one workgroup of the same launch
+    configuration, chip otherwise idle): distance evaluations, wave arg-max, cross-wave arg-max (LDS slot + barrier), winner's coordinates.
+    knn_valu: kNN-group is VALU-issue bound: G*N exact-rounded distance evaluations (3 sub + 3 mul + 2 add, no FMA: 8 lane-ops) + G*K extract-min rounds
+    (6-step DPP min + ballot + readlane + tournament-tree refresh: ~40 wave instructions) against 4 issue cycles per wave instruction on 1,024 SIMDs."""
+    import ctypes
+    from act_amd.pointnet2_ops import pointnet2_utils as pu
+    from act_amd.knn_cuda import knn_group
+    B, N, _ = pts.shape
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3                # us
+    _, center = pu.furthest_point_sample_with_centers(pts, G)
+    fps_us = timed(lambda: pu.furthest_point_sample_with_centers(pts, G))
+    knn_us = timed(lambda: knn_group(pts, center, M, want_nbr=True))
+    res = {}
+    us = (ctypes.c_double * 5)(); w, p = ctypes.c_int(0), ctypes.c_int(0)
+    if N <= 8192:
+        rc = C.lib.act_fps_chain_probe(N, 4000, us, ctypes.byref(w), ctypes.byref(p), C.stream())
+        if rc != 0:
+            raise RuntimeError(f"act_fps_chain_probe -> {rc}")
+        floor = sum(us[0:4])
+        per_it = fps_us / max(G - 1, 1)
+        res["fps_chain"] = {"iterations": G - 1, "kernel_us": fps_us, "us_per_iteration": per_it, "floor_us_per_iteration": floor,
+                            "frac_of_floor": floor / per_it,
+                            "phases_us": {"distance_evals_%d_per_lane" % p.value: us[0], "wave_argmax_dpp": us[1], "cross_wave_lds_barrier_%d_waves" % w.value: us[2],
+                                          "centre_reload_lds": us[3]},
+                            "whole_iteration_one_workgroup_alone_us": us[4], "waves": w.value, "points_per_lane": p.value,
+                            "note": "floor = sum of the four dependent phases, each timed as 4000 dependent repetitions in one workgroup on an idle chip "
+                                    "(s_memrealtime); us_per_iteration = hipEvent time of the launch at B=%d / (G-1), which also carries launch, cloud load and "
+                                    "index / centre write-back" % B}
+    evals, rounds = float(B) * G * N, float(B) * G * M
+    wave_instr = evals / 64.0 * 8.0 + rounds * 40.0
+    floor_knn = wave_instr * 4.0 / (1024.0 * clock_ghz * 1e3)   # us: 4 issue cycles per wave instruction, 1,024 SIMDs
+    res["knn_valu"] = {"distance_evals": evals, "extract_min_rounds": rounds, "wave_instructions_model": wave_instr, "floor_us": floor_knn, "kernel_us": knn_us,
+                       "frac_of_floor": floor_knn / knn_us, "clock_ghz_assumed": clock_ghz,
+                       "note": "VALU-issue model: 8 lane-ops per exact-rounded squared distance (packed fp32 halves the mul / add part: the floor is an upper "
+                               "bound on the work), ~40 wave instructions per extract-min round; HBM side of this launch: %.1f us" %
+                               ((12.0 * N + 12.0 * G + 20.0 * G * M) * B / PEAK_HBM_GBS / 1e3)}
+    return res
+
+
 XGMI_LINK_GBS = 153.0               # per xGMI link and direction; 7 links per GPU (point-to-point, fully connected 8-GPU node)
 
 
@@ -618,7 +669,14 @@ def main():
         fps_b = (12.0 * N + 16.0 * G_) * B                          # algorithmic bytes / cloud: 13,312 (C2) / 106,496 (C5)
         knn_b = (12.0 * N + 12.0 * G_ + 20.0 * G_ * M_) * B         # 54,016 (C2) / 759,808 (C5)
         out["group_fps_knn"] = {"Mpts_per_s": B * N / (gms * 1e-3) / 1e6, "ms": gms,
-                                "alg_GBs": (fps_b + knn_b) / (gms * 1e-3) / 1e9, "frac_hbm": (fps_b + knn_b) / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                                "alg_GBs": (fps_b + knn_b) / (gms * 1e-3) / 1e9, "frac_hbm": (fps_b + knn_b) / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "frac_hbm_note": "small by construction (BASELINE.md section 2): the %.1f MB of a batch would take %.1f us at the HBM rate; "
+                                                 "what bounds these kernels is the serial chain / VALU issue models below" %
+                                                 ((fps_b + knn_b) / 1e6, (fps_b + knn_b) / PEAK_HBM_GBS / 1e3)}
+        try:
+            out["group_fps_knn"].update(point_op_latency_models(gpts, G_, M_, C))
+        except Exception as e:                               # a report, never a reason to lose the bench line
+            out["group_fps_knn"]["fps_chain"] = {"failed": str(e)[-200:]}
 
     # ---- BASELINE configs[2] (Stage I, B=128) and configs[4] (C5 stress, B=32): short timings of the same bench in child processes, after the
     # headline's timed region (this process is idle meanwhile) -- so the driver's own line carries them, not only profiles/.  ~20 s each.

@@ -39,6 +39,10 @@ int         act_prof_read(int id, double* total_ms, long long* launches, double*
 size_t act_fps_scratch_floats(int B, int N);   /* 0 for N <= 16384 (the cloud lives in registers / LDS), else B*N running distances */
 int act_fps_f32(const float* xyz, int B, int N, int G, int32_t* idx_out, float* centers_out,
                 int skip_near_origin, float* scratch /* act_fps_scratch_floats floats, NULL when that is 0 */, act_stream_t stream);
+/* Measurement infrastructure (bench.py: group_fps_knn.fps_chain), not a product entry point: latency in microseconds per iteration of the four dependent
+   phases of one FPS step -- {distance evaluations, wave arg-max, cross-wave arg-max (LDS + barrier), winner's coordinates} -- and of the whole step, each
+   timed as `iters` dependent repetitions in ONE workgroup of the launch configuration act_fps_f32 uses for clouds of N points (N <= 8192).  Synchronises. */
+int act_fps_chain_probe(int N, int iters, double* us_per_iteration /* [5] */, int* waves_out, int* points_per_lane_out, act_stream_t stream);
 
 /* knn_cuda.KNN(k).forward fused with Group's gather + centre subtraction
  * (models/dvae.py:159,172-182; DGCNN graph k=4 models/dvae.py:23,68).
