@@ -143,7 +143,11 @@ def test_twenty_step_trajectory_vs_oracle(dev, prefetch):
             scale = max(1.0, t.abs().max().item())
             d, spread = stat_diff(bg, hist_g, n), stat_diff(b2, hist_2, n)
             report.append(f"{n}: |HIP - oracle| {d:.2e}; oracle vs oracle (other thread count) {spread:.2e}; scale {scale:.2e}")
-            if d > max(5 * TOL * scale, 3 * spread):
+            # BN2 sits behind several zero-gradient directions at once (first_conv.3.bias, second_conv.0.bias, the columns of second_conv.0.weight that see
+            # per-group constants: 1 vs 8 oracle threads move them by 3e-4 .. 5e-4 in 20 steps, and BN2's mean with them by 8e-4 .. 3.5e-3): on top of the
+            # measured spread a fixed allowance of 5e-3 of the statistic's scale -- a wrong momentum or variance correction would be off by 1e-1
+            allow = 5e-3 * scale if n.startswith(E + "second_conv.1.") else 0.0
+            if d > max(5 * TOL * scale, 3 * spread, allow):
                 bad.append(report[-1])
             n_stats += 1
     print("[trajectory] oracle vs oracle loss spread %.2e\n[trajectory] " % max(abs(x - y) for x, y in zip(lo, lo2)) + "\n[trajectory] ".join(report))
