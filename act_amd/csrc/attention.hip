@@ -120,12 +120,44 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
     auto v_lds_offset = [&](int idx) -> int {                        // where staging item idx of a pair goes inside the pair's V image
         return VT ? (idx % HD) * LDT + 4 * (idx / HD) : (idx / (HD / 4)) * LDK + (idx % (HD / 4)) * 4;
     };
+    // (cloud, head) of every pair of the workgroup: wave-uniform, divided ONCE (a 32-bit division is ~25 VALU instructions, and it sat inside the chunk loop)
+    int pb[PAIRS], ph[PAIRS];
+#pragma unroll
+    for (int p2 = 0; p2 < PAIRS; ++p2) {
+        const unsigned pr2 = (unsigned)pair0 + p2;
+        const bool live = (long long)pr2 < npairs;
+        const unsigned b2 = live ? pr2 / (unsigned)H : 0u;
+        pb[p2] = __builtin_amdgcn_readfirstlane((int)b2);
+        ph[p2] = __builtin_amdgcn_readfirstlane((int)(live ? pr2 - b2 * (unsigned)H : 0u));
+    }
+    const bool all_live = pair0 + PAIRS <= npairs;
     auto load_chunk = [&](int kc) {
+        // fast path (round 6): a FULL chunk inside ONE key segment, every pair of the workgroup live -- all rows valid, base pointer and row pitch are
+        // wave-uniform: an SGPR base plus one 32-bit lane offset per item instead of per-item compares, 64-bit address arithmetic and exec-masked
+        // branches (the PMC pass showed 6.5 VALU instructions per MFMA at the teacher shape, 110 of the 290 per chunk in this staging code)
+        const bool in0 = kc + ROWS <= a.S0, in1 = kc >= a.S0 && kc + ROWS <= Sk;
+        if (!VT && all_live && (in0 || in1)) {
+            const unsigned ld = in0 ? a.ld0 : a.ld1;
+            const int r0 = in0 ? kc : kc - a.S0;
+#pragma unroll
+            for (int p2 = 0; p2 < PAIRS; ++p2) {
+                const size_t po = (in0 ? (size_t)pb[p2] * a.kv0_bs : (size_t)pb[p2] * a.kv1_bs) + (size_t)ph[p2] * HD + (size_t)r0 * ld;
+                const float* kb = (in0 ? a.k0 : a.k1) + po; const float* vb = (in0 ? a.v0 : a.v1) + po;
+#pragma unroll
+                for (int it = 0; it < ITS; ++it) {
+                    const int idx = tid + NTHR * it;
+                    const unsigned of = (unsigned)(idx / (HD / 4)) * ld + (idx % (HD / 4)) * 4;
+                    kreg[p2][it] = *reinterpret_cast<const float4*>(kb + of);
+                    vreg[p2][it] = *reinterpret_cast<const float4*>(vb + of);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int p2 = 0; p2 < PAIRS; ++p2) {
             const unsigned pr2 = (unsigned)pair0 + p2;
             const bool live = (long long)pr2 < npairs;
-            const unsigned b2 = live ? pr2 / (unsigned)H : 0u, h2 = live ? pr2 - b2 * (unsigned)H : 0u;
+            const unsigned b2 = (unsigned)pb[p2], h2 = (unsigned)ph[p2];
             const float* k0p = a.k0 + (size_t)b2 * a.kv0_bs + h2 * HD; const float* v0p = a.v0 + (size_t)b2 * a.kv0_bs + h2 * HD;
             const float* k1p = a.k1 + (size_t)b2 * a.kv1_bs + h2 * HD; const float* v1p = a.v1 + (size_t)b2 * a.kv1_bs + h2 * HD;
 #pragma unroll
@@ -218,15 +250,22 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- online softmax over keys (registers + one lane^32 exchange)
         float mc = -3.0e38f;
+        if (kc + ROWS <= Sk) {                                       // (wave-uniform) a full chunk has no key to mask: 3 VALU instructions per score less
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
+            for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kc + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float v = key < Sk ? acc[jt][r] : -3.0e38f;
-                acc[jt][r] = v;
-                mc = fmaxf(mc, v);
-            }
+                for (int r = 0; r < 16; ++r) mc = fmaxf(mc, acc[jt][r]);
+        } else {
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kc + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float v = key < Sk ? acc[jt][r] : -3.0e38f;
+                    acc[jt][r] = v;
+                    mc = fmaxf(mc, v);
+                }
+        }
         mc = fmaxf(mc, __shfl_xor(mc, 32));
         const float mn = fmaxf(m, mc);
         const float alpha = __expf(scale * (m - mn));                // 0 on the first chunk (m = -huge)
