@@ -1242,9 +1242,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_reg_kernel(const AttnRegArgs 
 //     key block the sum continues through global memory (the workgroup owns its rows).
 // Two workgroup barriers per query tile (stage -> compute -> reduce); two workgroups per CU cover each other's staging.  Tails as above: the last
 // tile of a side is shifted back to end at the last row, the rows it shares with its neighbour are masked out of P / not stored.
-template <int HD, int KW, bool PRIO = false>
-__global__ __launch_bounds__(256, 2) void attn_bwd_one_kernel(const AttnRegArgs a) {
-    constexpr int PAIRS = 4 / KW, NDT = HD / 32, LDQ = HD + 4, LDT = 36, C4 = HD / 4;
+// NP = pairs per workgroup (64 * KW * NP threads): 4 / KW fills a 256-thread workgroup; NP = 1 at KW = 2 (S = 64: 128-thread workgroups, one pair each) spreads the
+// 768 pairs of the student decoder over three workgroups per CU instead of 1.5 (A/B: ACT_ATTN_BWD_NP)
+template <int HD, int KW, int NP = 4 / KW>
+__global__ __launch_bounds__(64 * KW * NP, 2) void attn_bwd_one_kernel(const AttnRegArgs a) {
+    constexpr int PAIRS = NP, NDT = HD / 32, LDQ = HD + 4, LDT = 36, C4 = HD / 4;
     constexpr int PSZ = 2 * 32 * LDQ + 64;                             // floats per pair: Q tile | dO tile | lse[32] | D[32]
     constexpr int XSZ = 32 * LDQ;                                      // floats per wave: dS^t [32][LDT] first, then the partial dQ [32][LDQ]
     constexpr int NT = 64 * KW;                                        // threads of a pair group
@@ -1311,7 +1313,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_kernel(const AttnRegArgs 
             __syncthreads();
             if (work) {
                 f32x16 sa, dp;
-                if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
                 {
@@ -1386,7 +1387,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_one_kernel(const AttnRegArgs 
 #pragma unroll
                     for (int dt = 0; dt < NDT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[r][dt], dst[r], dq[dt], 0, 0, 0);
                 att_store_o<HD>(X + ql * LDQ, half, dq, 1.0f);         // (every dS^t value of this wave is in registers by now: same region)
-                if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
             // ---- dQ rows of this query tile: sum of the pair's partial tiles in wave order (+ what earlier key blocks left in global memory)
@@ -1443,25 +1443,24 @@ static int launch_attn_fwd_reg(const AttnRegArgs& a, int head_dim, hipStream_t s
 }
 // ACT_ATTN_BWD_ONE: 1 (default) = the single-pass kernel wherever the register kernels' tile conditions hold, 0 = the two-role kernel (A/B)
 static const bool g_attn_bwd_one = [] { const char* e = getenv("ACT_ATTN_BWD_ONE"); return !(e && e[0] == '0'); }();
-template <int HD, int KW>
+template <int HD, int KW, int NP>
 static int launch_attn_bwd_one_t(const AttnRegArgs& a, hipStream_t s) {
-    constexpr int PAIRS = 4 / KW;
-    const size_t smem = ((size_t)PAIRS * (2 * 32 * (HD + 4) + 64) + (size_t)4 * 32 * (HD + 4)) * sizeof(float);
-    static const bool prio = [] { const char* e = getenv("ACT_ATTN_BWD_PRIO"); return e && e[0] == '1'; }();      // dev A/B knob
-    auto k = prio ? attn_bwd_one_kernel<HD, KW, true> : attn_bwd_one_kernel<HD, KW, false>;
+    const size_t smem = ((size_t)NP * (2 * 32 * (HD + 4) + 64) + (size_t)NP * KW * 32 * (HD + 4)) * sizeof(float);
+    auto k = attn_bwd_one_kernel<HD, KW, NP>;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
     const long long pairs = (long long)a.B * a.H;
-    hipLaunchKernelGGL(k, dim3((unsigned)((pairs + PAIRS - 1) / PAIRS)), dim3(256), smem, s, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)((pairs + NP - 1) / NP)), dim3(64 * KW * NP), smem, s, a);
     ACT_LAUNCH_CHECK();
     return 0;
 }
 static int launch_attn_bwd_one(const AttnRegArgs& a, int head_dim, hipStream_t s) {
     const int nkt = (a.S0 + a.S1 + 31) / 32;
-    if (head_dim == 64) return nkt <= 2 ? launch_attn_bwd_one_t<64, 2>(a, s) : launch_attn_bwd_one_t<64, 4>(a, s);
-    return nkt <= 2 ? launch_attn_bwd_one_t<32, 2>(a, s) : launch_attn_bwd_one_t<32, 4>(a, s);
+    static const int np2 = [] { const char* e = getenv("ACT_ATTN_BWD_NP"); return e ? atoi(e) : 2; }();     // pairs per workgroup at KW = 2 (dev A/B knob: 1 or 2)
+    if (head_dim == 64) return nkt <= 2 ? (np2 == 1 ? launch_attn_bwd_one_t<64, 2, 1>(a, s) : launch_attn_bwd_one_t<64, 2, 2>(a, s)) : launch_attn_bwd_one_t<64, 4, 1>(a, s);
+    return nkt <= 2 ? (np2 == 1 ? launch_attn_bwd_one_t<32, 2, 1>(a, s) : launch_attn_bwd_one_t<32, 2, 2>(a, s)) : launch_attn_bwd_one_t<32, 4, 1>(a, s);
 }
 static int launch_attn_bwd_reg(const AttnRegArgs& a, int head_dim, hipStream_t s) {
     if (g_attn_bwd_one) return launch_attn_bwd_one(a, head_dim, s);

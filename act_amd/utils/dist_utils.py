@@ -91,12 +91,16 @@ def pin_rank(local_rank, local_world, device_index=None, max_cores=None):
         info["reason"] = "ACT_PIN_CORES=0" if os.environ.get("ACT_PIN_CORES", "1") == "0" else ("single rank" if local_world <= 1 else "no sched_setaffinity")
         return info
     allowed = sorted(os.sched_getaffinity(0))
-    node = gpu_numa_cpus(device_index) if device_index is not None and torch.cuda.is_available() else None
-    ron = None
-    if node:
-        # ranks whose GPU sits on the same node: device i -> node, by the same sysfs walk (all ranks see all devices of the node)
-        same = [r for r in range(local_world) if (gpu_numa_cpus(r % max(1, torch.cuda.device_count())) or []) == node]
-        if local_rank in same:
+    node, ron = None, None
+    if device_index is not None and torch.cuda.is_available():
+        # the NUMA pools of ALL local ranks (every rank sees every device of the node and does the same sysfs walk, so all ranks decide alike): the NUMA-aware
+        # plan is used only when it works for every rank -- a cpuset that misses one GPU's node would otherwise mix plain and NUMA slices, which overlap
+        ndev = max(1, torch.cuda.device_count())
+        nodes = [gpu_numa_cpus(r % ndev) for r in range(local_world)]
+        aset = set(allowed)
+        if all(n and any(c in aset for c in n) for n in nodes):
+            node = nodes[local_rank]
+            same = [r for r in range(local_world) if nodes[r] == node]
             ron = (same.index(local_rank), len(same))
     cores = plan_affinity(allowed, local_rank, local_world, node, ron, max_cores)
     try:

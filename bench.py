@@ -23,6 +23,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
     os.environ["NCCL_DEBUG"] = "WARN"               # keep RCCL's version banner off stdout (one JSON line contract)
+os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # ... and whatever RCCL still has to say (e.g. its 'Missing "iommu=pt"' warning at init) goes to stderr
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

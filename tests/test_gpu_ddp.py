@@ -276,6 +276,8 @@ def test_bench_preflight_self_launched(tmp_path, gpus):
             assert pf["ranks_pinned"] == 2 and aff[0]["cores"] != aff[1]["cores"]
     else:
         assert pf["stack_chunk"] == 0 and not aff[0]["pinned"]
+        # the one-JSON-line contract on stdout also holds with RCCL initialised (its warnings go to stderr: NCCL_DEBUG_FILE)
+        assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[-1500:]
     assert "roofline" not in d and "cpu_baseline" not in d and "other_workloads" not in d
     print(f"[preflight] gpus={gpus}: wall {wall:.1f} s (in-process {pf['wall_s']} s), process group init {pf['process_group_init_s']} s, "
           f"all-reduce {pf['allreduce_ms']:.2f} ms, affinity {aff}")
