@@ -1458,7 +1458,9 @@ static int launch_attn_bwd_one_t(const AttnRegArgs& a, hipStream_t s) {
 }
 static int launch_attn_bwd_one(const AttnRegArgs& a, int head_dim, hipStream_t s) {
     const int nkt = (a.S0 + a.S1 + 31) / 32;
-    static const int np2 = [] { const char* e = getenv("ACT_ATTN_BWD_NP"); return e ? atoi(e) : 2; }();     // pairs per workgroup at KW = 2 (dev A/B knob: 1 or 2)
+    // pairs per workgroup at KW = 2 (ACT_ATTN_BWD_NP = 1 | 2): one pair per 128-thread workgroup spreads the 768 pairs of the student decoder over three workgroups
+    // per CU -- 50.3 -> 48.0 us (profiles/r06_attn_bwd_np_ab.txt)
+    static const int np2 = [] { const char* e = getenv("ACT_ATTN_BWD_NP"); return e ? atoi(e) : 1; }();
     if (head_dim == 64) return nkt <= 2 ? (np2 == 1 ? launch_attn_bwd_one_t<64, 2, 1>(a, s) : launch_attn_bwd_one_t<64, 2, 2>(a, s)) : launch_attn_bwd_one_t<64, 4, 1>(a, s);
     return nkt <= 2 ? (np2 == 1 ? launch_attn_bwd_one_t<32, 2, 1>(a, s) : launch_attn_bwd_one_t<32, 2, 2>(a, s)) : launch_attn_bwd_one_t<32, 4, 1>(a, s);
 }
