@@ -10,6 +10,7 @@
 // Tokenizer: hard gumbel-softmax + one-hot x codebook == argmax_n(logits + G) followed by a row gather, fused with the
 // head's GroupNorm + LeakyReLU so the [B,G,8192] logits are read exactly once and never rewritten.
 #include "common.h"
+#include <atomic>
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------- GN statistics
@@ -389,6 +390,177 @@ __global__ __launch_bounds__(256) void gn_lrelu_bwd_apply_kernel(const float* __
     }
 }
 
+// ---- LDS-resident forms of passes 1 and 3 (round 6; G <= 128) ------------------------------------------------------------------------------
+// The kernels above walk a chain of dependent global gathers per (g, neighbour) with four loads in flight per thread: 0.8 TB/s on the Stage-I shapes
+// (8,192 rows x 512 / 1,024 channels).  Here a workgroup = (sample, 64 channels) first copies its [G][64] slabs of Y (and Z) into LDS with coalesced,
+// independent loads -- every operand is read from HBM exactly once -- and all gathers become conflict-free LDS reads (lane = channel).
+// Pass 3 also replaces the four [G][64] scatter images by a GATHER over the incoming edges of each row: an inverse adjacency (CSR over the k G edges of
+// the sample, built in LDS by one thread per row) lists a row's edges in ascending (g, j); deterministic, same terms as the kernels above in another
+// fixed order (agreement to fp32 rounding: tests/test_gpu_dense.py).
+template <bool HASZ>
+__global__ __launch_bounds__(256) void edge_gn_bwd_partials_lds_kernel(const float* __restrict__ yz, int ldy, int zoff,
+                                                                       const int64_t* __restrict__ idx, int B, int G, int k, int C, int groups,
+                                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                       float slope, const float* __restrict__ dout, int ldd,
+                                                                       float* __restrict__ part) {
+    extern __shared__ float lds[];                          // Y slab [G][64] | idx [k][G] (int)
+    __shared__ float red[2][3][64];
+    float* ys = lds; int* es = reinterpret_cast<int*>(lds + (size_t)G * 64);
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    const bool live = c < C;
+    for (int r = gl; r < G; r += 4) ys[r * 64 + cl] = live ? yz[((size_t)b * G + r) * ldy + c] : 0.f;
+    for (int e = threadIdx.x; e < k * G; e += 256) es[e] = (int)idx[(size_t)b * k * G + e];
+    __syncthreads();
+    float sg = 0.f, sb = 0.f;
+    if (live) {
+        const int gi = c / (C / groups);
+        const float mu = mean[b * groups + gi], rs = rstd[b * groups + gi], gm = gamma[c], bt = beta[c], a = rs * gm;
+#pragma unroll 4
+        for (int g = gl; g < G; g += 4) {
+            float v = 0.f;
+            for (int j = 0; j < k; ++j) {
+                const float t = ys[es[j * G + g] * 64 + cl];
+                if (j == 0 || (a >= 0.f ? t > v : t < v)) v = t;
+            }
+            if (HASZ) v += yz[((size_t)b * G + g) * ldy + zoff + c];
+            const float xh = (v - mu) * rs;
+            const float y = xh * gm + bt;
+            const float da = dout[((size_t)b * G + g) * ldd + c] * (y > 0.f ? 1.f : slope);
+            sg += da * xh; sb += da;
+        }
+    }
+    if (gl > 0) { red[0][gl - 1][cl] = sg; red[1][gl - 1][cl] = sb; }
+    __syncthreads();
+    if (gl == 0 && live) {
+        part[((size_t)0 * B + b) * C + c] = (sg + red[0][0][cl]) + (red[0][1][cl] + red[0][2][cl]);
+        part[((size_t)1 * B + b) * C + c] = (sb + red[1][0][cl]) + (red[1][1][cl] + red[1][2][cl]);
+    }
+}
+// K = 4 (the DGCNN graphs) as a compile-time constant: with a runtime neighbour count the inner loops stay rolled and every LDS round trip of the dependent
+// chain index -> gather -> select is exposed (measured per phase on the Stage-I shapes: 19 + 37 + 29 us of a 104 us launch; 20 us is the HBM time).
+template <bool HASZ, int K>
+__global__ __launch_bounds__(256) void edge_gn_bwd_apply_lds_kernel(const float* __restrict__ yz, int ldy, int zoff,
+                                                                    const int64_t* __restrict__ idx, int B, int G, int C, int groups,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                                    const float* __restrict__ dout, int ldd, const float* __restrict__ mstat,
+                                                                    float* __restrict__ dyz) {
+    static_assert(K == 4, "edge list entries are int4 rows");
+    constexpr int MAXI = 32;                                 // rows per g-lane: G <= 128
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // Y [G][64] | Z [G][64] | da [G][64] | js [G][64] (int) | edges [G][K] (int, row g = its K source rows) | CSR [K G] (int: g << 8 | j)
+    float* ys = lds; float* zs = ys + (size_t)G * 64; float* das = zs + (size_t)G * 64;
+    int* jss = reinterpret_cast<int*>(das + (size_t)G * 64);
+    int* es = jss + (size_t)G * 64; int* csr = es + K * G;
+    __shared__ int s_base[128], s_tot[128];
+    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
+    const bool live = c < C;
+    const int ni = (G - gl + 3) >> 2;                       // rows g = gl + 4 i of this g-lane
+    // every global operand of the slab is requested up front: Y, Z -> LDS, dout -> registers (one value per (g, channel) of this thread)
+    float dreg[MAXI];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const int r = gl + 4 * i;
+        dreg[i] = 0.f;
+        if (i < ni) {
+            const size_t row = (size_t)b * G + r;
+            ys[r * 64 + cl] = live ? yz[row * ldy + c] : 0.f;
+            if (HASZ) zs[r * 64 + cl] = live ? yz[row * ldy + zoff + c] : 0.f;
+            if (live) dreg[i] = dout[row * ldd + c];
+        }
+    }
+    for (int e = threadIdx.x; e < K * G; e += 256) { const int j = e / G, g = e - j * G; es[g * K + j] = (int)idx[(size_t)b * K * G + e]; }
+    __syncthreads();
+    // inverse adjacency (CSR over the K G edges, edges of a row in ascending (g, j)): one thread per row, int4 reads of the edge table
+    const int4* e4 = reinterpret_cast<const int4*>(es);
+    if ((int)threadIdx.x < G) {
+        const int r = threadIdx.x;
+        int cnt = 0;
+#pragma unroll 8
+        for (int g = 0; g < G; ++g) { const int4 v = e4[g]; cnt += (v.x == r) + (v.y == r) + (v.z == r) + (v.w == r); }
+        s_tot[r] = cnt;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+        int acc = 0;
+        for (int q = 0; q < (int)threadIdx.x; ++q) acc += s_tot[q];
+        s_base[threadIdx.x] = acc;
+        const int r = threadIdx.x;
+        int p = acc;
+#pragma unroll 8
+        for (int g = 0; g < G; ++g) {
+            const int4 v = e4[g];
+            if (v.x == r) csr[p++] = (g << 8) | 0;
+            if (v.y == r) csr[p++] = (g << 8) | 1;
+            if (v.z == r) csr[p++] = (g << 8) | 2;
+            if (v.w == r) csr[p++] = (g << 8) | 3;
+        }
+    }
+    float mu = 0.f, rs = 0.f, gm = 0.f, bt = 0.f, a = 0.f, m1 = 0.f, m2 = 0.f;
+    if (live) {
+        const int gi = c / (C / groups);
+        mu = mean[b * groups + gi]; rs = rstd[b * groups + gi]; gm = gamma[c]; bt = beta[c]; a = rs * gm;
+        m1 = mstat[b * groups + gi]; m2 = mstat[(size_t)B * groups + b * groups + gi];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            if (i < ni) {
+                const int g = gl + 4 * i;
+                const int4 sv = e4[g];
+                const float t[K] = {ys[sv.x * 64 + cl], ys[sv.y * 64 + cl], ys[sv.z * 64 + cl], ys[sv.w * 64 + cl]};
+                float vs = t[0]; int js = 0;
+#pragma unroll
+                for (int j = 1; j < K; ++j) if (a >= 0.f ? t[j] > vs : t[j] < vs) { vs = t[j]; js = j; }      // first extremum wins (torch.max)
+                const float z = HASZ ? zs[g * 64 + cl] : 0.f;
+                const float xs = (vs + z - mu) * rs;
+                const float da = dreg[i] * (xs * gm + bt > 0.f ? 1.f : slope) * gm;
+                das[g * 64 + cl] = da; jss[g * 64 + cl] = js;
+                if (HASZ) {
+                    float dz = 0.f;
+#pragma unroll
+                    for (int j = 0; j < K; ++j) {
+                        const float xh = (t[j] + z - mu) * rs;
+                        dz += rs * ((j == js ? da : 0.f) - m1 - xh * m2);
+                    }
+                    dyz[((size_t)b * G + g) * ldy + zoff + c] = dz;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll 2
+        for (int i = 0; i < ni; ++i) {
+            const int r = gl + 4 * i;
+            const float yr = ys[r * 64 + cl];
+            const int base = s_base[r], n = s_tot[r];
+            float acc = 0.f;
+            for (int p0 = 0; p0 < n; p0 += 4) {                      // four edges per trip: their LDS reads are independent, the sum keeps the edge order
+                int e[4]; float zz[4], dd[4]; int jj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) e[u] = p0 + u < n ? csr[base + p0 + u] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int g = e[u] >= 0 ? e[u] >> 8 : 0;
+                    zz[u] = HASZ ? zs[g * 64 + cl] : 0.f; dd[u] = das[g * 64 + cl]; jj[u] = jss[g * 64 + cl];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (e[u] >= 0) {
+                        const float xh = (yr + zz[u] - mu) * rs;
+                        acc += rs * (((e[u] & 255) == jj[u] ? dd[u] : 0.f) - m1 - xh * m2);
+                    }
+            }
+            dyz[((size_t)b * G + r) * ldy + c] = acc;
+        }
+    }
+}
+static std::atomic<int> g_edge_bwd_lds{[] { const char* e = getenv("ACT_EDGE_BWD_LDS"); return e ? atoi(e) : 1; }()};
+// runtime switch (A/B, bit-identity test): 1 (default) = the LDS-resident backward passes where G <= 128, 0 = the global-gather kernels; on < 0 only reads
+extern "C" int act_edge_bwd_lds(int on) { return on < 0 ? g_edge_bwd_lds.load() : g_edge_bwd_lds.exchange(on ? 1 : 0); }
+
 extern "C" int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C, int groups,
                                              const float* gamma, const float* beta, const float* stats, float slope,
                                              const float* dout, int ldd, float* dyz, float* part /* [2][B][C] */,
@@ -399,11 +571,26 @@ extern "C" int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff,
     // compulsory bytes: y (and z) and dout read once, dy (and dz) written once, index list read once
     ActProfScope ps(KID_GN_LRELU_MAX, s, 0.0, 4.0 * B * G * (double)C * (2.0 * (zoff >= 0 ? 2 : 1) + 1.0) + 8.0 * B * G * (double)k);
     const float* mean = stats; const float* rstd = stats + (size_t)B * groups;
+    const bool use_lds = idx && G <= 128 && k == 4 && g_edge_bwd_lds.load() != 0;      // (k = 4: the DGCNN graphs; other neighbour counts keep the generic kernels)
+    if (use_lds) {
+        const size_t sm1 = ((size_t)G * 64 + (size_t)k * G) * sizeof(float);
+        if (zoff >= 0) hipLaunchKernelGGL(edge_gn_bwd_partials_lds_kernel<true>, dim3((C + 63) / 64, B), dim3(256), sm1, s, yz, ldy, zoff, idx, B, G, k, C, groups,
+                                          mean, rstd, gamma, beta, slope, dout, ldd, part);
+        else           hipLaunchKernelGGL(edge_gn_bwd_partials_lds_kernel<false>, dim3((C + 63) / 64, B), dim3(256), sm1, s, yz, ldy, zoff, idx, B, G, k, C, groups,
+                                          mean, rstd, gamma, beta, slope, dout, ldd, part);
+    } else
     hipLaunchKernelGGL(edge_gn_bwd_partials_kernel, dim3((C + 63) / 64, B), dim3(256), 0, s, yz, ldy, zoff, idx, B, G, k, C, groups, mean,
                        rstd, gamma, beta, slope, dout, ldd, part);
     const float inv_n = 1.0f / ((float)(C / groups) * (float)G * (float)k);
     hipLaunchKernelGGL(edge_gn_bwd_means_kernel, dim3(B * groups), dim3(256), 0, s, part, gamma, B, C, groups, inv_n, mstat);
-    if (!idx) {
+    if (use_lds) {
+        const size_t sm3 = ((size_t)4 * G * 64 + (size_t)2 * k * G) * sizeof(float);
+#define APPLY_LDS(Z) { auto kfn = edge_gn_bwd_apply_lds_kernel<Z, 4>; \
+            if (sm3 > 48 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3); if (e != hipSuccess) return (int)e; } \
+            hipLaunchKernelGGL(kfn, dim3((C + 63) / 64, B), dim3(256), sm3, s, yz, ldy, zoff, idx, B, G, C, groups, mean, rstd, gamma, beta, slope, dout, ldd, mstat, dyz); }
+        if (zoff >= 0) APPLY_LDS(true) else APPLY_LDS(false)
+#undef APPLY_LDS
+    } else if (!idx) {
         const long long total = (long long)B * G * C;
         hipLaunchKernelGGL(gn_lrelu_bwd_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, yz, G, C, groups, mean, rstd, gamma, beta,
                            slope, dout, ldd, mstat, B, dyz, total);

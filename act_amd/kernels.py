@@ -1062,6 +1062,7 @@ _C._declare({
     "act_edge_gn_lrelu_max_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _vp],
     "act_gn_gumbel_argmax_gather_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _u64, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "act_edge_gn_lrelu_max_bwd_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _vp, _vp],
+    "act_edge_bwd_lds": [_i],
     "act_gumbel_softmax_fwd_f32": [_vp, _i, _i, _vp, _u64, _f, _vp, _vp],
     "act_gumbel_softmax_bwd_f32": [_vp, _vp, _i, _i, _f, _vp, _vp],
     "act_kl_uniform_fwd_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -1070,7 +1071,7 @@ _C._declare({
 _C.lib.act_layernorm_bwd_workspace.restype = _sz
 _C.lib.act_colsum_workspace.restype = _sz
 _C.lib.act_colstats_workspace.restype = _sz
-for _n in ("act_edge_gn_lrelu_max_f32", "act_gn_gumbel_argmax_gather_f32", "act_edge_gn_lrelu_max_bwd_f32",
+for _n in ("act_edge_gn_lrelu_max_f32", "act_gn_gumbel_argmax_gather_f32", "act_edge_gn_lrelu_max_bwd_f32", "act_edge_bwd_lds",
            "act_gumbel_softmax_fwd_f32", "act_gumbel_softmax_bwd_f32", "act_kl_uniform_fwd_f32", "act_kl_uniform_bwd_f32"):
     _C.SIGNATURES.setdefault(_n, getattr(_C.lib, _n).argtypes)
 

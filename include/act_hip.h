@@ -320,6 +320,9 @@ int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, const int64_t*
 int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C, int groups,
                                   const float* gamma, const float* beta, const float* stats, float slope,
                                   const float* dout, int ldd, float* dyz, float* part, float* mstat, act_stream_t stream);
+/* runtime switch of the graph-layer passes of that backward (A/B and identity tests): 1 (default) = LDS-resident slabs + gather over an inverse
+ * adjacency where G <= 128 (round 6), 0 = the global-gather / scatter-image kernels; on < 0 only reads.  Returns the previous value. */
+int act_edge_bwd_lds(int on);
 /* Tokenizer head: logits = LeakyReLU(GroupNorm(h [B*G, C])); index = argmax_c((logits + gumbel) / tau);
  * out [B*G, D] = codebook[index]  (F.gumbel_softmax(hard=True) + einsum with the codebook, models/dvae.py:587-588).
  * noise [B*G, C] (nullable: Philox4x32-10 keyed by seed); index_out / logits_out nullable. */

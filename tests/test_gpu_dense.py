@@ -337,6 +337,43 @@ def test_dgcnn_edge_tail_backward(K, B, G, k, C):
     assert _rel(gn.weight.grad, wd2.grad) <= 5e-5 and _rel(gn.bias.grad, bd2.grad) <= 5e-5
 
 
+@pytest.mark.parametrize("B,G,k,C,with_z", [(3, 64, 4, 256, True), (2, 16, 4, 32, True), (2, 128, 3, 96, True), (4, 64, 4, 1024, True), (2, 64, 4, 128, False)])
+def test_dgcnn_edge_tail_backward_lds_form_matches_the_gather_scatter_kernels(K, B, G, k, C, with_z):
+    """round 6: the LDS-resident passes of the edge-conv tail backward (slabs of Y / Z staged once, gathers from LDS, dY as a gather over an inverse adjacency
+    that lists the incoming edges in the order the scatter images were filled) against the global-gather / scatter-image kernels they replace at G <= 128:
+    same terms in the same order (reported when bit-identical), two runs of the new form are bit-identical (deterministic, no atomics)."""
+    yz = _rnd(f"el.yz{G}{C}", B * G, 2 * C if with_z else C).cuda(); do = _rnd(f"el.do{G}{C}", B * G, C).cuda()
+    gw = _rnd(f"el.w{C}", C); gb = 0.1 * _rnd(f"el.b{C}", C)
+    gen = torch.Generator().manual_seed(G * 11 + C)
+    idx = torch.stack([torch.stack([torch.randint(0, G, (G,), generator=gen) for j in range(k)]) for b in range(B)])
+    idx[:, 0] = torch.arange(G)
+    idx[0, 1:, :] = 3                                              # a hub: one row collects (k - 1) G edges of sample 0
+    idx = idx.cuda()
+    gn = torch.nn.GroupNorm(4, C).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(gw); gn.bias.copy_(gb)
+    res = []
+    prev = K.lib.act_edge_bwd_lds(-1)
+    try:
+        for on in (0, 1, 1):
+            K.lib.act_edge_bwd_lds(on)
+            gn.zero_grad()
+            yg = yz.clone().requires_grad_(True)
+            out = K.edge_gn_lrelu_max_train(yg, C if with_z else -1, idx, B, G, k, C, gn)
+            (out * do).sum().backward()
+            torch.cuda.synchronize()
+            res.append((yg.grad.clone(), gn.weight.grad.clone(), gn.bias.grad.clone()))
+    finally:
+        K.lib.act_edge_bwd_lds(prev)
+    for a, b in zip(res[1], res[2]):
+        assert torch.equal(a, b)
+    same = all(torch.equal(a, b) for a, b in zip(res[0], res[1]))
+    print(f"[edge bwd lds] B={B} G={G} k={k} C={C} z={with_z}: bit-identical to the gather / scatter kernels: {same}")
+    for a, b in zip(res[0], res[1]):
+        assert _rel(b, a) <= 2e-6
+    assert res[1][0].abs().max() > 0
+
+
 @pytest.mark.parametrize("B,G,C,tau", [(2, 16, 64, 0.7), (3, 8, 8192, 1.0), (2, 5, 1000, 0.0625)])
 def test_soft_gumbel_softmax_and_kl_to_uniform(K, B, G, C, tau):
     """Stage-I tokenizer: F.gumbel_softmax(hard=False) with injected noise and the KL(mean softmax || uniform) term
