@@ -407,10 +407,12 @@ __global__ __launch_bounds__(256) void edge_gn_bwd_partials_lds_kernel(const flo
     extern __shared__ float lds[];                          // Y slab [G][64] | idx [k][G] (int)
     __shared__ float red[2][3][64];
     float* ys = lds; int* es = reinterpret_cast<int*>(lds + (size_t)G * 64);
-    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 63, gl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
     const bool live = c < C;
-    for (int r = gl; r < G; r += 4) ys[r * 64 + cl] = live ? yz[((size_t)b * G + r) * ldy + c] : 0.f;
+    const int cc = live ? c : C - 1;                        // unconditional loads (see the apply kernel): dead lanes read a valid column
+#pragma unroll 8
+    for (int r = gl; r < G; r += 4) ys[r * 64 + cl] = yz[((size_t)b * G + r) * ldy + cc];
     for (int e = threadIdx.x; e < k * G; e += 256) es[e] = (int)idx[(size_t)b * k * G + e];
     __syncthreads();
     float sg = 0.f, sb = 0.f;
@@ -440,7 +442,9 @@ __global__ __launch_bounds__(256) void edge_gn_bwd_partials_lds_kernel(const flo
 }
 // K = 4 (the DGCNN graphs) as a compile-time constant: with a runtime neighbour count the inner loops stay rolled and every LDS round trip of the dependent
 // chain index -> gather -> select is exposed (measured per phase on the Stage-I shapes: 19 + 37 + 29 us of a 104 us launch; 20 us is the HBM time).
-template <bool HASZ, int K>
+// MAXI = rows per g-lane as a compile-time bound (16: G <= 64, 32: G <= 128): the unrolled bodies are code, and the first version's 70 KB of it did not fit the
+// instruction cache two CUs share
+template <bool HASZ, int K, int MAXI>
 __global__ __launch_bounds__(256) void edge_gn_bwd_apply_lds_kernel(const float* __restrict__ yz, int ldy, int zoff,
                                                                     const int64_t* __restrict__ idx, int B, int G, int C, int groups,
                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -448,30 +452,34 @@ __global__ __launch_bounds__(256) void edge_gn_bwd_apply_lds_kernel(const float*
                                                                     const float* __restrict__ dout, int ldd, const float* __restrict__ mstat,
                                                                     float* __restrict__ dyz) {
     static_assert(K == 4, "edge list entries are int4 rows");
-    constexpr int MAXI = 32;                                 // rows per g-lane: G <= 128
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // Y [G][64] | Z [G][64] | da [G][64] | js [G][64] (int) | edges [G][K] (int, row g = its K source rows) | CSR [K G] (int: g << 8 | j)
+    // Y [G][64] | Z [G][64] | da [G][64] | js [G][64] (int) | edges [G][K] (int, row g = its K source rows) | CSR [K G + 1] (int: g << 8 | j; last = dump slot)
     float* ys = lds; float* zs = ys + (size_t)G * 64; float* das = zs + (size_t)G * 64;
     int* jss = reinterpret_cast<int*>(das + (size_t)G * 64);
     int* es = jss + (size_t)G * 64; int* csr = es + K * G;
     __shared__ int s_base[128], s_tot[128];
-    const int cl = threadIdx.x & 63, gl = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 63, gl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (wave-uniform: the row guards below are scalar branches)
     const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
     const bool live = c < C;
+    const int cc = live ? c : C - 1;                        // dead lanes of a ragged last slab read a valid column and store nothing
     const int ni = (G - gl + 3) >> 2;                       // rows g = gl + 4 i of this g-lane
-    // every global operand of the slab is requested up front: Y, Z -> LDS, dout -> registers (one value per (g, channel) of this thread)
-    float dreg[MAXI];
+    // every global operand of the slab is requested up front, UNCONDITIONALLY (a predicated load becomes an exec-masked branch with a full wait behind it:
+    // the first version serialised its 48 loads that way): Y, Z -> registers -> LDS, dout stays in registers (one value per (g, channel) of this thread)
+    float dreg[MAXI], yv[MAXI], zv[MAXI];
 #pragma unroll
     for (int i = 0; i < MAXI; ++i) {
-        const int r = gl + 4 * i;
-        dreg[i] = 0.f;
-        if (i < ni) {
-            const size_t row = (size_t)b * G + r;
-            ys[r * 64 + cl] = live ? yz[row * ldy + c] : 0.f;
-            if (HASZ) zs[r * 64 + cl] = live ? yz[row * ldy + zoff + c] : 0.f;
-            if (live) dreg[i] = dout[row * ldd + c];
-        }
+        const size_t row = (size_t)b * G + min(gl + 4 * i, G - 1);
+        yv[i] = yz[row * ldy + cc];
+        zv[i] = HASZ ? yz[row * ldy + zoff + cc] : 0.f;
+        dreg[i] = dout[row * ldd + cc];
     }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+        if (i < ni) {
+            const int r = gl + 4 * i;
+            ys[r * 64 + cl] = yv[i];
+            if (HASZ) zs[r * 64 + cl] = zv[i];
+        }
     for (int e = threadIdx.x; e < K * G; e += 256) { const int j = e / G, g = e - j * G; es[g * K + j] = (int)idx[(size_t)b * K * G + e]; }
     __syncthreads();
     // inverse adjacency (CSR over the K G edges, edges of a row in ascending (g, j)): one thread per row, int4 reads of the edge table
@@ -490,13 +498,14 @@ __global__ __launch_bounds__(256) void edge_gn_bwd_apply_lds_kernel(const float*
         s_base[threadIdx.x] = acc;
         const int r = threadIdx.x;
         int p = acc;
-#pragma unroll 8
+        const int dump = K * G;                              // branch-free fill: a non-matching edge is written to the dump slot
+#pragma unroll 4
         for (int g = 0; g < G; ++g) {
             const int4 v = e4[g];
-            if (v.x == r) csr[p++] = (g << 8) | 0;
-            if (v.y == r) csr[p++] = (g << 8) | 1;
-            if (v.z == r) csr[p++] = (g << 8) | 2;
-            if (v.w == r) csr[p++] = (g << 8) | 3;
+            csr[v.x == r ? p : dump] = (g << 8) | 0; p += v.x == r;
+            csr[v.y == r ? p : dump] = (g << 8) | 1; p += v.y == r;
+            csr[v.z == r ? p : dump] = (g << 8) | 2; p += v.z == r;
+            csr[v.w == r ? p : dump] = (g << 8) | 3; p += v.w == r;
         }
     }
     float mu = 0.f, rs = 0.f, gm = 0.f, bt = 0.f, a = 0.f, m1 = 0.f, m2 = 0.f;
@@ -537,21 +546,21 @@ __global__ __launch_bounds__(256) void edge_gn_bwd_apply_lds_kernel(const float*
             const float yr = ys[r * 64 + cl];
             const int base = s_base[r], n = s_tot[r];
             float acc = 0.f;
-            for (int p0 = 0; p0 < n; p0 += 4) {                      // four edges per trip: their LDS reads are independent, the sum keeps the edge order
+            for (int p0 = 0; p0 < n; p0 += 4) {                      // four edges per trip, branch-free: their LDS reads are independent, the sum keeps the edge order
                 int e[4]; float zz[4], dd[4]; int jj[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) e[u] = p0 + u < n ? csr[base + p0 + u] : -1;
+                for (int u = 0; u < 4; ++u) e[u] = csr[base + min(p0 + u, n - 1)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int g = e[u] >= 0 ? e[u] >> 8 : 0;
+                    const int g = e[u] >> 8;
                     zz[u] = HASZ ? zs[g * 64 + cl] : 0.f; dd[u] = das[g * 64 + cl]; jj[u] = jss[g * 64 + cl];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (e[u] >= 0) {
-                        const float xh = (yr + zz[u] - mu) * rs;
-                        acc += rs * (((e[u] & 255) == jj[u] ? dd[u] : 0.f) - m1 - xh * m2);
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const float xh = (yr + zz[u] - mu) * rs;
+                    const float term = rs * (((e[u] & 255) == jj[u] ? dd[u] : 0.f) - m1 - xh * m2);
+                    acc += p0 + u < n ? term : 0.f;
+                }
             }
             dyz[((size_t)b * G + r) * ldy + c] = acc;
         }
@@ -584,11 +593,12 @@ extern "C" int act_edge_gn_lrelu_max_bwd_f32(const float* yz, int ldy, int zoff,
     const float inv_n = 1.0f / ((float)(C / groups) * (float)G * (float)k);
     hipLaunchKernelGGL(edge_gn_bwd_means_kernel, dim3(B * groups), dim3(256), 0, s, part, gamma, B, C, groups, inv_n, mstat);
     if (use_lds) {
-        const size_t sm3 = ((size_t)4 * G * 64 + (size_t)2 * k * G) * sizeof(float);
-#define APPLY_LDS(Z) { auto kfn = edge_gn_bwd_apply_lds_kernel<Z, 4>; \
+        const size_t sm3 = ((size_t)4 * G * 64 + (size_t)2 * k * G + 4) * sizeof(float);
+#define APPLY_LDS(Z, MI) { auto kfn = edge_gn_bwd_apply_lds_kernel<Z, 4, MI>; \
             if (sm3 > 48 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm3); if (e != hipSuccess) return (int)e; } \
             hipLaunchKernelGGL(kfn, dim3((C + 63) / 64, B), dim3(256), sm3, s, yz, ldy, zoff, idx, B, G, C, groups, mean, rstd, gamma, beta, slope, dout, ldd, mstat, dyz); }
-        if (zoff >= 0) APPLY_LDS(true) else APPLY_LDS(false)
+        if (zoff >= 0) { if (G <= 64) APPLY_LDS(true, 16) else APPLY_LDS(true, 32) }
+        else           { if (G <= 64) APPLY_LDS(false, 16) else APPLY_LDS(false, 32) }
 #undef APPLY_LDS
     } else if (!idx) {
         const long long total = (long long)B * G * C;
