@@ -226,6 +226,67 @@ __global__ __launch_bounds__(EGF_THREADS) void edge_gn_fused_kernel(const float*
     }
 }
 
+// ---- slab form of the three-kernel path for graph layers whose (sample, group) slice does not fit the LDS (round 6: the stress geometry, G = 512) ----------
+// edge_gn_stats_kernel / edge_gn_apply_max_kernel walk k global gathers (and k int64 index loads) per output element: 0.57 TB/s of compulsory traffic at
+// 16,384 rows x 512 / 1,024 channels.  Here a workgroup = (sample, SW-channel slab) copies its [G][SW] slab of Y into LDS with unconditional, independent loads
+// (SW = 32 at G <= 512: 64 KB, two workgroups per CU), the k = 4 source rows of every g come from an int4 table in LDS, Z and the output are touched once,
+// coalesced.  Statistics: one partial (sum, sum of squares around the group's pivot) per slab, written into the GN_SPLIT slots of edge_gn_finalize_kernel
+// (a group has cpg / SW <= GN_SPLIT slabs; slab 0 zeroes the unused slots), so the finalize stage is shared with the generic path.
+template <int SW, bool APPLY>
+__global__ __launch_bounds__(256) void edge_gn_slab_kernel(const float* __restrict__ yz, int ldy, int zoff, const int64_t* __restrict__ idx, int G, int C,
+                                                           int groups, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                                                           float* __restrict__ part, float* __restrict__ out, int ldo, int ooff) {
+    constexpr int K = 4, GL = 256 / SW;                      // g-lanes per workgroup
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float sh[2][4];
+    float* ys = lds; int* es = reinterpret_cast<int*>(lds + (size_t)G * SW);        // Y slab [G][SW] | edges [G][K]
+    const int cl = threadIdx.x % SW, gl = threadIdx.x / SW;
+    const int c = blockIdx.x * SW + cl, b = blockIdx.y;                              // (C % SW == 0: every lane is live)
+    const int cpg = C / groups, gi = (blockIdx.x * SW) / cpg, c0 = gi * cpg;
+    const float* yb = yz + (size_t)b * G * ldy;
+#pragma unroll 8
+    for (int g = gl; g < G; g += GL) ys[g * SW + cl] = yb[(size_t)g * ldy + c];
+    for (int e = threadIdx.x; e < K * G; e += 256) { const int j = e / G, g = e - j * G; es[g * K + j] = (int)idx[(size_t)b * K * G + e]; }
+    __syncthreads();
+    const int4* e4 = reinterpret_cast<const int4*>(es);
+    if (!APPLY) {
+        // pivot = first element of the GROUP (what edge_gn_finalize_kernel adds back)
+        const int r00 = (int)idx[(size_t)b * K * G];
+        const float pv = yb[(size_t)r00 * ldy + c0] + yb[zoff + c0];
+        float s1 = 0.f, q1 = 0.f;
+#pragma unroll 4
+        for (int g = gl; g < G; g += GL) {
+            const int4 sv = e4[g];
+            const float z = yb[(size_t)g * ldy + zoff + c] - pv;
+            const float t[K] = {ys[sv.x * SW + cl] + z, ys[sv.y * SW + cl] + z, ys[sv.z * SW + cl] + z, ys[sv.w * SW + cl] + z};
+#pragma unroll
+            for (int j = 0; j < K; ++j) { s1 += t[j]; q1 += t[j] * t[j]; }
+        }
+        s1 = wave_sum_f32(s1); q1 = wave_sum_f32(q1);
+        if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = q1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nsl = cpg / SW, sl = (blockIdx.x * SW - c0) / SW;              // slabs per group, this slab's index inside its group
+            float* pp = part + ((size_t)(b * groups + gi) * GN_SPLIT) * 2;
+            pp[sl * 2 + 0] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+            pp[sl * 2 + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+            if (sl == 0) for (int u = nsl; u < GN_SPLIT; ++u) { pp[u * 2] = 0.f; pp[u * 2 + 1] = 0.f; }
+        }
+    } else {
+        const float mu = mean[b * groups + gi], a = rstd[b * groups + gi] * gamma[c], bt = beta[c];
+        float* ob = out + (size_t)b * G * ldo + ooff + c;
+#pragma unroll 4
+        for (int g = gl; g < G; g += GL) {
+            const int4 sv = e4[g];
+            const float t0 = ys[sv.x * SW + cl], t1 = ys[sv.y * SW + cl], t2 = ys[sv.z * SW + cl], t3 = ys[sv.w * SW + cl];
+            const float vmax = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)), vmin = fminf(fminf(t0, t1), fminf(t2, t3));
+            const float v = (a >= 0.f ? vmax : vmin) + yb[(size_t)g * ldy + zoff + c];
+            ob[(size_t)g * ldo] = lrelu((v - mu) * a + bt, slope);
+        }
+    }
+}
+
 extern "C" int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, const int64_t* idx, int B, int G, int k, int C,
                                          int groups, const float* gamma, const float* beta, float eps, float slope,
                                          float* stats /* [18][B*groups] */, float* out, int ldo, int ooff, act_stream_t stream) {
@@ -249,6 +310,25 @@ extern "C" int act_edge_gn_lrelu_max_f32(const float* yz, int ldy, int zoff, con
             }
             hipLaunchKernelGGL(edge_gn_fused_kernel, dim3(B * groups), dim3(EGF_THREADS), smem, s, yz, ldy, zoff, idx, G, k, C, groups, gamma, beta, eps, slope,
                                mean, rstd, out, ldo, ooff);
+            ACT_LAUNCH_CHECK(); return 0;
+        }
+    }
+    {   // slab form (round 6): graph layers with k = 4 whose slice is too large for the single-kernel path -- Y slab of 32 channels in LDS, G <= 512
+        static const bool slab = [] { const char* e = getenv("ACT_EDGE_GN_SLAB"); return !(e && e[0] == '0'); }();
+        const int cpg = C / groups;
+        constexpr int SW = 32;
+        const size_t smem = ((size_t)G * SW + (size_t)4 * G) * sizeof(float);
+        if (slab && idx && zoff >= 0 && k == 4 && (cpg % SW) == 0 && cpg / SW <= GN_SPLIT && smem <= 72 * 1024) {
+            auto ks = edge_gn_slab_kernel<SW, false>; auto ka = edge_gn_slab_kernel<SW, true>;
+            if (smem > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ks), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ka), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL(ks, dim3(C / SW, B), dim3(256), smem, s, yz, ldy, zoff, idx, G, C, groups, mean, rstd, gamma, beta, slope, part, out, ldo, ooff);
+            hipLaunchKernelGGL(edge_gn_finalize_kernel, dim3((B * groups + 63) / 64), dim3(64), 0, s, yz, ldy, zoff, idx, G, k, C, groups, B * groups,
+                               part, eps, mean, rstd);
+            hipLaunchKernelGGL(ka, dim3(C / SW, B), dim3(256), smem, s, yz, ldy, zoff, idx, G, C, groups, mean, rstd, gamma, beta, slope, part, out, ldo, ooff);
             ACT_LAUNCH_CHECK(); return 0;
         }
     }
