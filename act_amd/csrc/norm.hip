@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     float4* __restrict__ xo = xin_out ? reinterpret_cast<float4*>(xin_out + (size_t)row * D) : nullptr;
     const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gamma);
     const float4* __restrict__ b4 = reinterpret_cast<const float4*>(beta);
+    // (round 6: batching this kernel's loads the way layernorm_bwd_kernel does costs it two waves per SIMD of occupancy -- 117 VGPRs -- and was 5 % SLOWER: with one
+    //  row per wave and eight waves per SIMD the chunk-by-chunk round trips are already covered)
 #pragma unroll
     for (int i = 0; i < LN_MAXV; ++i) {
         const int c = lane + 64 * i;
@@ -98,9 +100,24 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
     for (int i = 0; i < MAXV; ++i) { ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i]; }
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(T, r0 + rows_per_block);
+    // Round 6: every load of a row is issued UNCONDITIONALLY and up front (lanes beyond the row read its last float4 and are masked in the arithmetic).  With the
+    // loads inside `if (c < nv)` each 64-lane chunk became an exec-masked block -- load, s_waitcnt vmcnt(0), compute, branch -- i.e. MAXV serialised memory round
+    // trips per row, and as many again for the residual gradient; gamma is loop-invariant and now loaded once per workgroup.  Same arithmetic per element (results can
+    // differ from the previous build in the last bit where hipcc's FMA contraction falls differently: Stage-I loss 0.8377311 vs 0.8377298 after 14 steps).
+    int cc[MAXV]; float4 gv[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { cc[i] = min(lane + 64 * i, nv - 1); gv[i] = g4[cc[i]]; }
     for (int row = r0 + wave; row < r1; row += NW) {
         const float4* __restrict__ dyr = reinterpret_cast<const float4*>(dy + (size_t)row * D);
         const float4* __restrict__ xr = reinterpret_cast<const float4*>(xin + (size_t)row * D);
+        const float4* __restrict__ drr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * D) : nullptr;
+        float4 dv[MAXV], xv[MAXV], rv[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) { dv[i] = dyr[cc[i]]; xv[i] = xr[cc[i]]; }
+        if (drr) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) rv[i] = drr[cc[i]];
+        }
         const float mu = mean[row], rs = rstd[row];
         float4 h[MAXV], w[MAXV];
         float s1 = 0.f, s2 = 0.f;
@@ -108,7 +125,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
             if (c < nv) {
-                const float4 d = dyr[c], x = xr[c], g = g4[c];
+                const float4 d = dv[i], x = xv[i], g = gv[i];
                 float4 xh; xh.x = (x.x - mu) * rs; xh.y = (x.y - mu) * rs; xh.z = (x.z - mu) * rs; xh.w = (x.w - mu) * rs;
                 float4 dg; dg.x = d.x * g.x; dg.y = d.y * g.y; dg.z = d.z * g.z; dg.w = d.w * g.w;
                 h[i] = xh; w[i] = dg;
@@ -120,7 +137,6 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
         }
         const float m1 = wave_sum_f32(s1) / (float)D, m2 = wave_sum_f32(s2) / (float)D;
         float4* __restrict__ dxr = reinterpret_cast<float4*>(dx + (size_t)row * D);
-        const float4* __restrict__ drr = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * D) : nullptr;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int c = lane + 64 * i;
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_bwd_kernel(const float* __r
                 float4 o;
                 o.x = rs * (w[i].x - m1 - h[i].x * m2); o.y = rs * (w[i].y - m1 - h[i].y * m2);
                 o.z = rs * (w[i].z - m1 - h[i].z * m2); o.w = rs * (w[i].w - m1 - h[i].w * m2);
-                if (drr) { const float4 r = drr[c]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+                if (drr) { const float4 r = rv[i]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
                 dxr[c] = o;
             }
         }
