@@ -50,7 +50,7 @@ def build(verbose=False, force=False):
     cc = hipcc()
     objs, jobs = [], []
     for src in sources():
-        flags = COMMON + PER_FILE.get(src, [])
+        flags = COMMON + PER_FILE.get(src, []) + os.environ.get("ACT_HIPCC_EXTRA", "").split()   # dev builds only (e.g. -DACT_ATTN_DIAG)
         path = os.path.join(CSRC, src)
         obj = os.path.join(OBJ, src[:-4] + ".o")
         sigf = obj + ".sig"

@@ -15,6 +15,10 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef ACT_ATTN_SOFTMAX_LEAN
+#define ACT_ATTN_SOFTMAX_LEAN 1          // 0: the round-1..5 form of the forward's online softmax (A/B builds: ACT_HIPCC_EXTRA=-DACT_ATTN_SOFTMAX_LEAN=0)
+#endif
 
 // General operand description: queries come from `q` (Sq rows per cloud), keys/values from up to two row segments
 // (segment 0: S0 rows, e.g. the prompt tokens of the teacher; segment 1: S1 rows).  Packed qkv is the special case
@@ -27,6 +31,8 @@ struct AttnFwdArgs {
     float scale;
     float* out; float* lse;              // out [B, Sq, H*HD]; lse [B, H, Sq] or null
     unsigned short* out_hi; unsigned short* out_lo;   // optional: out ALSO / ONLY (out == null) as (hi, lo) bf16 planes of the same layout (opt-in split-bf16 teacher)
+    int slot_prio;                       // > 0: static wave priority from the workgroup's CU slot (attn_slot_prio)
+    int stagger, stagger_mod;            // start-up de-phasing of the workgroups that share a CU: sleep (slot % stagger_mod) * stagger * 1024 cycles (0 = off)
 };
 
 // JT = 32-key tiles per LDS-resident key chunk (Sk <= 128: one chunk; longer sequences: chunks of 128 keys with an online
@@ -40,7 +46,33 @@ struct AttnFwdArgs {
 // Same products in the same order: bit-identical to VT = false (tests/test_gpu_dense.py).
 // NW (round 6) = waves per workgroup: 4, or 2 = ONE pair per workgroup at QT = 2 (Sq = 64: only the two query tiles of a pair share K / V, so a barrier need not couple two
 // pairs; 6 independent workgroups per CU instead of 3).  PRIO: s_setprio 1 around the MFMA bursts (waves in their softmax / staging phase yield the issue port).
-template <int HD, int JT, int QT, bool VT, int NW = 4, bool PRIO = false>
+// The workgroups of a single-round launch that share a CU start together and run their staging / MFMA / softmax phases in lock step (one resident round of
+// waves: the matrix pipe idles while all of them are in softmax).  De-phasing: the workgroup in CU slot t (HW_ID.TG_ID, wave-uniform, the same for every wave
+// of the workgroup; stagger < 0: slot taken from blockIdx.x / 256 instead) sleeps (t % mod) * |stagger| * 1024 cycles before its first load.
+__device__ __forceinline__ void attn_stagger(int stagger, int mod) {
+    if (stagger == 0) return;
+    unsigned slot;
+    if (stagger > 0) { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); slot = (hwid >> 16) & 15u; }
+    else { slot = blockIdx.x >> 8; stagger = -stagger; }
+    const int n = (int)(slot % (unsigned)mod) * stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
+// DIAG (dev ablation, ACT_ATTN_FWD_DIAG, results are WRONG when non-zero): 1 = every pair reads pair 0's operands (all fetches hit L2), 2 = no output store,
+// 4 = no exponentials (p = score), 8 = second product skipped, 16 = first product skipped, 32 = no barriers after the first chunk
+// Static priority by CU slot: the waves of the workgroups that share a SIMD run the same phases (MFMA burst, softmax, MFMA burst, staging) and the arbiter
+// serves equal priorities in turn, so they stay in lock step and the matrix pipe idles while all of them are in their VALU phase (ablation: time = skeleton
+// + MFMA, no overlap).  With DIFFERENT priorities the highest one owns the matrix pipe whenever it wants it and the others fill its VALU phases.
+__device__ __forceinline__ void attn_slot_prio(int mode) {
+    if (mode <= 0) return;
+    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const unsigned slot = mode == 2 ? (hwid & 15u) : ((hwid >> 16) & 15u);       // 1: workgroup slot on the CU (TG_ID); 2: wave slot on the SIMD (WAVE_ID)
+    switch (slot % 3u) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(1); break;
+    }
+}
+template <int HD, int JT, int QT, bool VT, int NW = 4, bool PRIO = false, int DIAG = 0>
 __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(const AttnFwdArgs a) {
     constexpr int NTHR = NW * 64;
     constexpr int LDK = HD + 4;
@@ -53,6 +85,8 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
     extern __shared__ __attribute__((aligned(16))) float smem[];    // [PAIRS][K image | V image]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, Sk = a.S0 + a.S1;
+    attn_stagger(a.stagger, a.stagger_mod);
+    attn_slot_prio(a.slot_prio);
     const long long npairs = (long long)a.B * H;
     const long long pair0 = (long long)blockIdx.x * PAIRS;
     const int qblock = blockIdx.y * (QT * 32);                       // first query row of this workgroup
@@ -60,12 +94,14 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
     const int pl = wave / QT, qt = wave % QT;
     const long long pr = pair0 + pl;
     const bool active = pl < PAIRS && pr < npairs && qblock + qt * 32 < a.Sq;
-    const int b = active ? (int)(pr / H) : 0, h = active ? (int)(pr % H) : 0;
+    const int b_true = active ? (int)(pr / H) : 0, h_true = active ? (int)(pr % H) : 0;
+    const int b = (DIAG & 1) ? 0 : b_true, h = (DIAG & 1) ? 0 : h_true;
     const float* Ks = smem + (size_t)pl * PSZ;
     const float* Vs = smem + (size_t)pl * PSZ + KSZ;
     const int ql = lane & 31, half = lane >> 5;
     const int q = qblock + qt * 32 + ql;
     const float scale = a.scale;
+    const float sc2 = scale * 1.44269504088896340736f;             // scale * log2(e)
 
     // ---- Q operand: lane (q, half) holds Q[q][half*HD/2 + s], s = 0..HD/2-1
     float qreg[HD / 2];
@@ -127,8 +163,8 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
         const unsigned pr2 = (unsigned)pair0 + p2;
         const bool live = (long long)pr2 < npairs;
         const unsigned b2 = live ? pr2 / (unsigned)H : 0u;
-        pb[p2] = __builtin_amdgcn_readfirstlane((int)b2);
-        ph[p2] = __builtin_amdgcn_readfirstlane((int)(live ? pr2 - b2 * (unsigned)H : 0u));
+        pb[p2] = (DIAG & 1) ? 0 : __builtin_amdgcn_readfirstlane((int)b2);
+        ph[p2] = (DIAG & 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(live ? pr2 - b2 * (unsigned)H : 0u));
     }
     const bool all_live = pair0 + PAIRS <= npairs;
     auto load_chunk = [&](int kc) {
@@ -181,7 +217,7 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
     };
     if constexpr (PF) load_chunk(0);
     for (int kc = 0; kc < Sk; kc += ROWS) {
-        if (kc > 0) __syncthreads();                                 // previous chunk fully consumed
+        if (kc > 0 && !(DIAG & 32)) __syncthreads();                 // previous chunk fully consumed
         if constexpr (PF) {
             // ---- this chunk of K and V (zero rows beyond Sk) for every pair of the workgroup: registers -> LDS, then request the next chunk
 #pragma unroll
@@ -228,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
                 }
             }
         }
-        __syncthreads();
+        if (!(DIAG & 32) || kc == 0) __syncthreads();
         if (!active) continue;                                       // idle waves only help staging
         // ---- S^T tiles: acc[jt][r] = score(key = kc + jt*32 + (r&3) + 8*(r>>2) + 4*half, query = ql)
         f32x16 acc[JT];
@@ -241,6 +277,7 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
 #pragma unroll
             for (int s4 = 0; s4 < HD / 8; ++s4) {
                 const float4 kk = *reinterpret_cast<const float4*>(kp + s4 * 4);
+                if constexpr ((DIAG & 16) != 0) { acc[jt][s4] += kk.x * qreg[s4 * 4] + kk.y + kk.z + kk.w; continue; }
                 acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[s4 * 4 + 0], acc[jt], 0, 0, 0);
                 acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[s4 * 4 + 1], acc[jt], 0, 0, 0);
                 acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[s4 * 4 + 2], acc[jt], 0, 0, 0);
@@ -268,6 +305,25 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
         }
         mc = fmaxf(mc, __shfl_xor(mc, 32));
         const float mn = fmaxf(m, mc);
+#if ACT_ATTN_SOFTMAX_LEAN
+        // exp(scale (s - m)) = exp2(s c - m c), c = scale log2(e): ONE packed FMA per two scores in front of v_exp_f32 instead of sub + mul + mul per score, and the
+        // row sum as packed adds.  On gfx950 no VALU instruction overlaps an f32 MFMA of the same SIMD (profiles/r06_mfma_valu_kinds.txt): every instruction removed
+        // here is matrix-pipe time.  (m c is rounded once: a score equal to the maximum gives exp2(+-1 ulp of m c) instead of exactly 1 -- 1e-7.)
+        const float mcn = mn * sc2;
+        const float alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m, sc2, -mcn));       // 0 on the first chunk (m = -huge)
+        m = mn;
+        f32x2 lc2 = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = __builtin_elementwise_fma(f32x2{acc[jt][r], acc[jt][r + 1]}, f32x2{sc2, sc2}, f32x2{-mcn, -mcn});
+                const f32x2 p = (DIAG & 4) ? t : f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};     // masked keys: exp2(-huge) == 0
+                acc[jt][r] = p[0]; acc[jt][r + 1] = p[1];
+                lc2 += p;
+            }
+        float lc = lc2[0] + lc2[1];
+#else
         const float alpha = __expf(scale * (m - mn));                // 0 on the first chunk (m = -huge)
         m = mn;
         float lc = 0.f;
@@ -275,10 +331,11 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
         for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(scale * (acc[jt][r] - m));    // masked keys: exp(-huge) == 0
+                const float p = (DIAG & 4) ? scale * (acc[jt][r] - m) : __expf(scale * (acc[jt][r] - m));    // masked keys: exp(-huge) == 0
                 acc[jt][r] = p;
                 lc += p;
             }
+#endif
         lc += __shfl_xor(lc, 32);
         l = l * alpha + lc;
         if (kc > 0) {
@@ -315,16 +372,19 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
                     const int key = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;   // this half-wave's k index for step r
                     const float* vp = Vs + (size_t)key * LDK + ql;
 #pragma unroll
-                    for (int dt = 0; dt < HD / 32; ++dt)
+                    for (int dt = 0; dt < HD / 32; ++dt) {
+                        if constexpr ((DIAG & 8) != 0) { o[dt][r] += vp[dt * 32] * acc[jt][r]; continue; }
                         o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], acc[jt][r], o[dt], 0, 0, 0);
+                    }
                 }
         }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     if (active && q < a.Sq) {
         const float inv_l = 1.0f / l;
-        const size_t obase = ((size_t)b * a.Sq + q) * (H * HD) + h * HD;
+        const size_t obase = ((size_t)b_true * a.Sq + q) * (H * HD) + h_true * HD;
         float* op = a.out ? a.out + obase : nullptr;
+        if constexpr ((DIAG & 2) != 0) { if (l != 12345.678f) op = nullptr; }
 #pragma unroll
         for (int dt = 0; dt < HD / 32; ++dt)
 #pragma unroll
@@ -346,7 +406,7 @@ __global__ __launch_bounds__(NW * 64, (JT == 1 ? 3 : 2)) void attn_fwd_kernel(co
                     *reinterpret_cast<uint2*>(a.out_lo + oi) = make_uint2(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16));
                 }
             }
-        if (a.lse && half == 0) a.lse[((size_t)b * H + h) * a.Sq + q] = scale * m + __logf(l);
+        if (a.lse && half == 0) a.lse[((size_t)b_true * H + h_true) * a.Sq + q] = scale * m + __logf(l);
     }
 }
 
@@ -1500,13 +1560,17 @@ static const bool g_attn_vt = [] { const char* e = getenv("ACT_ATTN_VT"); return
 // dev A/B knobs (round 6): ACT_ATTN_FWD_NW=2 -> one pair per 128-thread workgroup where QT == 2; ACT_ATTN_FWD_PRIO=1 -> s_setprio around the MFMA bursts
 static const int g_attn_fwd_nw = [] { const char* e = getenv("ACT_ATTN_FWD_NW"); return e ? atoi(e) : 4; }();
 static const bool g_attn_fwd_prio = [] { const char* e = getenv("ACT_ATTN_FWD_PRIO"); return e && e[0] == '1'; }();
-template <int HD, int JT, int QT, bool VT, int NW, bool PRIO>
-static int launch_attn_fwd4(const AttnFwdArgs& a, hipStream_t s) {
+template <int HD, int JT, int QT, bool VT, int NW, bool PRIO, int DIAG = 0>
+static int launch_attn_fwd4(const AttnFwdArgs& a0, hipStream_t s) {
     constexpr int pairs = NW / QT;
+    static const int stg = [] { const char* e = getenv("ACT_ATTN_FWD_STAGGER"); return e ? atoi(e) : 0; }();          // dev A/B knob (kernel comment)
+    static const int stg_mod = [] { const char* e = getenv("ACT_ATTN_FWD_STAGGER_MOD"); return e ? atoi(e) : 3; }();
+    static const int sprio = [] { const char* e = getenv("ACT_ATTN_FWD_SLOT_PRIO"); return e ? atoi(e) : 0; }();   // dev A/B knob (attn_slot_prio)
+    AttnFwdArgs a = a0; a.slot_prio = sprio; a.stagger = stg; a.stagger_mod = stg_mod > 0 ? stg_mod : 1;
     const size_t smem = (size_t)pairs * (JT * 32 * (HD + 4) + (VT ? HD * (JT * 32 + 4) : JT * 32 * (HD + 4))) * sizeof(float);
     const long long np = (long long)a.B * a.H;
     const unsigned gx = (unsigned)((np + pairs - 1) / pairs), gy = (unsigned)((a.Sq + QT * 32 - 1) / (QT * 32));
-    auto k = attn_fwd_kernel<HD, JT, QT, VT, NW, PRIO>;
+    auto k = attn_fwd_kernel<HD, JT, QT, VT, NW, PRIO, DIAG>;
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
@@ -1518,6 +1582,14 @@ static int launch_attn_fwd4(const AttnFwdArgs& a, hipStream_t s) {
 template <int HD, int JT, int QT>
 static int launch_attn_fwd3(const AttnFwdArgs& a, hipStream_t s) {
     const bool vt = g_attn_vt && (a.S0 % (JT * 32)) == 0;              // a key chunk must not straddle the two key segments (kernel comment)
+#ifdef ACT_ATTN_DIAG                                                     // only in a library built with ACT_HIPCC_EXTRA=-DACT_ATTN_DIAG (benchmarks/scripts/r06_run31.sh)
+    if constexpr (QT == 2 && JT == 1 && HD == 64) {                     // dev ablation of the teacher shape (kernel comment; wrong results)
+        static const int diag = [] { const char* e = getenv("ACT_ATTN_FWD_DIAG"); return e ? atoi(e) : 0; }();
+#define DG(D) if (diag == D) return launch_attn_fwd4<HD, JT, QT, false, 4, false, D>(a, s)
+        DG(1); DG(2); DG(3); DG(4); DG(8); DG(16); DG(24); DG(28); DG(31); DG(7); DG(32); DG(35); DG(39); DG(56); DG(63);
+#undef DG
+    }
+#endif
     if constexpr (QT == 2 && JT <= 2) {
         if (!vt && g_attn_fwd_nw == 2) return g_attn_fwd_prio ? launch_attn_fwd4<HD, JT, QT, false, 2, true>(a, s) : launch_attn_fwd4<HD, JT, QT, false, 2, false>(a, s);
         if (!vt && g_attn_fwd_prio) return launch_attn_fwd4<HD, JT, QT, false, 4, true>(a, s);
