@@ -652,7 +652,13 @@ def main():
                 continue
             out["roofline"]["mfma_util"] = {"percent_time_weighted": mu, "dominant": mu.get(dom),
                                             "source": "committed profile figure, not measured in this run: rocprofv3 --pmc MfmaUtil pass of this workload, "
-                                                      "profiles/" + os.path.basename(pf)}
+                                                      "profiles/" + os.path.basename(pf),
+                                            "attention_bound_note": "on gfx950 no VALU instruction of any wave issues while a v_mfma_f32_32x32x2_f32 of the same SIMD executes "
+                                                                    "(benchmarks/micro/mfma_valu_overlap.hip, mfma_valu_kinds.hip -> profiles/r06_mfma_valu_*.txt), so an f32 attention "
+                                                                    "kernel is bounded by MFMA time PLUS VALU time: forward 64 MFMAs (4,096 cycles) + 104 VALU instructions (~510 cycles) "
+                                                                    "per 32-key chunk and wave = 0.89 at best; at the teacher shape (64 q x 128 k) the launch, the un-overlapped HBM fill "
+                                                                    "(Q + first chunk of all 768 workgroups) and the drain (O) add ~15 us to 20.5 us of MFMA time "
+                                                                    "(profiles/r06_attn_fwd_ablation.txt)"}
             break
         # ---- FPS + kNN "Group" throughput (BASELINE metric part 2), hipEvents on the current stream ------------------
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
