@@ -49,11 +49,43 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int wg, int& ti
     tile_n = in_group / gsz;
 }
 
+// GELU (exact, erf form: nn.GELU() of the reference, utils/transformer_layers.py:130-139) in 14 VALU instructions instead of the ~28 of 0.5 x (1 + erff(x / sqrt 2)) on the
+// device library's two-branch erff.  On gfx950 no VALU instruction issues beside an f32 MFMA of the same SIMD (profiles/r06_mfma_valu_kinds.txt), so an epilogue's VALU count is
+// matrix-pipe time: the erff form cost 5 % of the teacher's fc1 launches and 12-13 % of the student's (profiles/r06_gelu_epilogue_ab.txt).
+//   e2(x) = 0.5 erfc(|x| / sqrt 2) = exp2(-(t h(t) + 1)),  t = |x| / sqrt 2,  h(t) = -log2(erfc(t)) / t  as ONE degree-8 polynomial on [0, 4] (weighted minimax fit,
+//   benchmarks/fit_gelu_poly.py; beyond t = 4 the polynomial argument is clamped and the exponent keeps falling linearly: e2 < 8e-9 there);
+//   gelu(x) = max(x, 0) - |x| e2(x);   gelu'(x) = Phi(x) + x phi(x),  Phi = x >= 0 ? 1 - e2 : e2  (no 1 + erf cancellation on the negative side).
+// Against the float64 function over [-12, 12]: max abs error 2.4e-7 (gelu) / 1.5e-7 (gelu'), rms 4e-8 / 2e-8 -- the fp32 erf form itself (torch CPU) has 1.2e-6 / 2.9e-7, rms 1.1e-7 / 4.5e-8.
+#ifndef ACT_GELU_FAST
+#define ACT_GELU_FAST 1                  // 0: the erff form of rounds 1-5 (A/B builds: ACT_HIPCC_EXTRA=-DACT_GELU_FAST=0)
+#endif
+__device__ __forceinline__ float gelu_half_erfc(float x) {           // 0.5 erfc(|x| / sqrt 2)
+    const float t = __builtin_fabsf(x) * 0.70710678118654752440f;
+    const float tc = __builtin_fminf(t, 4.0f);
+    float h = -5.621429409075063e-06f;
+    h = __builtin_fmaf(h, tc, 9.077531285583973e-05f);
+    h = __builtin_fmaf(h, tc, -0.0005887305014766753f);
+    h = __builtin_fmaf(h, tc, 0.0017150973435491323f);
+    h = __builtin_fmaf(h, tc, 0.0005855816416442394f);
+    h = __builtin_fmaf(h, tc, -0.028170492500066757f);
+    h = __builtin_fmaf(h, tc, 0.14846348762512207f);
+    h = __builtin_fmaf(h, tc, 0.918418288230896f);
+    h = __builtin_fmaf(h, tc, 1.62790846824646f);
+    return __builtin_amdgcn_exp2f(__builtin_fmaf(-h, t, -1.0f));
+}
+#if ACT_GELU_FAST
+__device__ __forceinline__ float gelu_f(float x) { return __builtin_fmaf(-__builtin_fabsf(x), gelu_half_erfc(x), __builtin_fmaxf(x, 0.0f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float e2 = gelu_half_erfc(x);
+    const float Phi = x >= 0.0f ? 1.0f - e2 : e2;
+    return __builtin_fmaf(x * 0.39894228040143267794f, __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f), Phi);
+}
+#else
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
-
+#endif
 // ACT: compile-time value of e.act (ACT_EPI_*), or -1 = decide at run time.  The run-time form inlines erff / expf for EVERY accumulator element
 // (64 per lane in a 128 x 128 tile): ~60 KB of code per kernel that the launches without an activation only jump over -- more than the
 // instruction cache two CUs share -- so the vector epilogues below take ONE uniform branch to a body specialised for the activation, and the launchers of

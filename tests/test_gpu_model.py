@@ -236,18 +236,46 @@ def test_stage1_tiny_golden(dev):
         # in ||e||/||r|| (tests/test_oracle_golden.py::test_stage1_tiny_gradient_conditioning; ReLU / LeakyReLU / max / arg-min
         # switch points within rounding distance).  Element-wise the HIP gradients are within 1e-4 of the oracle's (below).
         assert abs(pd[str(n)].grad.norm().item() - v) <= 5e-4 * max(1.0, v), (n, pd[str(n)].grad.norm().item(), v)
+    # ---- element-wise gradients against the oracle.  The discrete selections of this graph (ReLU / LeakyReLU kinks, max over points and neighbours, Chamfer
+    # arg-min) sit within rounding distance of a switch on most inputs: over twelve (cloud, noise) seeds the HIP gradients are either within ~3e-6 of the
+    # oracle's (every selection agrees) or off by 2e-4 .. 6e-3 in the rows one differing selection reroutes -- with the erff GELU of rounds 1-5 on 8 of the 12
+    # seeds, with the one-polynomial GELU of round 6 on 6 of them, and not the same ones (profiles/r06_stage1_tiny_grad_seeds.txt,
+    # benchmarks/diag/stage1_tiny_grad_diff.py).  A 1e-4 check on ONE seed therefore tests the luck of that seed (rounds 1-5: seed 777 at 9.2e-5).  Instead:
+    # on the golden's seed and on three more, every gradient must agree in the flip-tolerant sense (||e|| / ||r|| <= 5e-3: the reference arithmetic's own
+    # spread, test_oracle_golden.py::test_stage1_tiny_gradient_conditioning), and on at least ONE of the seeds every selection must agree -- where the bar is
+    # 1e-5, ten times tighter than the old check.
     from oracle import models as OM, layers as OL
-    torch.manual_seed(0)
-    ora = fill_module(OM.ACTPromptedDiscreteVAEwithVIT(OM.edict(cfg)), "g7.").train(); ora.prompt_p = 0.0
-    ro = ora(pts.cpu(), OL.Draws({"gumbel": _gumbel_noise((TINY_B, 16, 64))}), temperature=0.7, hard=False)
-    lo = ora.get_loss(ro); (lo[0] + 0.1 * lo[1]).backward()
-    od = dict(ora.named_parameters())
-    checked = 0
-    for n, p in pd.items():
-        if p.grad is not None and od[n].grad is not None:
-            assert _rel(p.grad, od[n].grad) <= TOL, (n, _rel(p.grad, od[n].grad))
-            checked += 1
-    assert checked >= 60
+
+    def seeded_noise(seed):
+        torch.manual_seed(seed)
+        return -torch.empty((TINY_B, 16, 64)).exponential_().log()
+
+    def hip_and_oracle_grads(cloud_seed, noise_seed):
+        p_ = torch.from_numpy(clouds(cloud_seed, TINY_B, TINY_N)).to(dev)
+        vae.zero_grad(set_to_none=True)
+        r_ = vae(p_, temperature=0.7, hard=False, draws=Draws({"gumbel": seeded_noise(noise_seed)}, device=dev))
+        a_, b_ = vae.get_loss(r_, p_); (a_ + 0.1 * b_).backward()
+        torch.manual_seed(0)
+        ora = fill_module(OM.ACTPromptedDiscreteVAEwithVIT(OM.edict(cfg)), "g7.").train(); ora.prompt_p = 0.0
+        ro = ora(p_.cpu(), OL.Draws({"gumbel": seeded_noise(noise_seed)}), temperature=0.7, hard=False)
+        lo = ora.get_loss(ro); (lo[0] + 0.1 * lo[1]).backward()
+        assert abs(a_.item() - lo[0].item()) <= TOL and abs(b_.item() - lo[1].item()) <= TOL
+        return {n: q.grad.detach().double().cpu() for n, q in vae.named_parameters() if q.grad is not None}, \
+               {n: q.grad.detach().double() for n, q in ora.named_parameters() if q.grad is not None}
+
+    flip_free = 0
+    for cloud_seed, noise_seed in ((4, 777), (6, 779), (9, 782), (13, 786)):
+        hg, og = hip_and_oracle_grads(cloud_seed, noise_seed)
+        common = [n for n in hg if n in og]
+        assert len(common) >= 60
+        worst = 0.0
+        for n in common:
+            l2 = ((hg[n] - og[n]).norm() / og[n].norm().clamp_min(1e-30)).item()
+            assert l2 <= 5e-3 or _rel(hg[n], og[n]) <= TOL, (noise_seed, n, "L2", l2, "max", _rel(hg[n], og[n]))
+            worst = max(worst, _rel(hg[n], og[n]))
+        print(f"[stage1 tiny] seed {noise_seed}: worst element-wise deviation {worst:.2e}" + ("  (every selection agrees)" if worst <= 1e-5 else "  (a selection differs)"))
+        flip_free += worst <= 1e-5
+    assert flip_free >= 1, "no seed on which HIP and oracle take the same discrete selections: element-wise agreement unverified"
 
 
 def test_plain_dvae_golden_and_oracle(dev):
