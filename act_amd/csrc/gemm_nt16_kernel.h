@@ -2,6 +2,7 @@
 // gemm_nt16_fx.hip: the fused mini-PointNet variants; two translation units so they compile in parallel)
 #pragma once
 #include "gemm_common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // NT specialisation (both operands K-contiguous in memory: every forward Linear / Conv1d(k=1)): the LDS image keeps the
@@ -15,6 +16,11 @@
 // tensor never exists in HBM); FX_COLSTATS leaves per-tile column (mean, sum of squared deviations) of the stored values for the
 // following BatchNorm (no statistics pass over the output); FX_GROUPMAX reduces every `group` consecutive rows to their max / first
 // arg-max (the max-pool over the points of a group) in the epilogue; FX_NOSTORE drops the C store when only that max is wanted.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 // ---- consumer passes of the fused mini-PointNet variants, after the epilogue (acc holds the values as stored: epilogue_rows<KEEP>): shared by the
 // compiler-scheduled kernel below and the hand-scheduled one (gemm_nt_asm_kernel.h).  `red`: >= 2 * BN floats of LDS no wave still reads.
 template <int BM, int BN, int FX, typename Acc>
@@ -113,6 +119,9 @@ __device__ __forceinline__ void nt_fx_tail(const GemmParams& p, Acc& acc, float*
     }
 }
 
+#ifndef ACT_NT16_BUFFER_LOADS
+#define ACT_NT16_BUFFER_LOADS 1     // 0: per-thread 64-bit pointers in the K loop as in rounds 1-5 (A/B builds: ACT_HIPCC_EXTRA=-DACT_NT16_BUFFER_LOADS=0)
+#endif
 #ifndef NT16_OCC_SMALL
 #define NT16_OCC_SMALL 3
 #endif
@@ -167,7 +176,26 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
     // registers by hipcc here and would round-trip through scratch memory in the main loop
     float4 ra0, ra1, rb0, rb1;
     ra0 = ra1 = rb0 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_g = [&](int t) {
+    // round 6: operand addresses as a wave-uniform base (SGPRs, advanced per K tile by scalar adds) + ONE 32-bit lane offset per load, so that the loop holds no
+    // 64-bit VALU pointer increments (8 v_lshl_add_u64 per K tile of 64 MFMAs before: on gfx950 every VALU instruction is matrix-pipe time).  The per-thread
+    // pointer form stays for the M-tail kernels and for listed row groups, whose rows are not affine in the tile origin.
+    const bool lin = !MG && !(FX != 0 && p.fx.row_groups != nullptr) && (size_t)BM * (size_t)p.lda < (1u << 29) && (size_t)BN * (size_t)p.ldb < (1u << 29);
+    const float* a_base = p.A + (size_t)m0 * p.lda + kbeg;
+    const float* b_base = p.B + (size_t)n0 * p.ldb + kbeg;
+    // (byte offsets from the tile's first row / column)
+    const unsigned a_of0 = ((unsigned)srow * (unsigned)p.lda + sch * 4) * 4u, a_of1 = a_of0 + 256u * (unsigned)p.lda;
+    const unsigned b_of0 = ((unsigned)srow_b * (unsigned)p.ldb + sch * 4) * 4u, b_of1 = b_of0 + 256u * (unsigned)p.ldb;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_base), 0, -1, 0x00020000);     // raw buffer, no bounds (full tiles only)
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(b_base), 0, -1, 0x00020000);
+    auto load_g = [&](auto lin_c, int t) {
+        if constexpr (decltype(lin_c)::value) {                      // buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen: no address arithmetic on the vector ALU
+            const int so = t * (BK * 4);
+            ra0 = buf_load4(rs_a, a_of0, so);
+            if constexpr (NA > 1) ra1 = buf_load4(rs_a, a_of1, so);
+            rb0 = buf_load4(rs_b, b_of0, so);
+            if constexpr (NB > 1) rb1 = buf_load4(rs_b, b_of1, so);
+            return;
+        }
         ra0 = *reinterpret_cast<const float4*>(ga + t * BK);
         if constexpr (NA > 1) ra1 = *reinterpret_cast<const float4*>(ga + stride_a + t * BK);
         rb0 = *reinterpret_cast<const float4*>(gb + t * BK);
@@ -194,15 +222,17 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
         if constexpr (NB > 1) *reinterpret_cast<float4*>(&Bs[buf][s_off + 1024]) = rb1;
     };
 
-    if (ntiles > 0) {
-        load_g(0);
-        store_lds(0, 0);
-        __syncthreads();
-    }
     const int kl = lane >> 4, ml = lane & 15;
     const int hsw = (4 - ((ml >> 2) & 3)) & 3;                        // row-block bases are multiples of 16: H depends on ml only
     const int a_off = (wm * (BM / 2) + ml) * 16 + 4 * (kl ^ hsw);
     const int b_off = (wn * (BN / 2) + ml) * 16 + 4 * (kl ^ hsw);
+    // the K loop, instantiated for both address forms (a run-time select inside ONE loop made the compiler fold them back into per-thread 64-bit pointers)
+    auto k_loop = [&](auto lin_c) {
+    if (ntiles > 0) {
+        load_g(lin_c, 0);
+        store_lds(0, 0);
+        __syncthreads();
+    }
     auto compute = [&](int buf) {
         float4 af[TM], bf[TN];
 #pragma unroll
@@ -260,30 +290,33 @@ __global__ __launch_bounds__(256, (BM * BN <= 128 * 64 && FX == 0) ? NT16_OCC_SM
         if (ntiles > 0) {                                   // (tile 0 is in LDS buffer 0 and visible: prologue above)
             Frag F0, F1;
             const int last = ntiles - 1;
-            load_g(min(1, last));
+            load_g(lin_c, min(1, last));
             read_frags(F0, 0);
-            store_lds(1, 0); load_g(min(2, last));
+            store_lds(1, 0); load_g(lin_c, min(2, last));
             lds_barrier();
             for (int t = 0; t < ntiles; t += 2) {
                 read_frags(F1, 1);
                 mfma_tile(F0);
-                store_lds(0, 0); load_g(min(t + 3, last));
+                store_lds(0, 0); load_g(lin_c, min(t + 3, last));
                 lds_barrier();
                 read_frags(F0, 0);
                 mfma_tile(F1);
-                store_lds(1, 0); load_g(min(t + 4, last));
+                store_lds(1, 0); load_g(lin_c, min(t + 4, last));
                 lds_barrier();
             }
         }
     } else {
     for (int t = 0; t + 1 < ntiles; ++t) {              // steady state: fetch tile t+1 while computing tile t
-        load_g(t + 1);
+        load_g(lin_c, t + 1);
         compute(t & 1);
         store_lds((t & 1) ^ 1, t + 1);
         __syncthreads();
     }
     if (ntiles > 0) compute((ntiles - 1) & 1);
     }
+    };
+    if constexpr (MG || !ACT_NT16_BUFFER_LOADS) k_loop(std::false_type{});
+    else { if (lin) k_loop(std::true_type{}); else k_loop(std::false_type{}); }
 
     {
         const int wu = __builtin_amdgcn_readfirstlane(wave);
