@@ -584,6 +584,8 @@ extern "C" int act_sgemm_ex_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
     p.xcd_rows = 0;
     if ((xcd_rows_env == 1 || xcd_rows_env == 2 || xcd_rows_env == 4) && p.tiles_m % xcd_rows_env == 0 && p.tiles_n % (8 / xcd_rows_env) == 0)
         p.xcd_rows = xcd_rows_env;
+    static const bool fastdiv_env = [] { const char* e = getenv("ACT_GEMM_FASTDIV"); return !(e && e[0] == '0'); }();   // dev A/B knob (gemm_set_tiling)
+    if (fastdiv_env) gemm_set_tiling(p);
     const long long nt = (long long)p.tiles_m * p.tiles_n;
     int kps = K;
     if (splits > 1) { kps = (K + splits - 1) / splits; kps = (kps + 31) / 32 * 32; splits = (K + kps - 1) / kps; }
@@ -693,6 +695,7 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         if (!(mask & FX_NOSTORE) && !C) return ACT_E_NULLPTR;
         const int tile = (N % 128 == 0) ? 0 : 1, BN = tile == 0 ? 128 : 64;
         p.tiles_m = M / 128; p.tiles_n = N / BN; p.k_per_split = K; p.partial = nullptr;
+        gemm_set_tiling(p);
         ActProfScope ps(KID_GEMM_NT, s, 2.0 * M * N * (double)K, 4.0 * ((double)M * K + (double)N * K + ((mask & FX_NOSTORE) ? 0.0 : (double)M * N)));
         // hand-scheduled main loop when every K tile is 32 deep (ACT_GEMM_FX_ASM=0: the compiler-scheduled kernels, for A/B runs); same bits either way
         const dim3 fgrid((unsigned)(p.tiles_m * p.tiles_n));
@@ -705,6 +708,7 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         if ((M % 128) || (N % 128) || (K % 16) || (M % fx->group)) return ACT_E_BADARG;
         if ((scatter & FX_SCATTER_EPI) && ((ldc & 3) || (reinterpret_cast<uintptr_t>(C) & 15))) return ACT_E_BADARG;
         p.tiles_m = M / 128; p.tiles_n = N / 128; p.k_per_split = K; p.partial = nullptr;
+        gemm_set_tiling(p);
         ActProfScope ps(KID_GEMM_NN, s, 2.0 * M * N * (double)K, 4.0 * ((double)N * K + (double)M * N));
         const dim3 qgrid((unsigned)(p.tiles_m * p.tiles_n));
         if (!((g_fx_asm.load() & 2) && launch_sgemm_q_asm_fx(p, 1, scatter, qgrid, s)) && !launch_sgemm_q16_fx(p, 1, scatter, qgrid, s)) return ACT_E_BADARG;
@@ -718,6 +722,7 @@ extern "C" int act_sgemm_fx_f32(int a_kmajor, int b_kmajor, int M, int N, int K,
         if (!mask || !C) return ACT_E_NULLPTR;
         if ((M % 128) || (N % 128) || (K % 32) || (scatter && (K % fx->group))) return ACT_E_BADARG;
         p.tiles_m = M / 128; p.tiles_n = N / 128;
+        gemm_set_tiling(p);
         const long long nt = (long long)p.tiles_m * p.tiles_n;
         int splits = (int)((768 + nt - 1) / nt);                       // ~3 workgroups per CU; K = rows of the batch, a few hundred thousand
         if (splits > 256) splits = 256;                                // (the 256 x 128 gradient of the second conv is 2 tiles: 64 ranges left half the chip idle)

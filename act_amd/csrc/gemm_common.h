@@ -34,12 +34,45 @@ struct GemmParams {
     int group_m;                     // tile rasterisation: GROUP_M tile rows are swept column by column (1 = plain row-major)
     int epi_vec;                     // quad epilogues: C / bias / residual / aux are 16-byte aligned with leading dimensions % 4 == 0 (float4 accesses)
     int xcd_rows;                    // 0: every XCD owns a contiguous band of the rasterised tile order; r (1, 2, 4): the 8 XCDs form an r x 8/r grid of tile blocks
+    // round 6: the divisions of the tile rasterisation as multiply-high by host-computed reciprocals (gemm_set_tiling).  All operands are wave-uniform, so this is
+    // scalar-ALU work; the compiler expands a run-time integer division into ~20 VECTOR instructions (v_cvt / v_rcp_iflag_f32 / v_mul_hi ...) even for uniform
+    // operands, and on gfx950 vector-ALU time is matrix-pipe time (profiles/r06_mfma_valu_kinds.txt).  div_ok = 0: plain divisions (>= 2^24 tiles, or not set).
+    unsigned mg_tn, mg_pg, mg_gm, mg_tail;     // ceil(2^sh / d) for d = tiles_n, group_m * tiles_n, group_m, tiles_m % group_m
+    int sh_tn, sh_pg, sh_gm, sh_tail;
+    int div_ok;
 };
+// n / d for n < 2^24 with m = ceil(2^sh / d), sh = 24 + ceil(log2 d): n m / 2^sh = n / d + n e / (d 2^sh), e = m d - 2^sh < d <= 2^(sh - 24), so the excess is < 1 / d: exact
+__device__ __forceinline__ int gemm_fastdiv(int n, unsigned m, int sh) { return (int)(((unsigned long long)(unsigned)n * m) >> sh); }
+inline void gemm_set_tiling(GemmParams& p) {
+    p.div_ok = 0;
+    const long long nwg = (long long)p.tiles_m * p.tiles_n;
+    if (nwg <= 0 || nwg >= (1ll << 24) || p.tiles_n <= 0) return;
+    auto mk = [](unsigned d, unsigned& m, int& sh) { int s = 0; while ((1u << s) < d) ++s; sh = 24 + s; m = (unsigned)(((1ull << sh) + d - 1) / d); };
+    mk((unsigned)p.tiles_n, p.mg_tn, p.sh_tn);
+    if (p.group_m > 1) {
+        if ((long long)p.group_m * p.tiles_n >= (1ll << 24)) return;
+        mk((unsigned)(p.group_m * p.tiles_n), p.mg_pg, p.sh_pg);
+        mk((unsigned)p.group_m, p.mg_gm, p.sh_gm);
+        const int tail = p.tiles_m % p.group_m;
+        mk((unsigned)(tail > 0 ? tail : 1), p.mg_tail, p.sh_tail);
+    }
+    p.div_ok = 1;
+}
 
 // linear workgroup index (after the XCD remap) -> tile coordinates.  Grouped order: the tiles a (band of) CUs works on at the same
 // time form a compact 2-D block, so both the A row-panels and the B column-panels they touch are re-used out of the XCD's L2
 // instead of one of them streaming from fabric for every tile row.
 __device__ __forceinline__ void tile_coords(const GemmParams& p, int wg, int& tile_m, int& tile_n) {
+    if (p.div_ok) {                                                   // same mapping as below, divisions by reciprocal multiplication (scalar ALU)
+        if (p.group_m <= 1) { tile_m = gemm_fastdiv(wg, p.mg_tn, p.sh_tn); tile_n = wg - tile_m * p.tiles_n; return; }
+        const int per_group = p.group_m * p.tiles_n;
+        const int group = gemm_fastdiv(wg, p.mg_pg, p.sh_pg), first_m = group * p.group_m;
+        const int gsz = min(p.tiles_m - first_m, p.group_m);          // group_m, or tiles_m % group_m in the last group
+        const int in_group = wg - group * per_group;
+        tile_n = gsz == p.group_m ? gemm_fastdiv(in_group, p.mg_gm, p.sh_gm) : gemm_fastdiv(in_group, p.mg_tail, p.sh_tail);
+        tile_m = first_m + in_group - tile_n * gsz;
+        return;
+    }
     if (p.group_m <= 1) { tile_m = wg / p.tiles_n; tile_n = wg % p.tiles_n; return; }
     const int per_group = p.group_m * p.tiles_n;
     const int group = wg / per_group, first_m = group * p.group_m;
