@@ -83,6 +83,35 @@ def test_gemm_epilogues(K):
     assert _rel(c, res.double().cpu() + 0.5 * base) <= 1e-5
 
 
+def test_gelu_epilogue_against_the_float64_function(K):
+    """The one-polynomial GELU / GELU gradient of the GEMM epilogues (csrc/gemm_common.h, round 6; nn.GELU() of utils/transformer_layers.py:130-139) on the device,
+    element by element against the float64 function: a product with the identity weight hands every x to the epilogue exactly.  Bars from the fp32 emulation of
+    benchmarks/fit_gelu_poly.py (2.4e-7 / 1.5e-7 max abs error; torch's own fp32 erf form has 1.2e-6 / 2.9e-7) with head-room for v_exp_f32 (1 ulp): 4e-7 max(1, |x|)
+    for the value, 4e-7 for the gradient -- and the tails: x = -100 gives -0 (not NaN, not -7e-7), x = +100 gives x."""
+    from scipy.special import erf
+    N = 128
+    g = torch.Generator().manual_seed(5)
+    xs = torch.cat([torch.linspace(-12, 12, 384 * N - 2048), torch.randn(2048 - 16, generator=g) * 1.5,
+                    torch.tensor([0.0, -0.0, 1e-30, -1e-30, 1e-6, -1e-6, 20.0, -20.0, 100.0, -100.0, 5.6568, -5.6568, 5.66, -5.66, 0.7071, -0.7071])]).float()
+    x = xs.view(-1, N).cuda().contiguous(); M = x.shape[0]
+    eye = torch.eye(N, device="cuda")
+    aux = torch.empty(M, N, device="cuda")
+    y = K.gemm(x, eye, act=K.EPI_GELU, aux=aux)
+    assert torch.equal(aux, x)                                        # the epilogue saw exactly x
+    xd = x.double().cpu().numpy()
+    ref = 0.5 * xd * (1.0 + erf(xd / np.sqrt(2.0)))
+    err = np.abs(y.double().cpu().numpy() - ref)
+    assert (err <= 4e-7 * np.maximum(1.0, np.abs(xd))).all(), (err.max(), xd.flat[err.argmax()])
+    ones = torch.ones(M, N, device="cuda")
+    gy = K.gemm(ones, eye, act=K.EPI_MUL_GELU_GRAD, aux=x)            # 1 * gelu'(x)
+    refg = 0.5 * (1.0 + erf(xd / np.sqrt(2.0))) + xd * np.exp(-0.5 * xd * xd) / np.sqrt(2.0 * np.pi)
+    errg = np.abs(gy.double().cpu().numpy() - refg)
+    assert errg.max() <= 4e-7, (errg.max(), xd.flat[errg.argmax()])
+    yl = y.cpu().view(-1)
+    assert yl[-8].item() == 100.0 and yl[-7].item() == 0.0 and yl[-10].item() == 20.0 and abs(yl[-9].item()) < 1e-20
+    assert torch.isfinite(y).all() and torch.isfinite(gy).all()
+
+
 @pytest.mark.parametrize("T,D,eps", [(1792, 384, 1e-5), (300, 768, 1e-6), (7, 64, 1e-5), (33, 128, 1e-5), (5, 2048, 1e-5)])
 def test_layernorm_fwd_bwd(K, T, D, eps):
     x = _rnd(f"ln.x{T}", T, D); pos = _rnd(f"ln.p{T}", T, D) * 0.3
